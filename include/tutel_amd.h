@@ -1,0 +1,168 @@
+/*
+ * tutel_amd.h -- C ABI of libtutel_amd.so: the MI355X (gfx950) implementation of Tutel's MoE
+ * forward hot path.  This is the drop-in boundary: plain pointers + sizes + a HIP stream, no
+ * torch types.  Every entry point names the reference interface it replaces (paths relative to
+ * microsoft/tutel @ 2025-02-04).  The reference reaches its native code through
+ *   - tutel_custom_kernel.invoke(list[Tensor], list[int], blocks, fd)        custom_kernel.cpp:255-275
+ *   - tutel_custom_kernel.invoke_cpu_fp32/fp64(list[Tensor], list[int], kt) custom_kernel.cpp:280-323
+ *   - torch.ops.tutel_ops.cumsum / sparse_bmm_infer                         custom_kernel.cpp:822-894
+ * and through ATen (topk / one_hot / cumsum / bmm) for the rest of the path; INTEGRATION.md
+ * shows the ctypes stub a maintainer would drop into tutel/impls/jit_compiler.py.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers (HBM), caller-allocated, contiguous unless strides
+ *     are part of the signature; outputs are written in place, nothing is returned but status;
+ *   - `stream` is a hipStream_t (NULL = the legacy default stream); every kernel is enqueued on
+ *     it and the call returns without synchronising (the reference launches on the *default*
+ *     stream, custom_kernel.cpp:268-274 -- taking the caller's current stream is deliberate);
+ *   - return value 0 = success; non-zero = error, text via tutel_amd_last_error().  Argument
+ *     errors are reported BEFORE anything is enqueued (mirrors CHECK_* -> c10::Error ->
+ *     RuntimeError in the reference, custom_kernel.cpp:37-42);
+ *   - not thread-safe per stream beyond what HIP guarantees; one process per GPU, like the
+ *     reference (custom_kernel.cpp:172,327-338).
+ *   - index layout: the k per-choice vectors of the reference's `indices_s / locations_s /
+ *     gates_s` lists (fast_dispatch.py:148,161-175) are rows of ONE [k, T] array.
+ */
+#ifndef TUTEL_AMD_H
+#define TUTEL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TUTEL_AMD_ABI_VERSION 1
+
+typedef void *tutel_stream_t; /* hipStream_t */
+
+/* element types of token / weight / score arrays */
+enum { TUTEL_F32 = 0, TUTEL_F16 = 1, TUTEL_BF16 = 2 };
+/* fused activation of the expert GEMM epilogue (experts/ffn.py:19-24,117) */
+enum { TUTEL_ACT_NONE = 0, TUTEL_ACT_RELU = 1, TUTEL_ACT_GELU = 2, TUTEL_ACT_SILU = 3 };
+
+/* ---- library info ----------------------------------------------------------------------- */
+int tutel_amd_abi_version(void);
+const char *tutel_amd_target_arch(void); /* "gfx950" */
+const char *tutel_amd_last_error(void);  /* thread-local text of the last failure */
+
+/* ---- routing -------------------------------------------------------
+ * Replaces the ATen op chain of extract_critical(), fast_dispatch.py:143-178:
+ *   softmax (moe_layer.py:290) -> torch.topk (:146) -> one_hot (:150) -> gates (:151,173-175)
+ *   -> k x fast_cumsum_sub_one (:159-171; GPU kernel custom_kernel.cpp:829-868)
+ *   -> dispatch_count (:177-178) -> gshard_loss inputs (losses.py:12-19).
+ *
+ * Scratch: `ws` must hold tutel_amd_routing_workspace_bytes(T, E, k) bytes; gate_topk fills it
+ * (per-tile expert histograms + per-tile score column sums), compute_location consumes it.
+ */
+size_t tutel_amd_routing_workspace_bytes(int T, int E, int k);
+
+/* in[T,E] (dtype): scores, or logits when apply_softmax != 0 (softmax over E in fp32, rounded
+ * to dtype, as F.softmax on a `dtype` tensor does).  Outputs:
+ *   scores_out [T,E] dtype  (optional, may be NULL; only meaningful with apply_softmax)
+ *   idx   [k,T] int32  descending score; EXACT ties -> lowest expert index (torch.topk leaves
+ *                      tie order unspecified; SURVEY section 7 hard part 1)
+ *   gates [k,T] dtype  scores[t, idx_k[t]], divided by clamp(sum_k, eps(dtype)) when
+ *                      normalize_gate != 0 and k > 1, each step rounded in `dtype` exactly as
+ *                      fast_dispatch.py:151,173-175 does.
+ * Limits: 1 <= k <= min(E, 16), E <= 1024. */
+int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax, int T, int E, int k,
+                        int normalize_gate, void *scores_out, int32_t *idx, void *gates, void *ws,
+                        size_t ws_bytes, tutel_stream_t stream);
+
+/* idx[k,T] -> loc[k,T] (stable rank of token t among tokens with the same k-th choice, queued
+ * after ALL tokens' earlier choices -- fast_dispatch.py:159-171), dispatch_count[E] (:177-178),
+ * stats[0] = max_e dispatch_count[e] (the dropless capacity before the all-reduce, :192),
+ * l_aux[0] = gshard loss in fp32 (losses.py:12-19; NULL to skip).
+ * hist_ready != 0: `ws` was filled by tutel_amd_gate_topk for the same (T,E,k) problem;
+ * hist_ready == 0: idx comes from elsewhere, the histograms are rebuilt here first (l_aux is
+ *                  then unavailable and must be NULL).
+ * capacity > 0 additionally builds slot_map[E*capacity] (see tutel_amd_slot_map); pass
+ * capacity <= 0 / slot_map NULL when the capacity is not known yet (capacity_factor <= 0). */
+int tutel_amd_compute_location(const int32_t *idx, int T, int E, int k, int hist_ready, void *ws,
+                               size_t ws_bytes, int32_t *loc, int32_t *dispatch_count,
+                               int32_t *stats, float *l_aux, int capacity, int32_t *slot_map,
+                               tutel_stream_t stream);
+
+/* slot_map[E*C]: for bucket row (e*C + c) the flat (choice,token) index j*T + t routed there,
+ * or -1 for an empty row.  Inverse of (idx, loc) restricted to loc < C && 0 <= idx < E -- the
+ * condition of the reference dispatch kernels, sparse.py:28-33 / custom_kernel.cpp:294.
+ * Needed because fast_encode here is bucket-major (one pass, writes the zero rows itself)
+ * instead of memset + k token-major launches (fast_dispatch.py:26-28). */
+int tutel_amd_slot_map(const int32_t *idx, const int32_t *loc, int T, int E, int k, int capacity,
+                       int32_t *slot_map, tutel_stream_t stream);
+
+/* Replaces torch.ops.tutel_ops.cumsum (custom_kernel.cpp:822-872) behind
+ * tutel.jit_kernels.gating.fast_cumsum_sub_one (gating.py:19-24): per-column inclusive
+ * cumsum - 1 of an int32 [T,E] array. */
+int tutel_amd_cumsum_sub_one(const int32_t *mask, int32_t *out, int T, int E,
+                             tutel_stream_t stream);
+
+/* ---- dispatch / combine --------------------------------------------
+ * fast_encode.  Replaces GatingEncoder.forward (fast_dispatch.py:18-29): torch.zeros +
+ * k launches of the `forward` kernel (sparse.py:21-35 | custom_kernel.cpp:293-300):
+ *   out[e*C + c, :] = g * x[t, :]  for the (j,t) in slot_map, g = gates[j,t] or 1 (gates NULL,
+ *   i.e. is_postscore=True); every other row = 0.  Math in fp32, one rounding to `dtype`
+ *   (fast_dispatch.py:95-96,126).  x [T,M], out [n_slots,M] in `dtype`; gates [k,T] gate_dtype. */
+int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *slot_map, const void *gates,
+                          int gate_dtype, int T, int M, int n_slots, void *out,
+                          tutel_stream_t stream);
+
+/* fast_decode.  Replaces GatingDecoder.forward (fast_dispatch.py:52-66): k launches of the
+ * `backward_data` kernel (sparse.py:42-64 | custom_kernel.cpp:301-312) each writing a [T,M]
+ * fp32 temp, summed left to right, then cast (:132):
+ *   out[t,:] = sum_j g_j[t] * buf[idx_j[t]*C + loc_j[t], :]   over j with loc < C && idx >= 0
+ * products and sums in fp32 in the reference's order (no FMA contraction), one rounding.
+ * gates NULL = all ones (is_postscore=False). Also serves GatingEncoder.backward (:31-38). */
+int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *idx, const int32_t *loc,
+                          const void *gates, int gate_dtype, int T, int M, int k, int capacity,
+                          void *out, tutel_stream_t stream);
+
+/* Gate gradient (backward only).  Replaces the `backward_gate` kernel
+ * (sparse.py:71-133 | custom_kernel.cpp:313-322):
+ *   ggate[j,t] = sum_m buf[idx_j[t]*C + loc_j[t], m] * x[t, m]   (0 when dropped), fp32 out. */
+int tutel_amd_gate_grad(const void *x, const void *buf, int dtype, const int32_t *idx,
+                        const int32_t *loc, int T, int M, int k, int capacity, float *ggate,
+                        tutel_stream_t stream);
+
+/* ---- expert FFN grouped GEMM -------------------------------------------
+ * One launch computes, for every local expert e and row r < R:
+ *     D[e, r, :] = act( A[e, r, :] @ op(W[e]) + bias[e, :] )         (fp32 accumulate on MFMA)
+ * Replaces each torch.matmul (+ torch.add bias, + activation) of FusedExpertsNetwork.forward,
+ * experts/ffn.py:114-120, and -- with row_counts -- torch.ops.tutel_ops.sparse_bmm_infer
+ * (custom_kernel.cpp:874-889, ffn.py:70-81) without its host loop / .cpu() sync.
+ *
+ *   w_kmajor = 1: W[e] is [N, K] row-major (batched_fc1_w [E_loc,H,M], ffn.py:26):  x @ W^T
+ *   w_kmajor = 0: W[e] is [K, N] row-major (batched_fc2_w [E_loc,H,M_out], :27):    x @ W
+ *
+ * Row addressing folds the expert-parallel permutes (communicate.py:606-622) into the GEMM:
+ * row r of expert e lives at
+ *     A + e*a_stride_e + (r / a_rows_per_w)*a_stride_w + (r % a_rows_per_w)*lda      (elements)
+ * so A may be the raw all-to-all output [W, E_loc, C, M] (a_rows_per_w = C) and D the raw
+ * all-to-all input, with no .contiguous() copy in between.  For a plain [E_loc, R, K] array use
+ * a_rows_per_w = R, a_stride_w = 0.
+ *
+ * row_counts (device int32[E_loc], may be NULL): rows >= ceil(count/row_align)*row_align of
+ * expert e are skipped and left unwritten, exactly the rows sparse_bmm_infer leaves
+ * uninitialised (custom_kernel.cpp:878-886).
+ *
+ * dtype: TUTEL_BF16 or TUTEL_F16 (fp32/fp64 experts stay on the ATen/rocBLAS bmm).
+ * Requirements: K % 64 == 0, N % 8 == 0, lda/ldw/ldd and strides % 8 == 0 (16-byte rows). */
+int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t a_stride_w, int a_rows_per_w,
+                          int lda, const void *W, int w_kmajor, int64_t w_stride_e, int ldw,
+                          const void *bias, int64_t bias_stride_e, void *D, int64_t d_stride_e,
+                          int64_t d_stride_w, int d_rows_per_w, int ldd, int E_loc, int R, int N,
+                          int K, int dtype, int act, const int32_t *row_counts, int row_align,
+                          tutel_stream_t stream);
+
+/* ---- self-test helpers (used by tests / smoke only) ---------------------------------------
+ * Dumps the lane->element permutation of ds_read_b64_tr_b16 (the transposing LDS read the
+ * [K,N]-weight GEMM relies on): out[64*4] uint16, LDS pre-filled with lds[i] = i, lane l
+ * reading 8 bytes at byte address l*8. */
+int tutel_amd_probe_tr16(uint16_t *out, tutel_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUTEL_AMD_H */

@@ -1,0 +1,312 @@
+"""
+oracle/moe_oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+CPU restatement of the reference's MoE *forward* hot path (microsoft/tutel @ 2025-02-04):
+gate -> softmax -> top-k routing (compute_location) -> fast_encode -> all-to-all layout ->
+per-expert FFN -> all-to-all layout -> fast_decode.  Every function cites the reference lines
+it follows (paths relative to /root/reference).
+
+Who may use this file: tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg --
+as the checker only.  Nothing under tutel_amd/ imports it; the product fails loudly when its
+HIP library is missing instead of falling back to this code.
+
+How it is pinned (so that "parity" means parity with the reference, not with ourselves):
+  * tests/test_oracle_vs_reference.py runs the reference itself in this container (python
+    package from /root/reference + its C++ CPU kernels compiled into oracle/_ref/ by
+    oracle/Makefile) and checks every function below against it on seeded inputs;
+  * tests/golden/*.npz are outputs of that reference (generator tests/golden/make_golden.py)
+    and are replayed against this oracle on any box (tests/test_oracle_golden.py).
+
+Arithmetic split: integer/index work and the scatter/gather loops are plain C
+(oracle/moe_oracle.c via ctypes); softmax / matmul / dtype rounding use torch-CPU ATen ops,
+which is precisely what the reference calls on its own CPU path (torch 2.10.0 in this image).
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libmoe_oracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "libmoe_oracle.so"])
+        _LIB = ctypes.CDLL(path)
+    return _LIB
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------------------------------------
+# routing
+# ---------------------------------------------------------------------------------------------
+def topk_indices(scores, k):
+    """k index vectors [T] int32: descending score, ties -> lowest expert index.
+    Reference: fast_dispatch.py:146-148 (torch.topk; tie order unspecified there, pinned here)."""
+    T, E = scores.shape
+    k = min(k, E)
+    idx = torch.empty([k, T], dtype=torch.int32)
+    if scores.dtype == torch.float64:
+        s = scores.contiguous()
+        _lib().orc_topk_f64(_p(s), T, E, k, _p(idx))
+    else:
+        s = scores.float().contiguous()  # bf16/fp16 -> fp32 is exact, ordering preserved
+        _lib().orc_topk_f32(_p(s), T, E, k, _p(idx))
+    return [idx[j].clone() for j in range(k)]
+
+
+def cumsum_sub_one(mask):
+    """Reference: jit_kernels/gating.py:13-15,19-24 (torch.cumsum(mask,0)-1)."""
+    m = mask.to(torch.int32).contiguous()
+    out = torch.empty_like(m)
+    _lib().orc_cumsum_sub_one_i32(_p(m), m.shape[0], m.shape[1], _p(out))
+    return out
+
+
+def compute_locations(idx_list, E):
+    """(loc_list, dispatch_count). Reference: fast_dispatch.py:150,159-171,177-178."""
+    k, T = len(idx_list), idx_list[0].numel()
+    idx = torch.stack([x.to(torch.int32).view(-1) for x in idx_list]).contiguous()
+    loc = torch.empty_like(idx)
+    cnt = torch.empty([E], dtype=torch.int32)
+    _lib().orc_compute_locations(_p(idx), T, E, k, _p(loc), _p(cnt))
+    return [loc[j].clone() for j in range(k)], cnt
+
+
+def gshard_loss(scores, idx0):
+    """Reference: losses.py:12-19 (only the FIRST choice enters the loss)."""
+    T, E = scores.shape
+    mask = torch.zeros([T, E], dtype=scores.dtype)
+    mask.scatter_(1, idx0.long().unsqueeze(-1), E / T)
+    me = torch.sum(scores, dim=0)
+    ce = torch.sum(mask, dim=0)
+    return torch.sum(me * ce) / T
+
+
+def capacity_of(T, E, k, capacity_factor, dispatch_count, alignment=1):
+    """Reference: fast_dispatch.py:188-199 (single rank: the all-reduce MAX is the identity)."""
+    spe = (T + E - 1) // E
+    if capacity_factor > 0:
+        cap = k * int(capacity_factor * spe)
+    else:
+        cap = int(dispatch_count.max())
+        if capacity_factor < 0:
+            cap = min(cap, k * int(-capacity_factor * spe))
+    rem = cap % alignment
+    if rem > 0:
+        cap += alignment - rem
+    return cap
+
+
+def extract_critical(scores, top_k, capacity_factor=1.0, normalize_gate=True, alignment=1,
+                     with_loss=True, topk_override=None):
+    """Reference: fast_dispatch.py:143-204 (batch_prioritized_routing=False).
+    Returns ((E, idx_list, loc_list, gate_list, capacity, dispatch_count), l_aux).
+    `topk_override`: inject the reference's own topk indices (used to compare everything
+    downstream of a tie independently of the tie rule)."""
+    T, E = scores.shape
+    k = min(top_k, E)
+    idx_list = topk_override if topk_override is not None else topk_indices(scores, k)
+    # gates_s[k] = (scores * one_hot).sum(1) == scores[t, idx_k[t]] exactly (:150-151)
+    gates = [scores.gather(1, i.long().unsqueeze(-1)).squeeze(-1) for i in idx_list]
+    l_aux = gshard_loss(scores, idx_list[0]) if with_loss else None
+    loc_list, cnt = compute_locations(idx_list, E)
+    if k > 1 and normalize_gate:  # :173-175 -- python sum(): ((0 + g0) + g1) ... in scores dtype
+        denom = torch.clamp(sum(gates), min=torch.finfo(gates[0].dtype).eps)
+        gates = [g / denom for g in gates]
+    cap = capacity_of(T, E, k, capacity_factor, cnt, alignment)
+    return (E, idx_list, loc_list, gates, cap, cnt), l_aux
+
+
+# ---------------------------------------------------------------------------------------------
+# dispatch / combine
+# ---------------------------------------------------------------------------------------------
+def _dispatch_dtype(dtype):
+    # fast_dispatch.py:94-96: fp32 unless (fp16 on a CUDA build); this image's torch is a HIP
+    # build, where the reference always dispatches in fp32 -- fp64 inputs included.
+    return torch.float32
+
+
+def fast_encode(x, crit, is_postscore=True):
+    """[T,M] -> [E,C,M].  Reference: fast_dispatch.py:209-214,101-128,18-29 and the CPU kernel
+    custom_kernel.cpp:293-300."""
+    E, idx_list, loc_list, gates, C, _ = crit
+    T, M = x.shape
+    dt = _dispatch_dtype(x.dtype)
+    xin = x.to(dt).contiguous()
+    out = torch.zeros([E * C, M], dtype=dt)
+    for j in range(len(idx_list)):
+        g = torch.ones([T], dtype=dt) if is_postscore else gates[j].to(dt).contiguous()
+        i32 = idx_list[j].to(torch.int32).contiguous()
+        l32 = loc_list[j].to(torch.int32).contiguous()
+        _lib().orc_encode_f32(_p(g), _p(i32), _p(l32), _p(xin), _p(out), T, M, C)
+    return out.to(x.dtype).view(E, C, M)
+
+
+def fast_decode(y, crit, is_postscore=True):
+    """[E,C,M] -> [T,M].  Reference: fast_dispatch.py:216-221,130-134,52-66 and the CPU kernel
+    custom_kernel.cpp:301-312; the k temps are summed left to right in fp32, one final cast."""
+    E, idx_list, loc_list, gates, C, _ = crit
+    M = y.shape[-1]
+    T = idx_list[0].numel()
+    dt = _dispatch_dtype(y.dtype)
+    buf = y.reshape(E * C, M).to(dt).contiguous()
+    acc = None
+    for j in range(len(idx_list)):
+        g = gates[j].to(dt).contiguous() if is_postscore else torch.ones([T], dtype=dt)
+        i32 = idx_list[j].to(torch.int32).contiguous()
+        l32 = loc_list[j].to(torch.int32).contiguous()
+        tmp = torch.empty([T, M], dtype=dt)
+        _lib().orc_decode_f32(_p(g), _p(i32), _p(l32), _p(tmp), _p(buf), T, M, C)
+        acc = tmp if acc is None else acc + tmp
+    return acc.to(y.dtype)
+
+
+def gate_grad(x, buf, idx, loc, C):
+    """Reference: custom_kernel.cpp:313-322 (backward only)."""
+    T, M = x.shape
+    xin, b = x.float().contiguous(), buf.reshape(-1, M).float().contiguous()
+    out = torch.empty([T], dtype=torch.float32)
+    _lib().orc_gate_grad_f32(_p(out), _p(idx.to(torch.int32).contiguous()),
+                             _p(loc.to(torch.int32).contiguous()), _p(xin), _p(b), T, M, C)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# experts / gate
+# ---------------------------------------------------------------------------------------------
+def expert_ffn(x, w1, b1, w2, b2, act=torch.relu, accum_fp32=False):
+    """x [E_loc,R,M]; w1 [E_loc,H,M]; w2 [E_loc,H,M_out]; b1 [E_loc,H]; b2 [E_loc,M_out].
+    Reference: experts/ffn.py:114-120.  accum_fp32=False reproduces the reference op by op in
+    the tensors' own dtype (ATen bmm rounds after each op); accum_fp32=True computes in fp32 on
+    the same (already rounded) inputs and rounds the hidden activation and the output once --
+    the tolerance anchor for the fused bf16/fp16 MFMA kernel (SURVEY section 7 hard part 7)."""
+    if not accum_fp32:
+        y = torch.matmul(x, w1.permute(0, 2, 1))
+        if b1 is not None:
+            y = torch.add(y, b1.unsqueeze(1))
+        y = act(y)
+        y = torch.matmul(y, w2)
+        if b2 is not None:
+            y = torch.add(y, b2.unsqueeze(1))
+        return y
+    dt = x.dtype
+    h = torch.matmul(x.float(), w1.float().permute(0, 2, 1))
+    if b1 is not None:
+        h = h + b1.float().unsqueeze(1)
+    h = act(h).to(dt).float()
+    y = torch.matmul(h, w2.float())
+    if b2 is not None:
+        y = y + b2.float().unsqueeze(1)
+    return y.to(dt)
+
+
+def gate_scores(x, wg, fp32_gate=False):
+    """Reference: gates/top.py:20-22 and moe_layer.py:290.  Returns (scores, logits_dtype)."""
+    w = wg.float() if fp32_gate else wg
+    logits = torch.nn.functional.linear(x.to(w.dtype), w)
+    return torch.softmax(logits, dim=1), logits.dtype
+
+
+# ---------------------------------------------------------------------------------------------
+# all-to-all layout (W ranks simulated in one process)
+# ---------------------------------------------------------------------------------------------
+def a2a_dispatch(per_rank):
+    """list of W tensors [E,C,M] (one per source rank) -> list of W tensors [E_loc, W*C, M].
+    Reference: communicate.py:181-192,447-503 (all_to_all(y,1,0)) + :606-613."""
+    W = len(per_rank)
+    E, C, M = per_rank[0].shape
+    E_loc = E // W
+    send = torch.stack([t.contiguous() for t in per_rank]).contiguous()
+    recv = torch.empty_like(send)
+    _lib().orc_a2a_dispatch_layout(_p(send), _p(recv), W, E_loc, C, M, send.element_size())
+    return [recv[d].view(E_loc, W * C, M) for d in range(W)]
+
+
+def a2a_combine(per_rank, C):
+    """inverse of a2a_dispatch: list of W [E_loc, W*C, M] -> list of W [E, C, M].
+    Reference: communicate.py:447-503 (all_to_all(y,0,1)) + :615-622."""
+    W = len(per_rank)
+    E_loc, R, M = per_rank[0].shape
+    out = [torch.empty([W * E_loc, C, M], dtype=per_rank[0].dtype) for _ in range(W)]
+    for d in range(W):
+        v = per_rank[d].view(E_loc, W, C, M)
+        for s in range(W):
+            out[s].view(W, E_loc, C, M)[d] = v[:, s]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# the layer
+# ---------------------------------------------------------------------------------------------
+def moe_forward(x, wg, w1, b1, w2, b2, top_k=2, capacity_factor=1.0, fp32_gate=False,
+                normalize_gate=True, is_postscore=True, act=torch.relu, alignment=1,
+                accum_fp32=False, topk_override=None):
+    """Single-rank MOELayer.forward.  Reference: moe_layer.py:255-363 (dtype chain :264-270,
+    :327, :359-361).  x [..., M] -> (y [..., M_out], l_aux, crit, stages dict)."""
+    orig_shape, orig_dtype = x.shape, x.dtype
+    M = orig_shape[-1]
+    xr = x.reshape(-1, M).to(w1.dtype)
+    scores, logits_dtype = gate_scores(xr, wg, fp32_gate)
+    crit, l_aux = extract_critical(scores, top_k, capacity_factor, normalize_gate, alignment,
+                                   topk_override=topk_override)
+    enc = fast_encode(xr.to(logits_dtype), crit, is_postscore).to(xr.dtype)
+    ffn = expert_ffn(enc, w1, b1, w2, b2, act, accum_fp32=accum_fp32)
+    dec = fast_decode(ffn.to(logits_dtype), crit, is_postscore)
+    y = dec.view(list(orig_shape[:-1]) + [ffn.shape[-1]]).to(orig_dtype)
+    return y, l_aux, crit, {"scores": scores, "encoded": enc, "expert_out": ffn}
+
+
+def moe_forward_ep(xs, wg, w1s, b1s, w2s, b2s, top_k=2, capacity_factor=1.0, fp32_gate=False,
+                   normalize_gate=True, is_postscore=True, act=torch.relu, alignment=1,
+                   accum_fp32=False):
+    """Expert-parallel forward with W ranks simulated in-process: xs[r] is rank r's [T,M]
+    tokens, w1s[r] etc. rank r's local expert weights.  Reference: moe_layer.py:344-351 with
+    num_local_experts > 0 (E = E_loc*W, moe_layer.py:46-55)."""
+    W = len(xs)
+    crits, encs, ldt = [], [], None
+    for r in range(W):
+        xr = xs[r].to(w1s[r].dtype)
+        scores, ldt = gate_scores(xr, wg, fp32_gate)
+        crit, _ = extract_critical(scores, top_k, capacity_factor, normalize_gate, alignment)
+        crits.append(crit)
+        encs.append(fast_encode(xr.to(ldt), crit, is_postscore).to(xr.dtype))
+    C = crits[0][4]
+    assert all(c[4] == C for c in crits)
+    recv = a2a_dispatch(encs)
+    outs = [expert_ffn(recv[r], w1s[r], b1s[r], w2s[r], b2s[r], act, accum_fp32=accum_fp32)
+            for r in range(W)]
+    back = a2a_combine(outs, C)
+    return [fast_decode(back[r].to(ldt), crits[r], is_postscore).to(xs[r].dtype)
+            for r in range(W)], crits
+
+
+# ---------------------------------------------------------------------------------------------
+# deterministic synthetic problem (mirrors helloworld.py:76-85,112-113 and ffn.py:39-49)
+# ---------------------------------------------------------------------------------------------
+def make_problem(T, M, H, E, dtype=torch.float32, seed=0, out_dim=None):
+    """nn.Linear-style init like FusedExpertsNetwork.reset_parameters (ffn.py:39-49) but from
+    one explicit generator so the GPU box can regenerate it bit-identically from the seed."""
+    g = torch.Generator().manual_seed(seed)
+    out_dim = out_dim or M
+
+    def uni(shape, bound):
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+    x = torch.randn([T, M], generator=g)
+    wg = uni([E, M], 1 / math.sqrt(M))
+    w1 = uni([E, H, M], 1 / math.sqrt(M))
+    b1 = uni([E, H], 1 / math.sqrt(M))
+    w2 = uni([E, H, out_dim], 1 / math.sqrt(H))
+    b2 = uni([E, out_dim], 1 / math.sqrt(H))
+    return [t.to(dtype) for t in (x, wg, w1, b1, w2, b2)]

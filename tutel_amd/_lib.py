@@ -1,0 +1,80 @@
+"""ctypes binding of libtutel_amd.so (C ABI: include/tutel_amd.h).
+
+The HIP library IS the product's compute path.  There is no CPU / eager fallback: if the
+library is missing or a call fails, this module raises -- loudly -- instead of computing the
+result some other way.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtutel_amd.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+F32, F16, BF16 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
+
+_vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/tutel_amd.h declares.
+SIGNATURES = {
+    "tutel_amd_abi_version": (_i, []),
+    "tutel_amd_target_arch": (ctypes.c_char_p, []),
+    "tutel_amd_last_error": (ctypes.c_char_p, []),
+    "tutel_amd_routing_workspace_bytes": (_sz, [_i, _i, _i]),
+    "tutel_amd_gate_topk": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "tutel_amd_compute_location": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "tutel_amd_slot_map": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "tutel_amd_cumsum_sub_one": (_i, [_vp, _vp, _i, _i, _vp]),
+    "tutel_amd_fast_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "tutel_amd_fast_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "tutel_amd_gate_grad": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "tutel_amd_expert_gemm": (_i, [_vp, _i64, _i64, _i, _i, _vp, _i, _i64, _i, _vp, _i64, _vp, _i64,
+                                   _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "tutel_amd_probe_tr16": (_i, [_vp, _vp]),
+}
+
+_lib = None
+
+
+class TutelAmdError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libtutel_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", CSRC_DIR, "-j8"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library.  Raises TutelAmdError when it is not there -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TutelAmdError(
+                f"tutel_amd: HIP library {LIB_PATH} is missing. Build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C tutel_amd/csrc` "
+                f"(hipcc --offload-arch=gfx950). There is no CPU fallback for the MoE hot path.")
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as ex:  # e.g. libamdhip64 missing
+            raise TutelAmdError(f"tutel_amd: cannot load {LIB_PATH}: {ex}") from ex
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as ex:
+                raise TutelAmdError(f"tutel_amd: {LIB_PATH} does not export `{name}` (stale build?)") from ex
+            fn.restype, fn.argtypes = res, args
+        if handle.tutel_amd_abi_version() != 1:
+            raise TutelAmdError("tutel_amd: ABI version mismatch between python and libtutel_amd.so")
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().tutel_amd_last_error().decode("utf-8", "replace")
+        raise TutelAmdError(f"{what} failed (status {status}): {msg}")

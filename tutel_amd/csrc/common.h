@@ -1,0 +1,146 @@
+// common.h -- shared device helpers for libtutel_amd.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/tutel_amd.h"
+
+#define WAVE 64
+
+// ---- error reporting ---------------------------------------------------------------------
+void tutel_set_error(const char *fmt, ...);
+
+#define TUTEL_REQUIRE(cond, ...)           \
+  do {                                     \
+    if (!(cond)) {                         \
+      tutel_set_error(__VA_ARGS__);        \
+      return -1;                           \
+    }                                      \
+  } while (0)
+
+#define TUTEL_CHECK_LAUNCH(what)                                                    \
+  do {                                                                              \
+    hipError_t _e = hipGetLastError();                                              \
+    if (_e != hipSuccess) {                                                         \
+      tutel_set_error("%s: launch failed: %s", what, hipGetErrorString(_e));        \
+      return (int)_e;                                                               \
+    }                                                                               \
+  } while (0)
+
+// ---- element types -----------------------------------------------------------------------
+struct bf16_t { uint16_t v; };
+struct f16_t { _Float16 v; };
+
+// fp32 -> bf16 round-to-nearest-even, NaN -> 0x7FC0 (c10::BFloat16 round_to_nearest_even).
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+  return __uint_as_float(((uint32_t)b) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int dtype = TUTEL_F32;
+  __device__ static __forceinline__ float to_f32(float x) { return x; }
+  __device__ static __forceinline__ float from_f32(float x) { return x; }
+  __device__ static __forceinline__ float eps() { return 1.1920928955078125e-07f; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int dtype = TUTEL_BF16;
+  __device__ static __forceinline__ float to_f32(bf16_t x) { return bf16_bits_to_f32(x.v); }
+  __device__ static __forceinline__ bf16_t from_f32(float x) { return bf16_t{f32_to_bf16_bits(x)}; }
+  __device__ static __forceinline__ float eps() { return 0.0078125f; }
+};
+template <> struct Elem<f16_t> {
+  static constexpr int dtype = TUTEL_F16;
+  __device__ static __forceinline__ float to_f32(f16_t x) { return (float)x.v; }
+  __device__ static __forceinline__ f16_t from_f32(float x) { return f16_t{(_Float16)x}; }
+  __device__ static __forceinline__ float eps() { return 0.0009765625f; }
+};
+
+// round x to T and back (what a `T`-typed torch op does to an fp32 intermediate)
+template <typename T> __device__ __forceinline__ float round_to(float x) {
+  return Elem<T>::to_f32(Elem<T>::from_f32(x));
+}
+
+static inline int dtype_size(int dtype) { return dtype == TUTEL_F32 ? 4 : 2; }
+static inline bool dtype_ok(int dtype) {
+  return dtype == TUTEL_F32 || dtype == TUTEL_F16 || dtype == TUTEL_BF16;
+}
+
+// 16-byte vector of raw bits
+struct __attribute__((aligned(16))) vec16 { uint32_t w[4]; };
+
+// unpack / pack 16 bytes <-> fp32 lanes
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void unpack(const vec16 &v, float *f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v.w[i]);
+  }
+  __device__ static __forceinline__ void pack(const float *f, vec16 &v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.w[i] = __float_as_uint(f[i]);
+  }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void unpack(const vec16 &v, float *f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(v.w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(v.w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void pack(const float *f, vec16 &v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v.w[i] = (uint32_t)f32_to_bf16_bits(f[2 * i]) | ((uint32_t)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+  }
+};
+template <> struct Vec<f16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void unpack(const vec16 &v, float *f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      union { uint32_t u; _Float16 h[2]; } c;
+      c.u = v.w[i];
+      f[2 * i] = (float)c.h[0];
+      f[2 * i + 1] = (float)c.h[1];
+    }
+  }
+  __device__ static __forceinline__ void pack(const float *f, vec16 &v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      union { uint32_t u; _Float16 h[2]; } c;
+      c.h[0] = (_Float16)f[2 * i];
+      c.h[1] = (_Float16)f[2 * i + 1];
+      v.w[i] = c.u;
+    }
+  }
+};
+
+// exact (non-contracted) fp32 multiply / add: the reference's CPU loops and its k-temps-then-sum
+// structure round every product and every sum separately (fast_dispatch.py:61-66).
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+
+// ---- wave helpers ------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,296 @@
+// dispatch.hip -- fast_encode / fast_decode / gate-grad for gfx950.
+//
+// These are permutations (HBM-bound byte movement, no MFMA):
+//   encode : bucket-major.  One wave per bucket row (e*C + c): look the owning (choice, token)
+//            up in slot_map, stream the token row with 16-byte loads/stores, or store zeros for
+//            an empty row.  One pass writes every byte of [E*C, M] exactly once -- the reference
+//            does torch.zeros + k token-major launches (fast_dispatch.py:26-28) in fp32.
+//            Algorithmic bytes: (T + E*C) * M * s.
+//   decode : token-major.  One wave per token: gather its k bucket rows, multiply by the gate
+//            and sum IN THE REFERENCE'S ORDER in fp32 (product rounded, then added: the
+//            reference materialises k fp32 temps and adds them, fast_dispatch.py:61-66), round
+//            once.  Algorithmic bytes: (n_kept + T) * M * s.
+// Rows are processed as 16-byte vectors (8 x bf16/fp16 or 4 x fp32 per lane, 1 KiB per wave
+// instruction); rows whose byte length is not a multiple of 16 take the scalar tail path.
+#include "common.h"
+
+#define DP_THREADS 256
+#define DP_WAVES 4
+
+
+__device__ __forceinline__ float load_gate(const void *g, int gate_dtype, size_t i) {
+  if (gate_dtype == TUTEL_F32) return reinterpret_cast<const float *>(g)[i];
+  if (gate_dtype == TUTEL_BF16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t *>(g)[i]);
+  return (float)reinterpret_cast<const _Float16 *>(g)[i];
+}
+
+// -------------------------------------------------------------------------------------------
+// encode
+// -------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict__ x,
+                                                           const int32_t *__restrict__ slot_map,
+                                                           const void *__restrict__ gates,
+                                                           int gate_dtype, int Tn, int M,
+                                                           int n_slots, T *__restrict__ out) {
+  constexpr int VN = Vec<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * DP_WAVES;
+  const int nvec = M / VN;  // full 16-byte vectors per row (rows are 16B aligned when M % VN == 0)
+  const bool vec_ok = (M % VN) == 0;
+
+  for (int slot = wave; slot < n_slots; slot += nwaves) {
+    int q = slot_map[slot];  // wave-uniform
+    q = __builtin_amdgcn_readfirstlane(q);
+    T *dst = out + (size_t)slot * M;
+    if (q < 0) {
+      if (vec_ok) {
+        vec16 z = {{0u, 0u, 0u, 0u}};
+        vec16 *d = reinterpret_cast<vec16 *>(dst);
+        for (int i = lane; i < nvec; i += 64) d[i] = z;
+      } else {
+        for (int i = lane; i < M; i += 64) dst[i] = Elem<T>::from_f32(0.f);
+      }
+      continue;
+    }
+    const int t = q % Tn;
+    const T *src = x + (size_t)t * M;
+    if (gates == nullptr) {  // is_postscore=True: pure copy (x * 1.0 is exact)
+      if (vec_ok) {
+        const vec16 *s = reinterpret_cast<const vec16 *>(src);
+        vec16 *d = reinterpret_cast<vec16 *>(dst);
+        int i = lane;
+        for (; i + 192 < nvec; i += 256) {  // 4 independent 16B loads in flight per lane
+          vec16 a = s[i], b = s[i + 64], c = s[i + 128], e = s[i + 192];
+          d[i] = a; d[i + 64] = b; d[i + 128] = c; d[i + 192] = e;
+        }
+        for (; i < nvec; i += 64) d[i] = s[i];
+      } else {
+        for (int i = lane; i < M; i += 64) dst[i] = src[i];
+      }
+    } else {
+      const float g = load_gate(gates, gate_dtype, (size_t)q);
+      if (vec_ok) {
+        const vec16 *s = reinterpret_cast<const vec16 *>(src);
+        vec16 *d = reinterpret_cast<vec16 *>(dst);
+        for (int i = lane; i < nvec; i += 64) {
+          vec16 v = s[i];
+          float f[VN];
+          Vec<T>::unpack(v, f);
+#pragma unroll
+          for (int u = 0; u < VN; ++u) f[u] = mul_rn(g, f[u]);
+          Vec<T>::pack(f, v);
+          d[i] = v;
+        }
+      } else {
+        for (int i = lane; i < M; i += 64) dst[i] = Elem<T>::from_f32(mul_rn(g, Elem<T>::to_f32(src[i])));
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// decode
+// -------------------------------------------------------------------------------------------
+template <typename T, int KMAX>
+__global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict__ buf,
+                                                           const int32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ loc,
+                                                           const void *__restrict__ gates,
+                                                           int gate_dtype, int Tn, int M, int k,
+                                                           int capacity, T *__restrict__ out) {
+  constexpr int VN = Vec<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * DP_WAVES;
+  const int nvec = M / VN;
+  const bool vec_ok = (M % VN) == 0;
+
+  for (int t = wave; t < Tn; t += nwaves) {
+    // per-choice row pointer (nullptr = dropped) and gate, wave-uniform
+    const T *rows[KMAX];
+    float g[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      rows[j] = nullptr;
+      g[j] = 0.f;
+      if (j < k) {
+        int e = idx[(size_t)j * Tn + t], l = loc[(size_t)j * Tn + t];
+        if (l < capacity && e >= 0 && l >= 0) {
+          rows[j] = buf + ((size_t)e * capacity + l) * M;
+          g[j] = gates ? load_gate(gates, gate_dtype, (size_t)j * Tn + t) : 1.0f;
+        }
+      }
+    }
+    T *dst = out + (size_t)t * M;
+    if (vec_ok) {
+      vec16 *d = reinterpret_cast<vec16 *>(dst);
+      for (int i = lane; i < nvec; i += 64) {
+        vec16 v[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+          if (rows[j]) v[j] = reinterpret_cast<const vec16 *>(rows[j])[i];
+        float acc[VN];
+#pragma unroll
+        for (int u = 0; u < VN; ++u) acc[u] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+          if (j >= k) break;
+          float f[VN];
+          if (rows[j]) {
+            Vec<T>::unpack(v[j], f);
+#pragma unroll
+            for (int u = 0; u < VN; ++u) f[u] = mul_rn(g[j], f[u]);
+          } else {
+#pragma unroll
+            for (int u = 0; u < VN; ++u) f[u] = 0.f;
+          }
+          if (j == 0) {
+#pragma unroll
+            for (int u = 0; u < VN; ++u) acc[u] = f[u];
+          } else {
+#pragma unroll
+            for (int u = 0; u < VN; ++u) acc[u] = add_rn(acc[u], f[u]);
+          }
+        }
+        vec16 o;
+        Vec<T>::pack(acc, o);
+        d[i] = o;
+      }
+    } else {
+      for (int i = lane; i < M; i += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < k && j < KMAX; ++j) {
+          float f = rows[j] ? mul_rn(g[j], Elem<T>::to_f32(rows[j][i])) : 0.f;
+          acc = (j == 0) ? f : add_rn(acc, f);
+        }
+        dst[i] = Elem<T>::from_f32(acc);
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// gate gradient: one wave per (choice, token); fp32 accumulate, butterfly reduce.
+// (The reference accumulates serially in the data dtype, custom_kernel.cpp:318-321; a parallel
+// fp32 reduction differs in summation order only -- tolerance stated in the test.)
+// -------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(DP_THREADS) void gate_grad_kernel(const T *__restrict__ x,
+                                                              const T *__restrict__ buf,
+                                                              const int32_t *__restrict__ idx,
+                                                              const int32_t *__restrict__ loc,
+                                                              int Tn, int M, int k, int capacity,
+                                                              float *__restrict__ ggate) {
+  constexpr int VN = Vec<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * DP_WAVES;
+  const int n = k * Tn;
+  const int nvec = M / VN;
+  const bool vec_ok = (M % VN) == 0;
+  for (int q = wave; q < n; q += nwaves) {
+    const int t = q % Tn;
+    int e = idx[q], l = loc[q];
+    float acc = 0.f;
+    if (l < capacity && e >= 0 && l >= 0) {
+      const T *row = buf + ((size_t)e * capacity + l) * M;
+      const T *xr = x + (size_t)t * M;
+      if (vec_ok) {
+        for (int i = lane; i < nvec; i += 64) {
+          float a[VN], b[VN];
+          Vec<T>::unpack(reinterpret_cast<const vec16 *>(row)[i], a);
+          Vec<T>::unpack(reinterpret_cast<const vec16 *>(xr)[i], b);
+#pragma unroll
+          for (int u = 0; u < VN; ++u) acc += a[u] * b[u];
+        }
+      } else {
+        for (int i = lane; i < M; i += 64) acc += Elem<T>::to_f32(row[i]) * Elem<T>::to_f32(xr[i]);
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) ggate[q] = acc;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------------
+static inline int dp_grid(int rows) {
+  int blocks = (rows + DP_WAVES - 1) / DP_WAVES;
+  const int cap = 256 * 8;  // 256 CUs x 8 blocks: grid-stride beyond that
+  return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+}
+
+extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *slot_map,
+                                     const void *gates, int gate_dtype, int T, int M, int n_slots,
+                                     void *out, tutel_stream_t stream) {
+  TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_fast_encode: unsupported dtype %d", dtype);
+  TUTEL_REQUIRE(gates == nullptr || dtype_ok(gate_dtype), "tutel_amd_fast_encode: unsupported gate dtype %d", gate_dtype);
+  TUTEL_REQUIRE(T >= 0 && M >= 1 && n_slots >= 0, "tutel_amd_fast_encode: bad sizes T=%d M=%d n_slots=%d", T, M, n_slots);
+  if (n_slots == 0) return 0;
+  TUTEL_REQUIRE(slot_map && out && (x || T == 0), "tutel_amd_fast_encode: null pointer");
+  TUTEL_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_amd_fast_encode: x/out must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int grid = dp_grid(n_slots);
+  int Tn = T > 0 ? T : 1;
+  if (dtype == TUTEL_F32)
+    hipLaunchKernelGGL(encode_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, (float *)out);
+  else if (dtype == TUTEL_BF16)
+    hipLaunchKernelGGL(encode_kernel<bf16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const bf16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, (bf16_t *)out);
+  else
+    hipLaunchKernelGGL(encode_kernel<f16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const f16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, (f16_t *)out);
+  TUTEL_CHECK_LAUNCH("tutel_amd_fast_encode");
+  return 0;
+}
+
+template <typename T>
+static void launch_decode(const void *buf, const int32_t *idx, const int32_t *loc, const void *gates,
+                          int gate_dtype, int Tn, int M, int k, int capacity, void *out, hipStream_t st) {
+  int grid = dp_grid(Tn);
+#define DEC(KM) hipLaunchKernelGGL((decode_kernel<T, KM>), dim3(grid), dim3(DP_THREADS), 0, st, (const T *)buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, (T *)out)
+  if (k <= 1) DEC(1);
+  else if (k <= 2) DEC(2);
+  else if (k <= 4) DEC(4);
+  else if (k <= 8) DEC(8);
+  else DEC(16);
+#undef DEC
+}
+
+extern "C" int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *idx,
+                                     const int32_t *loc, const void *gates, int gate_dtype, int T,
+                                     int M, int k, int capacity, void *out, tutel_stream_t stream) {
+  TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_fast_decode: unsupported dtype %d", dtype);
+  TUTEL_REQUIRE(gates == nullptr || dtype_ok(gate_dtype), "tutel_amd_fast_decode: unsupported gate dtype %d", gate_dtype);
+  TUTEL_REQUIRE(T >= 0 && M >= 1 && k >= 1 && k <= 16 && capacity >= 0, "tutel_amd_fast_decode: bad sizes T=%d M=%d k=%d C=%d", T, M, k, capacity);
+  if (T == 0) return 0;
+  TUTEL_REQUIRE(idx && loc && out && (buf || capacity == 0), "tutel_amd_fast_decode: null pointer");
+  TUTEL_REQUIRE(((uintptr_t)buf % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_amd_fast_decode: buf/out must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TUTEL_F32) launch_decode<float>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, out, st);
+  else if (dtype == TUTEL_BF16) launch_decode<bf16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, out, st);
+  else launch_decode<f16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, out, st);
+  TUTEL_CHECK_LAUNCH("tutel_amd_fast_decode");
+  return 0;
+}
+
+extern "C" int tutel_amd_gate_grad(const void *x, const void *buf, int dtype, const int32_t *idx,
+                                   const int32_t *loc, int T, int M, int k, int capacity,
+                                   float *ggate, tutel_stream_t stream) {
+  TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_gate_grad: unsupported dtype %d", dtype);
+  TUTEL_REQUIRE(T >= 0 && M >= 1 && k >= 1 && capacity >= 0, "tutel_amd_gate_grad: bad sizes");
+  if (T == 0) return 0;
+  TUTEL_REQUIRE(x && idx && loc && ggate && (buf || capacity == 0), "tutel_amd_gate_grad: null pointer");
+  TUTEL_REQUIRE(((uintptr_t)buf % 16) == 0 && ((uintptr_t)x % 16) == 0, "tutel_amd_gate_grad: x/buf must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int grid = dp_grid(k * T);
+  if (dtype == TUTEL_F32)
+    hipLaunchKernelGGL(gate_grad_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)x, (const float *)buf, idx, loc, T, M, k, capacity, ggate);
+  else if (dtype == TUTEL_BF16)
+    hipLaunchKernelGGL(gate_grad_kernel<bf16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const bf16_t *)x, (const bf16_t *)buf, idx, loc, T, M, k, capacity, ggate);
+  else
+    hipLaunchKernelGGL(gate_grad_kernel<f16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const f16_t *)x, (const f16_t *)buf, idx, loc, T, M, k, capacity, ggate);
+  TUTEL_CHECK_LAUNCH("tutel_amd_gate_grad");
+  return 0;
+}

@@ -1,0 +1,432 @@
+// routing.hip -- top-k gating + compute_location for gfx950.
+//
+// Reference behaviour restated (tutel/impls/fast_dispatch.py:143-178, losses.py:7-19,
+// jit_kernels/gating.py:19-24, custom_kernel.cpp:822-872): softmax -> torch.topk -> k one-hot
+// [T,E] int64 masks -> k column cumsums -> masked row sums.  That is ~35 ATen launches and
+// k x 2 MiB of one-hot traffic for what is, per token, "which experts, and what is my stable
+// rank among the tokens that chose the same expert".
+//
+// MI355X design (latency-bound, ~1 MB of traffic, so: few launches, wave64 primitives, no MFMA):
+//   K1 gate_topk_kernel : one wave per token row, lane = expert (E/64 experts per lane);
+//                         softmax by wave butterfly, top-k by k wave-argmax rounds with the
+//                         (score desc, expert index asc) order; per-tile expert histograms in
+//                         LDS -> ws; per-tile score column sums (for l_aux) -> ws.
+//   K2 location_kernel  : block b = token tile b.  Prefix over the (<=128) tile histograms
+//                         gives the tile's base per (choice, expert); inside the tile a wave
+//                         ranks 64 tokens at a time with ballot/popcount over the distinct
+//                         experts present (a counting-sort rank, no one-hot, no scan of [T,E]).
+//                         Emits loc, the bucket->token slot map, dispatch_count, max count and
+//                         the gshard loss.
+// Index outputs are integers and bit-exact against the oracle; gates follow the reference's
+// per-op rounding in the scores dtype.
+#include "common.h"
+
+#define RT_THREADS 256
+#define RT_WAVES 4
+#define RT_MAX_TILES 128
+#define RT_MAX_K 16
+#define RT_MAX_E 1024
+
+static inline int rt_tile(int T) {
+  int per = (T + 64 * RT_MAX_TILES - 1) / (64 * RT_MAX_TILES);
+  if (per < 1) per = 1;
+  return 64 * per;
+}
+static inline int rt_ntiles(int T) { return (T + rt_tile(T) - 1) / rt_tile(T); }
+
+extern "C" size_t tutel_amd_routing_workspace_bytes(int T, int E, int k) {
+  if (T <= 0 || E <= 0 || k <= 0) return 0;
+  size_t nt = (size_t)rt_ntiles(T);
+  return nt * ((size_t)k * E * sizeof(int32_t) + (size_t)E * sizeof(float));
+}
+
+// -------------------------------------------------------------------------------------------
+// K1: softmax (optional) + top-k + tile histogram + tile column sums
+// -------------------------------------------------------------------------------------------
+template <typename T, int EPL>
+__global__ __launch_bounds__(RT_THREADS) void gate_topk_kernel(
+    const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
+    T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
+    int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t *s_hist = reinterpret_cast<int32_t *>(smem);             // [k][E]
+  float *s_col = reinterpret_cast<float *>(smem) + (size_t)k * E;  // [RT_WAVES][E]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.x;
+  const int t0 = b * tile, t1 = min(Tn, t0 + tile);
+
+  for (int i = tid; i < k * E; i += RT_THREADS) s_hist[i] = 0;
+  __syncthreads();
+
+  float colacc[EPL];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) colacc[j] = 0.f;
+
+  for (int t = t0 + wid; t < t1; t += RT_WAVES) {
+    float v[EPL];
+    const T *row = in + (size_t)t * E;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      int e = lane + 64 * j;
+      float x = (e < E) ? Elem<T>::to_f32(row[e]) : -INFINITY;
+      v[j] = x;
+    }
+    if (apply_softmax) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) m = fmaxf(m, v[j]);
+      m = wave_max(m);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        int e = lane + 64 * j;
+        v[j] = (e < E) ? expf(v[j] - m) : 0.f;
+        s += v[j];
+      }
+      s = wave_sum(s);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        int e = lane + 64 * j;
+        if (e < E) {
+          T r = Elem<T>::from_f32(v[j] / s);
+          v[j] = Elem<T>::to_f32(r);
+          if (scores_out) scores_out[(size_t)t * E + e] = r;
+        } else {
+          v[j] = -INFINITY;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      int e = lane + 64 * j;
+      if (e < E) colacc[j] += v[j];
+      if (v[j] != v[j]) v[j] = -INFINITY;  // NaN sorts last
+    }
+
+    // k rounds of wave arg-max, order: score desc, expert index asc.
+    uint32_t taken = 0;
+    float myg = 0.f;
+    int myidx = -1;
+    for (int c = 0; c < k; ++c) {
+      float bv = -INFINITY;
+      int be = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        int e = lane + 64 * j;
+        bool ok = (e < E) && !((taken >> j) & 1u);
+        if (ok && (v[j] > bv || (v[j] == bv && e < be))) { bv = v[j]; be = e; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o, 64);
+        int oe = __shfl_xor(be, o, 64);
+        if (ov > bv || (ov == bv && oe < be)) { bv = ov; be = oe; }
+      }
+      if ((be & 63) == lane) taken |= 1u << (be >> 6);
+      if (lane == c) { myg = bv; myidx = be; }
+    }
+    // gates: raw score, optionally normalised by clamp(((0+g0)+g1)+..., eps) in dtype T.
+    float denom = __shfl(myg, 0, 64);
+    for (int c = 1; c < k; ++c) denom = round_to<T>(denom + __shfl(myg, c, 64));
+    if (lane < k) {
+      float g = myg;
+      if (normalize && k > 1) {
+        float d = fmaxf(denom, Elem<T>::eps());
+        if (denom != denom) d = denom;  // torch.clamp keeps NaN
+        g = g / d;
+      }
+      gates[(size_t)lane * Tn + t] = Elem<T>::from_f32(g);
+      idx[(size_t)lane * Tn + t] = myidx;
+      atomicAdd(&s_hist[lane * E + myidx], 1);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {
+    int e = lane + 64 * j;
+    if (e < E) s_col[wid * E + e] = colacc[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < k * E; i += RT_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
+  for (int e = tid; e < E; e += RT_THREADS) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < RT_WAVES; ++w) s += s_col[w * E + e];
+    ws_colsum[(size_t)b * E + e] = s;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// tile histograms from an externally supplied idx[k,T] (hist_ready == 0 path)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RT_THREADS) void tile_hist_kernel(const int32_t *__restrict__ idx,
+                                                              int Tn, int E, int k, int tile,
+                                                              int32_t *__restrict__ ws_hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t *s_hist = reinterpret_cast<int32_t *>(smem);
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int t0 = b * tile, t1 = min(Tn, t0 + tile);
+  for (int i = tid; i < k * E; i += RT_THREADS) s_hist[i] = 0;
+  __syncthreads();
+  for (int j = 0; j < k; ++j)
+    for (int t = t0 + tid; t < t1; t += RT_THREADS) {
+      int e = idx[(size_t)j * Tn + t];
+      if (e >= 0 && e < E) atomicAdd(&s_hist[j * E + e], 1);
+    }
+  __syncthreads();
+  for (int i = tid; i < k * E; i += RT_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
+}
+
+// -------------------------------------------------------------------------------------------
+// K2: locations
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RT_THREADS) void location_kernel(
+    const int32_t *__restrict__ idx, int Tn, int E, int k, int tile, int ntiles,
+    const int32_t *__restrict__ ws_hist, const float *__restrict__ ws_colsum,
+    int32_t *__restrict__ loc, int32_t *__restrict__ dispatch_count, int32_t *__restrict__ stats,
+    float *__restrict__ l_aux, int capacity, int32_t *__restrict__ slot_map) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t *s_cur = reinterpret_cast<int32_t *>(smem);  // [k][E] running absolute location
+  int32_t *s_tot = s_cur + (size_t)k * E;              // [k][E] per-choice totals
+  __shared__ float s_red[RT_WAVES];
+  __shared__ int s_redi[RT_WAVES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.x;
+  const int t0 = b * tile, t1 = min(Tn, t0 + tile);
+  const int kE = k * E;
+
+  // 1. base[j][e] = sum over earlier tiles, tot[j][e] = sum over all tiles
+  for (int i = tid; i < kE; i += RT_THREADS) {
+    int base = 0, tot = 0;
+    for (int tl = 0; tl < ntiles; ++tl) {
+      int h = ws_hist[(size_t)tl * kE + i];
+      if (tl < b) base += h;
+      tot += h;
+    }
+    s_cur[i] = base;
+    s_tot[i] = tot;
+  }
+  __syncthreads();
+  // 2. choice j is queued after ALL tokens' choices < j (fast_dispatch.py:165-169)
+  for (int e = tid; e < E; e += RT_THREADS) {
+    int acc = 0;
+    for (int j = 0; j < k; ++j) {
+      s_cur[j * E + e] += acc;
+      acc += s_tot[j * E + e];
+    }
+    if (b == 0) dispatch_count[e] = acc;
+  }
+  __syncthreads();
+
+  // 3. stable rank inside the tile: wave handles one choice, 64 tokens per step
+  for (int j = wid; j < k; j += RT_WAVES) {
+    int32_t *cur = s_cur + j * E;
+    for (int c0 = t0; c0 < t1; c0 += 64) {
+      int t = c0 + lane;
+      int e = (t < t1) ? idx[(size_t)j * Tn + t] : -1;
+      bool valid = (e >= 0) && (e < E);
+      int rank = 0, cnt = 0;
+      bool leader = false;
+      unsigned long long remaining = __ballot(valid);
+      while (remaining) {
+        int first = __ffsll((long long)remaining) - 1;
+        int e0 = __shfl(e, first, 64);
+        unsigned long long m = __ballot(valid && e == e0);
+        if (valid && e == e0) {
+          rank = __popcll(m & ((1ull << lane) - 1ull));
+          cnt = __popcll(m);
+          leader = (lane == first);
+        }
+        remaining &= ~m;
+      }
+      int base = valid ? cur[e] : 0;
+      int l = base + rank;
+      if (leader) cur[e] = base + cnt;
+      if (t < t1) {
+        loc[(size_t)j * Tn + t] = valid ? l : 0;
+        if (slot_map != nullptr && valid && l < capacity) slot_map[(size_t)e * capacity + l] = j * Tn + t;
+      }
+    }
+  }
+
+  // 4. block 0: max count and gshard loss
+  if (b == 0) {
+    int mx = 0;
+    float part = 0.f;
+    for (int e = tid; e < E; e += RT_THREADS) {
+      int acc = 0;
+      for (int j = 0; j < k; ++j) acc += s_tot[j * E + e];
+      mx = max(mx, acc);
+      if (l_aux != nullptr) {
+        float me = 0.f;
+        for (int tl = 0; tl < ntiles; ++tl) me += ws_colsum[(size_t)tl * E + e];
+        float ce = (float)s_tot[e] * ((float)E / (float)Tn);
+        part += me * ce;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = max(mx, __shfl_xor(mx, o, 64));
+      part += __shfl_xor(part, o, 64);
+    }
+    if (lane == 0) { s_red[wid] = part; s_redi[wid] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+      float p = 0.f;
+      int m2 = 0;
+      for (int w = 0; w < RT_WAVES; ++w) { p += s_red[w]; m2 = max(m2, s_redi[w]); }
+      if (stats != nullptr) stats[0] = m2;
+      if (l_aux != nullptr) l_aux[0] = p / (float)Tn;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// slot map from arbitrary (idx, loc)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slot_map_kernel(const int32_t *__restrict__ idx,
+                                                       const int32_t *__restrict__ loc, int n,
+                                                       int E, int capacity,
+                                                       int32_t *__restrict__ slot_map) {
+  int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  int e = idx[q], l = loc[q];
+  if (e >= 0 && e < E && l >= 0 && l < capacity) slot_map[(size_t)e * capacity + l] = q;
+}
+
+// -------------------------------------------------------------------------------------------
+// fast_cumsum_sub_one: block = 64 columns, 16 waves = 16 row chunks, two passes (the second
+// pass re-reads the chunk from L2).
+// -------------------------------------------------------------------------------------------
+#define CS_WAVES 16
+__global__ __launch_bounds__(CS_WAVES * 64) void cumsum_kernel(const int32_t *__restrict__ in,
+                                                              int32_t *__restrict__ out, int Tn,
+                                                              int E) {
+  __shared__ int32_t s_part[CS_WAVES][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int rows_per = (Tn + CS_WAVES - 1) / CS_WAVES;
+  const int r0 = wid * rows_per, r1 = min(Tn, r0 + rows_per);
+  int acc = 0;
+  if (col < E)
+    for (int r = r0; r < r1; ++r) acc += in[(size_t)r * E + col];
+  s_part[wid][lane] = acc;
+  __syncthreads();
+  int run = -1;
+  for (int w = 0; w < wid; ++w) run += s_part[w][lane];
+  if (col < E)
+    for (int r = r0; r < r1; ++r) {
+      run += in[(size_t)r * E + col];
+      out[(size_t)r * E + col] = run;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------------
+template <typename T>
+static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, int k, int normalize,
+                            void *scores_out, int32_t *idx, void *gates, void *ws,
+                            hipStream_t st) {
+  const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
+  int32_t *ws_hist = (int32_t *)ws;
+  float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
+  size_t lds = ((size_t)k * E + (size_t)RT_WAVES * E) * 4;
+  const int epl = (E + 63) / 64;
+#define GT_LAUNCH(EPL)                                                                          \
+  hipLaunchKernelGGL((gate_topk_kernel<T, EPL>), dim3(nt), dim3(RT_THREADS), lds, st,           \
+                     (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,  \
+                     idx, (T *)gates, ws_hist, ws_col)
+  if (epl <= 1) GT_LAUNCH(1);
+  else if (epl <= 2) GT_LAUNCH(2);
+  else if (epl <= 4) GT_LAUNCH(4);
+  else if (epl <= 8) GT_LAUNCH(8);
+  else GT_LAUNCH(16);
+#undef GT_LAUNCH
+  TUTEL_CHECK_LAUNCH("tutel_amd_gate_topk");
+  return 0;
+}
+
+extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax, int T, int E,
+                                   int k, int normalize_gate, void *scores_out, int32_t *idx,
+                                   void *gates, void *ws, size_t ws_bytes, tutel_stream_t stream) {
+  TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_gate_topk: unsupported dtype %d", dtype);
+  TUTEL_REQUIRE(T >= 0 && E >= 1 && E <= RT_MAX_E, "tutel_amd_gate_topk: need 1 <= E <= %d (got %d)", RT_MAX_E, E);
+  TUTEL_REQUIRE(k >= 1 && k <= RT_MAX_K && k <= E, "tutel_amd_gate_topk: need 1 <= k <= min(E,%d) (got k=%d, E=%d)", RT_MAX_K, k, E);
+  TUTEL_REQUIRE((size_t)k * E <= 8192, "tutel_amd_gate_topk: k*E = %d exceeds 8192", k * E);
+  if (T == 0) return 0;
+  TUTEL_REQUIRE(in && idx && gates && ws, "tutel_amd_gate_topk: null pointer");
+  TUTEL_REQUIRE(ws_bytes >= tutel_amd_routing_workspace_bytes(T, E, k), "tutel_amd_gate_topk: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, st);
+  if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, st);
+  return launch_gate_topk<f16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, st);
+}
+
+extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int k, int hist_ready,
+                                          void *ws, size_t ws_bytes, int32_t *loc,
+                                          int32_t *dispatch_count, int32_t *stats, float *l_aux,
+                                          int capacity, int32_t *slot_map, tutel_stream_t stream) {
+  TUTEL_REQUIRE(T >= 0 && E >= 1 && E <= RT_MAX_E, "tutel_amd_compute_location: need 1 <= E <= %d (got %d)", RT_MAX_E, E);
+  TUTEL_REQUIRE(k >= 1 && k <= RT_MAX_K, "tutel_amd_compute_location: need 1 <= k <= %d (got %d)", RT_MAX_K, k);
+  TUTEL_REQUIRE((size_t)k * E <= 8192, "tutel_amd_compute_location: k*E = %d exceeds 8192", k * E);
+  TUTEL_REQUIRE(dispatch_count != nullptr, "tutel_amd_compute_location: dispatch_count is null");
+  TUTEL_REQUIRE(hist_ready || l_aux == nullptr, "tutel_amd_compute_location: l_aux needs the column sums written by tutel_amd_gate_topk (hist_ready=1)");
+  hipStream_t st = (hipStream_t)stream;
+  if (T == 0) {
+    (void)hipMemsetAsync(dispatch_count, 0, (size_t)E * 4, st);
+    if (stats) (void)hipMemsetAsync(stats, 0, 4, st);
+    if (l_aux) (void)hipMemsetAsync(l_aux, 0, 4, st);
+    if (slot_map && capacity > 0) (void)hipMemsetAsync(slot_map, 0xFF, (size_t)E * capacity * 4, st);
+    return 0;
+  }
+  TUTEL_REQUIRE(idx && loc && ws, "tutel_amd_compute_location: null pointer");
+  TUTEL_REQUIRE(ws_bytes >= tutel_amd_routing_workspace_bytes(T, E, k), "tutel_amd_compute_location: workspace too small");
+  const int tile = rt_tile(T), nt = rt_ntiles(T);
+  int32_t *ws_hist = (int32_t *)ws;
+  float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
+  if (!hist_ready) {
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(nt), dim3(RT_THREADS), (size_t)k * E * 4, st, idx, T, E, k, tile, ws_hist);
+    TUTEL_CHECK_LAUNCH("tutel_amd_compute_location(hist)");
+  }
+  if (slot_map != nullptr && capacity > 0) {
+    hipError_t e = hipMemsetAsync(slot_map, 0xFF, (size_t)E * capacity * 4, st);
+    TUTEL_REQUIRE(e == hipSuccess, "tutel_amd_compute_location: memset failed: %s", hipGetErrorString(e));
+  } else {
+    slot_map = nullptr;
+    capacity = 0;
+  }
+  hipLaunchKernelGGL(location_kernel, dim3(nt), dim3(RT_THREADS), (size_t)2 * k * E * 4, st, idx, T, E, k,
+                     tile, nt, ws_hist, ws_col, loc, dispatch_count, stats, l_aux, capacity, slot_map);
+  TUTEL_CHECK_LAUNCH("tutel_amd_compute_location");
+  return 0;
+}
+
+extern "C" int tutel_amd_slot_map(const int32_t *idx, const int32_t *loc, int T, int E, int k,
+                                  int capacity, int32_t *slot_map, tutel_stream_t stream) {
+  TUTEL_REQUIRE(E >= 1 && k >= 1 && capacity >= 0 && T >= 0, "tutel_amd_slot_map: bad sizes");
+  TUTEL_REQUIRE((long long)k * T < 0x7fffffffLL, "tutel_amd_slot_map: k*T overflows int32");
+  hipStream_t st = (hipStream_t)stream;
+  if (capacity == 0) return 0;
+  TUTEL_REQUIRE(slot_map != nullptr, "tutel_amd_slot_map: null slot_map");
+  hipError_t e = hipMemsetAsync(slot_map, 0xFF, (size_t)E * capacity * 4, st);
+  TUTEL_REQUIRE(e == hipSuccess, "tutel_amd_slot_map: memset failed: %s", hipGetErrorString(e));
+  int n = k * T;
+  if (n == 0) return 0;
+  TUTEL_REQUIRE(idx && loc, "tutel_amd_slot_map: null pointer");
+  hipLaunchKernelGGL(slot_map_kernel, dim3((n + 255) / 256), dim3(256), 0, st, idx, loc, n, E, capacity, slot_map);
+  TUTEL_CHECK_LAUNCH("tutel_amd_slot_map");
+  return 0;
+}
+
+extern "C" int tutel_amd_cumsum_sub_one(const int32_t *mask, int32_t *out, int T, int E,
+                                        tutel_stream_t stream) {
+  TUTEL_REQUIRE(T >= 0 && E >= 0, "tutel_amd_cumsum_sub_one: bad sizes");
+  if (T == 0 || E == 0) return 0;
+  TUTEL_REQUIRE(mask && out, "tutel_amd_cumsum_sub_one: null pointer");
+  hipLaunchKernelGGL(cumsum_kernel, dim3((E + 63) / 64), dim3(CS_WAVES * 64), 0, (hipStream_t)stream, mask, out, T, E);
+  TUTEL_CHECK_LAUNCH("tutel_amd_cumsum_sub_one");
+  return 0;
+}

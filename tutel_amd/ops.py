@@ -1,0 +1,204 @@
+"""Tensor-level wrappers over the C ABI (include/tutel_amd.h).
+
+PyTorch is plumbing here: it owns the HBM allocations and the current HIP stream; every op
+below hands raw device pointers + sizes + that stream to libtutel_amd.so.  All ops require HIP
+device tensors and raise otherwise -- there is no CPU or eager implementation behind them.
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+ACT_CODES = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU, "silu": _lib.ACT_SILU}
+
+
+def _code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise _lib.TutelAmdError(f"tutel_amd: dtype {t.dtype} is not supported by the HIP kernels") from None
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.TutelAmdError(
+                "tutel_amd: the MoE hot path runs on the HIP device only (got a CPU tensor); "
+                "there is no CPU fallback.")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def supported_dtype(dtype):
+    return dtype in _DT
+
+
+# ---------------------------------------------------------------------------------------------
+# routing
+# ---------------------------------------------------------------------------------------------
+def routing_workspace(T, E, k, device):
+    n = _lib.lib().tutel_amd_routing_workspace_bytes(T, E, k)
+    return torch.empty([max(int(n), 4)], dtype=torch.uint8, device=device)
+
+
+def gate_topk(inp, k, apply_softmax=False, normalize_gate=True, want_scores=False, ws=None):
+    """inp [T,E] scores (or logits with apply_softmax) -> idx [k,T] i32, gates [k,T], ws, scores|None."""
+    _dev(inp)
+    assert inp.dim() == 2
+    inp = inp.contiguous()
+    T, E = inp.shape
+    k = min(int(k), E)
+    idx = torch.empty([k, T], dtype=torch.int32, device=inp.device)
+    gates = torch.empty([k, T], dtype=inp.dtype, device=inp.device)
+    scores = torch.empty_like(inp) if (want_scores and apply_softmax) else None
+    if ws is None:
+        ws = routing_workspace(T, E, k, inp.device)
+    L = _lib.lib()
+    _lib.check(L.tutel_amd_gate_topk(_ptr(inp), _code(inp), int(bool(apply_softmax)), T, E, k,
+                                     int(bool(normalize_gate)), _ptr(scores), _ptr(idx), _ptr(gates),
+                                     _ptr(ws), ws.numel(), _stream()), "tutel_amd_gate_topk")
+    return idx, gates, ws, (scores if apply_softmax else inp)
+
+
+def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False):
+    """idx [k,T] -> loc [k,T], dispatch_count [E], stats [1] (max count), l_aux [1]|None, slot_map|None."""
+    _dev(idx)
+    assert idx.dtype == torch.int32 and idx.dim() == 2 and idx.is_contiguous()
+    k, T = idx.shape
+    dev = idx.device
+    hist_ready = ws is not None
+    if ws is None:
+        ws = routing_workspace(T, E, k, dev)
+    loc = torch.empty_like(idx)
+    cnt = torch.empty([E], dtype=torch.int32, device=dev)
+    stats = torch.empty([1], dtype=torch.int32, device=dev)
+    l_aux = torch.empty([1], dtype=torch.float32, device=dev) if (want_l_aux and hist_ready) else None
+    smap = torch.empty([E * capacity], dtype=torch.int32, device=dev) if capacity > 0 else None
+    L = _lib.lib()
+    _lib.check(L.tutel_amd_compute_location(_ptr(idx), T, E, k, int(hist_ready), _ptr(ws), ws.numel(),
+                                            _ptr(loc), _ptr(cnt), _ptr(stats), _ptr(l_aux),
+                                            int(capacity), _ptr(smap), _stream()),
+               "tutel_amd_compute_location")
+    return loc, cnt, stats, l_aux, smap
+
+
+def slot_map(idx, loc, E, capacity):
+    _dev(idx, loc)
+    assert idx.dtype == torch.int32 and loc.dtype == torch.int32
+    assert idx.is_contiguous() and loc.is_contiguous() and idx.shape == loc.shape
+    k, T = idx.shape
+    smap = torch.empty([E * capacity], dtype=torch.int32, device=idx.device)
+    _lib.check(_lib.lib().tutel_amd_slot_map(_ptr(idx), _ptr(loc), T, E, k, int(capacity), _ptr(smap),
+                                             _stream()), "tutel_amd_slot_map")
+    return smap
+
+
+def cumsum_sub_one(mask):
+    _dev(mask)
+    m = mask.to(torch.int32).contiguous()
+    out = torch.empty_like(m)
+    _lib.check(_lib.lib().tutel_amd_cumsum_sub_one(_ptr(m), _ptr(out), m.shape[0], m.shape[1], _stream()),
+               "tutel_amd_cumsum_sub_one")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# dispatch / combine
+# ---------------------------------------------------------------------------------------------
+def fast_encode(x, smap, gates, n_slots):
+    """x [T,M] -> [n_slots, M]; gates [k,T] or None (is_postscore)."""
+    _dev(x, smap, gates)
+    assert x.dim() == 2 and x.is_contiguous() and smap.dtype == torch.int32 and smap.numel() == n_slots
+    T, M = x.shape
+    out = torch.empty([n_slots, M], dtype=x.dtype, device=x.device)
+    if gates is not None:
+        assert gates.is_contiguous()
+    _lib.check(_lib.lib().tutel_amd_fast_encode(_ptr(x), _code(x), _ptr(smap), _ptr(gates),
+                                                _code(gates) if gates is not None else 0, T, M,
+                                                int(n_slots), _ptr(out), _stream()),
+               "tutel_amd_fast_encode")
+    return out
+
+
+def fast_decode(buf, idx, loc, gates, capacity):
+    """buf [E*C, M] -> [T, M]; gates [k,T] or None (= ones)."""
+    _dev(buf, idx, loc, gates)
+    assert buf.dim() == 2 and buf.is_contiguous()
+    assert idx.dtype == torch.int32 and loc.dtype == torch.int32 and idx.is_contiguous() and loc.is_contiguous()
+    k, T = idx.shape
+    M = buf.shape[1]
+    out = torch.empty([T, M], dtype=buf.dtype, device=buf.device)
+    if gates is not None:
+        assert gates.is_contiguous() and gates.shape == idx.shape
+    _lib.check(_lib.lib().tutel_amd_fast_decode(_ptr(buf), _code(buf), _ptr(idx), _ptr(loc), _ptr(gates),
+                                                _code(gates) if gates is not None else 0, T, M, k,
+                                                int(capacity), _ptr(out), _stream()),
+               "tutel_amd_fast_decode")
+    return out
+
+
+def gate_grad(x, buf, idx, loc, capacity):
+    """ggate [k,T] fp32 = <buf[slot(j,t)], x[t]>."""
+    _dev(x, buf, idx, loc)
+    assert x.is_contiguous() and buf.is_contiguous() and x.dtype == buf.dtype
+    k, T = idx.shape
+    M = x.shape[1]
+    out = torch.empty([k, T], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().tutel_amd_gate_grad(_ptr(x), _ptr(buf), _code(x), _ptr(idx), _ptr(loc), T, M, k,
+                                              int(capacity), _ptr(out), _stream()), "tutel_amd_gate_grad")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# expert grouped GEMM
+# ---------------------------------------------------------------------------------------------
+def gemm_supported(dtype, N, K):
+    return dtype in (torch.bfloat16, torch.float16) and K % 64 == 0 and N % 8 == 0
+
+
+def expert_gemm(a, w, bias, w_kmajor, act="none", E_loc=None, R=None, a_layout=None, out=None,
+                d_layout=None, row_counts=None, row_align=1):
+    """D[e,r,:] = act(A[e,r,:] @ op(W[e]) + bias[e]).
+
+    a: [E_loc, R, K] contiguous, or any buffer described by a_layout=(stride_e, stride_w, rows_per_w, lda)
+    w: [E_loc, N, K] (w_kmajor) or [E_loc, K, N]; bias [E_loc, N] or None.
+    out/d_layout likewise (default: new contiguous [E_loc, R, N])."""
+    _dev(a, w, bias, out, row_counts)
+    assert w.dim() == 3 and w.is_contiguous()
+    if w_kmajor:
+        El, N, K = w.shape
+    else:
+        El, K, N = w.shape
+    E_loc = El if E_loc is None else E_loc
+    if a_layout is None:
+        assert a.dim() == 3 and a.is_contiguous() and a.shape[0] == E_loc and a.shape[2] == K
+        R = a.shape[1]
+        a_layout = (R * K, 0, R, K)
+    assert R is not None
+    if out is None:
+        out = torch.empty([E_loc, R, N], dtype=a.dtype, device=a.device)
+        d_layout = (R * N, 0, R, N)
+    assert d_layout is not None
+    if bias is not None:
+        assert bias.is_contiguous() and bias.shape[-1] == N and bias.dtype == a.dtype
+    assert w.dtype == a.dtype
+    _lib.check(_lib.lib().tutel_amd_expert_gemm(
+        _ptr(a), a_layout[0], a_layout[1], a_layout[2], a_layout[3],
+        _ptr(w), int(bool(w_kmajor)), w.stride(0), w.stride(1),
+        _ptr(bias), (bias.stride(0) if bias is not None else 0),
+        _ptr(out), d_layout[0], d_layout[1], d_layout[2], d_layout[3],
+        E_loc, R, N, K, _code(a), ACT_CODES[act],
+        _ptr(row_counts), int(row_align), _stream()), "tutel_amd_expert_gemm")
+    return out
+
+
+def probe_tr16():
+    out = torch.empty([256], dtype=torch.int16, device="cuda")
+    _lib.check(_lib.lib().tutel_amd_probe_tr16(_ptr(out), _stream()), "tutel_amd_probe_tr16")
+    return out
