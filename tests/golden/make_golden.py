@@ -1,0 +1,235 @@
+"""Generates tests/golden/*.npz by running the REFERENCE itself (microsoft/tutel, python package
+from /root/reference + its own C++ CPU kernels compiled into oracle/_ref/ by oracle/Makefile).
+Only runs in the build container (the GPU box has no /root/reference); the fixtures are committed.
+
+    make -C oracle && python tests/golden/make_golden.py
+
+Inputs are regenerated from seeds by oracle.moe_oracle.make_problem on any box (torch CPU
+generator, deterministic), so the fixtures hold the reference's OUTPUTS plus an input checksum.
+With --check the script instead compares the oracle against the live reference, function by
+function (used by tests/test_oracle_vs_reference.py)."""
+import argparse
+import logging
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("TUTEL_REFERENCE", "/root/reference")
+# the reference package is also called `tutel`: it must win over the repo's alias package
+sys.path = [REF, os.path.join(ROOT, "oracle", "_ref")] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT] + [ROOT]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+logging.disable(logging.CRITICAL)
+import tutel  # noqa: E402
+assert os.path.abspath(tutel.__file__).startswith(REF), tutel.__file__
+from tutel import moe as ref_moe  # noqa: E402
+from tutel.impls import losses as ref_losses  # noqa: E402
+from oracle import moe_oracle as O  # noqa: E402
+
+DT = {"float32": torch.float32, "float64": torch.float64, "bfloat16": torch.bfloat16, "float16": torch.float16}
+
+# (name, T, M, H, E, k, capacity_factor, dtype, fp32_gate, is_postscore, normalize_gate)
+LAYER_CASES = [
+    ("f32_k2_cf1", 512, 64, 32, 16, 2, 1.0, "float32", False, True, True),
+    ("f32_k1_cf1", 512, 64, 32, 16, 1, 1.0, "float32", False, True, True),
+    ("f32_k2_drop", 512, 64, 32, 16, 2, 0.5, "float32", False, True, True),
+    ("f32_k2_dropless", 512, 64, 32, 16, 2, 0.0, "float32", False, True, True),
+    ("f32_k2_cf2_prescore", 512, 64, 32, 16, 2, 2.0, "float32", False, False, True),
+    ("f32_k4_nonorm", 300, 64, 32, 12, 4, 1.0, "float32", False, True, False),
+    ("f64_k2_cf1", 256, 64, 32, 8, 2, 1.0, "float64", False, True, True),
+    ("bf16_k2_fp32gate", 512, 64, 64, 16, 2, 1.0, "bfloat16", True, True, True),
+    ("f16_k2_fp32gate", 512, 64, 64, 16, 2, 1.0, "float16", True, True, True),
+    ("c0_plumbing", 2048, 2048, 128, 2, 1, 1.0, "float32", False, True, True),  # BASELINE configs[0] shape
+]
+
+
+def build_reference_layer(T, M, H, E, k, cf, dtype, fp32_gate, is_postscore, normalize_gate, seed):
+    x, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=dtype, seed=seed)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        layer = ref_moe.moe_layer(
+            gate_type={"type": "top", "k": k, "fp32_gate": fp32_gate, "capacity_factor": cf},
+            experts={"type": "ffn", "num_experts_per_device": E, "hidden_size_per_expert": H,
+                     "activation_fn": lambda t: torch.nn.functional.relu(t)},
+            model_dim=M, is_postscore=is_postscore, normalize_gate=normalize_gate)
+    finally:
+        torch.set_default_dtype(old)
+    with torch.no_grad():
+        layer.gates[0].wg.weight.copy_(wg.to(layer.gates[0].wg.weight.dtype))
+        layer.experts.batched_fc1_w.copy_(w1)
+        layer.experts.batched_fc1_bias.copy_(b1)
+        layer.experts.batched_fc2_w.copy_(w2)
+        layer.experts.batched_fc2_bias.copy_(b2)
+    layer.eval()
+    return layer, (x, wg, w1, b1, w2, b2)
+
+
+def np_(t):
+    t = t.detach()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy()  # raw bits
+    return t.numpy()
+
+
+def checksum(tensors):
+    return float(sum(t.double().abs().sum() for t in tensors))
+
+
+def run_layer_case(case, seed=1234):
+    name, T, M, H, E, k, cf, dts, fp32_gate, post, norm = case
+    dtype = DT[dts]
+    layer, (x, wg, w1, b1, w2, b2) = build_reference_layer(T, M, H, E, k, cf, dtype, fp32_gate, post, norm, seed)
+    with torch.no_grad():
+        y = layer(x)
+        l_aux = y.l_aux
+        # intermediates through the reference's own low-level API
+        logits = layer.gates[0](x)
+        scores = torch.softmax(logits, dim=1)
+        crit, l2 = ref_moe.top_k_routing(scores, k, capacity_factor=cf, normalize_gate=norm)
+        enc = ref_moe.fast_encode(x.to(logits.dtype), crit, post).to(x.dtype)
+        ffn = layer.experts(enc, layer)
+    out = dict(
+        meta=np.array([T, M, H, E, k, int(fp32_gate), int(post), int(norm), seed], dtype=np.int64),
+        cf=np.array([cf]), dtype=np.array([dts]), in_checksum=np.array([checksum([x, wg, w1, b1, w2, b2])]),
+        scores=np_(scores), idx=np.stack([np_(i) for i in crit[1]]), loc=np.stack([np_(i) for i in crit[2]]),
+        gates=np.stack([np_(g) for g in crit[3]]), capacity=np.array([crit[4]]),
+        dispatch_count=np_(crit[5].to(torch.int32)), l_aux=np.array([float(l_aux)]))
+    # big outputs are stored as a row subsample + a checksum to keep the fixtures small
+    stride = 1 if y.numel() <= (1 << 16) else 32
+    out.update(y=np_(y[::stride].contiguous()), y_row_stride=np.array([stride]),
+               y_abs_sum=np.array([float(y.double().abs().sum())]))
+    if stride > 1:
+        out["scores"] = np_(scores[::stride].contiguous())
+    if T * M <= 512 * 64:
+        out.update(encoded=np_(enc), expert_out=np_(ffn))
+    return name, out, (layer, x, crit)
+
+
+def headline_integer_case(seed=0):
+    """BASELINE configs[1] shape, integer tensors only (T=4096, E=64, k=2, cf=1): tiny."""
+    g = torch.Generator().manual_seed(seed)
+    scores = torch.softmax(torch.randn([4096, 64], generator=g), dim=1)
+    out = {}
+    for cf in (1.0, 0.0):
+        crit, l_aux = ref_moe.top_k_routing(scores, 2, capacity_factor=cf)
+        tag = "cf1" if cf > 0 else "dropless"
+        out[f"idx_{tag}"] = np.stack([np_(i) for i in crit[1]])
+        out[f"loc_{tag}"] = np.stack([np_(i) for i in crit[2]])
+        out[f"capacity_{tag}"] = np.array([crit[4]])
+        out[f"count_{tag}"] = np_(crit[5].to(torch.int32))
+        out[f"l_aux_{tag}"] = np.array([float(l_aux)])
+    out["seed"] = np.array([seed])
+    return out
+
+
+def train_losses_case(E_loc=2, k=2, steps=4, T=1024, M=256, H=256, seed=5):
+    """A short training replay in the style of the reference's golden-loss tests
+    (tests/test_tutel.py:94-148 over examples/helloworld.py:126-146): fwd + bwd + SGD, fp32."""
+    layer, (x, *_rest) = build_reference_layer(T, M, H, E_loc, k, 1.0, torch.float32, False, True, True, seed)
+    layer.train()
+    opt = torch.optim.SGD(layer.parameters(), lr=1e-2)
+    xb = x.view(4, T // 4, M)
+    target = torch.zeros(4, dtype=torch.long)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        out = layer(xb)
+        loss = torch.nn.functional.nll_loss(torch.log_softmax(out.sum(dim=2), dim=1), target) + 0.01 * out.l_aux
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    return dict(losses=np.array(losses), meta=np.array([T, M, H, E_loc, k, steps, seed], dtype=np.int64))
+
+
+def check_oracle_against_reference():
+    """Function-by-function comparison of oracle/ against the live reference."""
+    bad = []
+
+    def expect(cond, what):
+        if not cond:
+            bad.append(what)
+
+    for dts in ("float32", "float64", "bfloat16", "float16"):
+        dtype = DT[dts]
+        for (T, E, k, cf) in [(512, 16, 2, 1.0), (512, 16, 1, 1.0), (4096, 64, 2, 1.0), (512, 16, 2, 0.0),
+                              (300, 7, 3, 1.5), (512, 16, 2, -0.5), (64, 2, 2, 1.0), (1000, 130, 4, 1.0)]:
+            g = torch.Generator().manual_seed(T + E + k)
+            scores = torch.softmax(torch.randn([T, E], generator=g), dim=1).to(dtype)
+            for norm in (True, False):
+                cr, lr = ref_moe.top_k_routing(scores, k, capacity_factor=cf, normalize_gate=norm)
+                co, lo = O.extract_critical(scores, k, cf, normalize_gate=norm)
+                tag = f"{dts} T={T} E={E} k={k} cf={cf} norm={norm}"
+                same_idx = all(torch.equal(a, b) for a, b in zip(cr[1], co[1]))
+                if dtype in (torch.float32, torch.float64):
+                    expect(same_idx, "topk indices " + tag)  # tie-free: must equal torch.topk
+                if not same_idx:  # exact ties (bf16/fp16): compare everything downstream of the tie
+                    co, lo = O.extract_critical(scores, k, cf, normalize_gate=norm, topk_override=cr[1])
+                    # and the tie rule itself must only differ on rows that really tie
+                    oi = torch.stack(O.topk_indices(scores, k)); ri = torch.stack(cr[1])
+                    rows = (oi != ri).any(0)
+                    s_o = scores.gather(1, oi.t().long())[rows]; s_r = scores.gather(1, ri.t().long())[rows]
+                    expect(torch.equal(s_o.sort(1)[0], s_r.sort(1)[0]), "tie rows pick equal scores " + tag)
+                expect(all(torch.equal(a, b) for a, b in zip(cr[2], co[2])), "locations " + tag)
+                expect(all(torch.equal(a, b) for a, b in zip(cr[3], co[3])), "gates " + tag)
+                expect(cr[4] == co[4], "capacity " + tag)
+                expect(torch.equal(cr[5].to(torch.int32), co[5]), "dispatch_count " + tag)
+                expect(torch.equal(lr, lo), "l_aux " + tag)
+            M = 48
+            x = torch.randn([T, M], generator=g).to(dtype)
+            y = torch.randn([E * cr[4], M], generator=g).to(dtype).view(E, -1, M)
+            for post in (True, False):
+                expect(torch.equal(ref_moe.fast_encode(x, cr, post), O.fast_encode(x, co, post)), f"encode post={post} " + tag)
+                expect(torch.equal(ref_moe.fast_decode(y, cr, post), O.fast_decode(y, co, post)), f"decode post={post} " + tag)
+        m = (torch.rand([777, 33]) < 0.2).to(torch.int64)
+        from tutel.jit_kernels.gating import fast_cumsum_sub_one
+        expect(torch.equal(fast_cumsum_sub_one(m).to(torch.int32), O.cumsum_sub_one(m)), "cumsum_sub_one")
+    # whole layer, including the dtype chain, against the reference layer
+    for case in LAYER_CASES[:9]:
+        name, out, (layer, x, crit) = run_layer_case(case)
+        _, T, M, H, E, k, cf, dts, fp32_gate, post, norm = case
+        _, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=DT[dts], seed=1234)
+        yo, lo, co, _ = O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k, capacity_factor=cf, fp32_gate=fp32_gate,
+                                      normalize_gate=norm, is_postscore=post)
+        with torch.no_grad():
+            yr = layer(x)
+        expect(torch.equal(yr, yo), f"layer output {name} maxdiff={(yr.double() - yo.double()).abs().max():.3e}")
+        expect(abs(float(yr.l_aux) - float(lo)) == 0, f"layer l_aux {name}")
+    # gate gradient kernel (backward-only row)
+    from tutel.impls.jit_compiler import tutel_custom_kernel as ck  # noqa
+    g = torch.Generator().manual_seed(9)
+    T, E, k, M = 200, 6, 2, 40
+    scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
+    cr, _ = ref_moe.top_k_routing(scores, k, capacity_factor=0.75)
+    x, buf = torch.randn([T, M], generator=g), torch.randn([E * cr[4], M], generator=g)
+    for j in range(k):
+        gg = torch.empty([T])
+        ck.invoke_cpu_fp32([gg, cr[1][j], cr[2][j], x, buf], [T, M, cr[4]], 2)
+        expect(torch.equal(gg, O.gate_grad(x, buf, cr[1][j], cr[2][j], cr[4])), f"gate_grad j={j}")
+    for b in bad:
+        print("MISMATCH:", b)
+    print("oracle-vs-reference: %d mismatches" % len(bad))
+    return len(bad)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    if args.check:
+        sys.exit(1 if check_oracle_against_reference() else 0)
+    for case in LAYER_CASES:
+        name, out, _ = run_layer_case(case)
+        np.savez_compressed(os.path.join(HERE, f"layer_{name}.npz"), **out)
+        print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items() if k in ("y", "idx")})
+    np.savez_compressed(os.path.join(HERE, "headline_integers.npz"), **headline_integer_case())
+    np.savez_compressed(os.path.join(HERE, "train_losses_top2_e2.npz"), **train_losses_case(2, 2))
+    np.savez_compressed(os.path.join(HERE, "train_losses_top1_e4.npz"), **train_losses_case(4, 1))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,235 @@
+"""Host-side logic on CPU: the drop-in API surface, capacity arithmetic, dtype chain, autograd
+wiring and -- with gloo at world_size 2 -- the expert-parallel exchange, its row layouts and the
+overlap chunking.  The HIP kernels are replaced by the oracle BY THE TEST (tests/_cpu_ops.py);
+the product itself has no CPU path (see test_abi.py::test_product_has_no_cpu_path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _cpu_ops
+
+
+def _make_layer(M, H, E_loc, k, cf=1.0, dtype=torch.float32, **kw):
+    from tutel import moe
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        layer = moe.moe_layer(
+            gate_type={"type": "top", "k": k, "capacity_factor": cf, **kw.pop("gate", {})},
+            experts={"type": "ffn", "num_experts_per_device": E_loc, "hidden_size_per_expert": H,
+                     "activation_fn": lambda t: torch.nn.functional.relu(t)},
+            model_dim=M, **kw)
+    finally:
+        torch.set_default_dtype(old)
+    return layer
+
+
+def _load(layer, wg, w1, b1, w2, b2):
+    with torch.no_grad():
+        layer.gates[0].wg.weight.copy_(wg.to(layer.gates[0].wg.weight.dtype))
+        layer.experts.batched_fc1_w.copy_(w1)
+        layer.experts.batched_fc1_bias.copy_(b1)
+        layer.experts.batched_fc2_w.copy_(w2)
+        layer.experts.batched_fc2_bias.copy_(b2)
+
+
+@pytest.mark.parametrize("k,cf,post,norm", [(2, 1.0, True, True), (1, 1.0, True, True), (2, 0.5, False, True),
+                                            (2, 0.0, True, False), (3, -0.5, True, True)])
+def test_layer_host_logic_matches_oracle(oracle, monkeypatch, k, cf, post, norm):
+    _cpu_ops.install(monkeypatch)
+    T, M, H, E = 384, 32, 16, 8
+    x, wg, w1, b1, w2, b2 = oracle.make_problem(T, M, H, E, seed=3)
+    layer = _make_layer(M, H, E, k, cf, is_postscore=post, normalize_gate=norm).eval()
+    _load(layer, wg, w1, b1, w2, b2)
+    with torch.no_grad():
+        y = layer(x.view(4, T // 4, M))
+    yo, lo, crit, _ = oracle.moe_forward(x, wg, w1, b1, w2, b2, top_k=k, capacity_factor=cf,
+                                         is_postscore=post, normalize_gate=norm)
+    assert y.shape == (4, T // 4, M)
+    assert torch.equal(y.view(T, M), yo)
+    assert abs(float(y.l_aux) - float(lo)) < 1e-6 and layer.l_aux is y.l_aux
+    assert torch.equal(layer.dispatch_count.cpu(), crit[5])
+
+
+def test_low_level_api_and_tuple_contract(oracle, monkeypatch):
+    """helloworld_from_scratch-style use: top_k_routing -> fast_encode -> expert -> fast_decode,
+    `crit` indexable like the reference's tuple, fast_dispatcher usable with foreign idx/loc."""
+    _cpu_ops.install(monkeypatch)
+    from tutel import moe
+    T, E, M, k = 200, 6, 16, 2
+    g = torch.Generator().manual_seed(1)
+    scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
+    x = torch.randn([T, M], generator=g)
+    crit, l_aux = moe.top_k_routing(scores, k, capacity_factor=1.5, alignment=4)
+    co, lo = oracle.extract_critical(scores, k, 1.5, alignment=4)
+    assert crit[0] == E and crit[4] == co[4] and crit[4] % 4 == 0 and len(crit) == 6
+    assert all(torch.equal(a, b) for a, b in zip(crit[1], co[1])) and all(torch.equal(a, b) for a, b in zip(crit[2], co[2]))
+    assert torch.equal(crit[-1], co[5]) and abs(float(l_aux) - float(lo)) < 1e-6
+    y = moe.fast_encode(x, crit)
+    assert y.shape == (E, crit[4], M) and torch.equal(y, oracle.fast_encode(x, co))
+    o = moe.fast_decode(y * 2, crit)
+    assert torch.equal(o, oracle.fast_decode(y * 2, co))
+    # dispatcher with caller-supplied vectors (separate tensors, int64 like a user might pass)
+    d = moe.fast_dispatcher(E, crit[4], M, torch.float32)
+    d.update([i.long() for i in crit[1]], [l.long() for l in crit[2]], [gt.clone() for gt in crit[3]], capacity=crit[4])
+    assert torch.equal(d.encode(x).view(E, -1, M), y)
+    # cumsum op
+    m = (torch.rand(50, 7, generator=g) < 0.3).long()
+    assert torch.equal(moe.fast_cumsum_sub_one(m), oracle.cumsum_sub_one(m))
+    with pytest.raises(Exception):
+        moe.fast_cumsum_sub_one(m, dim=1)
+
+
+def test_training_autograd_matches_dense_reference(oracle, monkeypatch):
+    """Backward through encode/decode/gates against plain torch autograd of the
+    same math built from one-hot matmuls."""
+    _cpu_ops.install(monkeypatch)
+    T, M, H, E, k = 96, 16, 8, 4, 2
+    x, wg, w1, b1, w2, b2 = oracle.make_problem(T, M, H, E, seed=11)
+    layer = _make_layer(M, H, E, k, 2.0).train()
+    _load(layer, wg, w1, b1, w2, b2)
+    xin = x.clone().requires_grad_(True)
+    y = layer(xin)
+    (y.sum() + y.l_aux).backward()
+
+    xr = x.clone().requires_grad_(True)
+    wgr, w1r, b1r, w2r, b2r = [t.clone().requires_grad_(True) for t in (wg, w1, b1, w2, b2)]
+    scores = torch.softmax(xr @ wgr.t(), dim=1)
+    crit, _ = oracle.extract_critical(scores.detach(), k, 2.0)
+    C = crit[4]
+    gates = [scores.gather(1, i.long().unsqueeze(-1)).squeeze(-1) for i in crit[1]]
+    den = torch.clamp(sum(gates), min=torch.finfo(torch.float32).eps)
+    gates = [gt / den for gt in gates]
+    disp = torch.zeros(T, E * C)
+    comb = torch.zeros(T, E * C)
+    for j in range(k):
+        keep = crit[2][j] < C
+        slot = crit[1][j].long() * C + crit[2][j].long()
+        r = torch.arange(T)[keep]
+        disp[r, slot[keep]] = 1.0
+        comb = comb + torch.zeros(T, E * C).index_put((r, slot[keep]), gates[j][keep])
+    enc = (disp.t() @ xr).view(E, C, M)
+    out = torch.relu(enc @ w1r.permute(0, 2, 1) + b1r.unsqueeze(1)) @ w2r + b2r.unsqueeze(1)
+    yr = comb @ out.view(E * C, M)
+    l_aux = oracle.gshard_loss(scores, crit[1][0])
+    (yr.sum() + l_aux).backward()
+    torch.testing.assert_close(y, yr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xin.grad, xr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(layer.gates[0].wg.weight.grad, wgr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(layer.experts.batched_fc1_w.grad, w1r.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(layer.experts.batched_fc2_bias.grad, b2r.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_constructor_contract(monkeypatch):
+    _cpu_ops.install(monkeypatch)
+    from tutel import moe
+    with pytest.raises(Exception, match="Unrecognized argument"):
+        _make_layer(16, 8, 2, 1, bogus=1)
+    layer = _make_layer(16, 8, 2, 2, pad_samples=True)  # tolerated, warns
+    assert layer.num_global_experts == 2 and layer.num_local_experts == 2 and layer.sharded_count == 1
+    assert layer.valid_rs == [0, 1] and layer.world_size == 1
+    assert {n for n, _ in layer.get_parameter_iterator("local_experts")} == {
+        "batched_fc1_w", "batched_fc2_w", "batched_fc1_bias", "batched_fc2_bias"}
+    assert [n for n, _ in layer.get_parameter_iterator("gate")] == ["0.wg.weight"]
+    assert all(getattr(p, "_tutel_expert", False) for p in layer.experts.parameters())
+    sd = layer.state_dict()
+    assert "_num_global_experts" in sd and sd["experts.batched_fc1_w"].shape == (2, 8, 16)
+    layer2 = _make_layer(16, 8, 2, 2)
+    layer2.load_state_dict(sd)
+    legacy = {k: v for k, v in sd.items() if k != "_num_global_experts"}
+    layer2.load_state_dict(legacy)  # legacy checkpoints load with a warning
+    top2 = moe.moe_layer("Top2Gate", 16, experts={"type": "ffn", "count_per_node": 2, "hidden_size_per_expert": 8})
+    assert top2.gates[0].top_k == 2
+    assert moe.moe_layer.global_expert_count(2) == 2
+    with pytest.raises(Exception):
+        moe.moe_layer.global_expert_count(0)
+
+
+def test_activation_classifier():
+    from tutel_amd.experts.ffn import classify_activation
+    import torch.nn.functional as F
+    assert classify_activation(lambda t: F.relu(t)) == "relu"
+    assert classify_activation(F.gelu) == "gelu" and classify_activation(F.silu) == "silu"
+    assert classify_activation(lambda t: t) == "none" and classify_activation("relu") == "relu"
+    drop = torch.nn.Dropout(0.5).train()
+    assert classify_activation(lambda t: drop(F.relu(t))) is None  # stochastic -> never fused
+    assert classify_activation(lambda t: F.relu(t) * 1.5) is None
+
+
+# ---- world_size 2 over gloo ---------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ep_worker(rank, world, port, degree, use_2dh, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import _cpu_ops as shim
+        from oracle import moe_oracle as O
+        from tutel_amd import ops
+        for name in ("gate_topk", "compute_location", "slot_map", "cumsum_sub_one", "fast_encode", "fast_decode", "gate_grad"):
+            setattr(ops, name, getattr(shim, name))
+        from tutel import system, net
+        env = system.init_data_model_parallel(backend="gloo")
+        assert env.global_size == world and env.global_rank == rank and net.get_world_size() == world
+        T, M, H, E_loc, k = 256, 32, 16, 2, 2
+        E = E_loc * world
+        torch.manual_seed(0)
+        # global problem, identical on every rank; each rank keeps its slice of experts and its own tokens
+        xs = [O.make_problem(T, M, H, E, seed=100 + r)[0] for r in range(world)]
+        _, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, seed=7)
+        sl = slice(rank * E_loc, (rank + 1) * E_loc)
+        layer = _make_layer(M, H, E_loc, k, 1.0, a2a_ffn_overlap_degree=degree, use_2dh=use_2dh).eval()
+        assert layer.num_global_experts == E and layer.world_size == world
+        _load(layer, wg, w1[sl], b1[sl], w2[sl], b2[sl])
+        with torch.no_grad():
+            y = layer(xs[rank])
+        want, crits = O.moe_forward_ep(xs, wg, [w1[r * E_loc:(r + 1) * E_loc] for r in range(world)],
+                                       [b1[r * E_loc:(r + 1) * E_loc] for r in range(world)],
+                                       [w2[r * E_loc:(r + 1) * E_loc] for r in range(world)],
+                                       [b2[r * E_loc:(r + 1) * E_loc] for r in range(world)],
+                                       top_k=k, alignment=degree)
+        ok = torch.equal(y, want[rank])
+        # the flexible all_to_all itself, against the oracle's byte layout
+        enc = O.fast_encode(xs[rank], crits[rank])
+        got = net.all_to_all(enc, 1, 0)
+        encs = [O.fast_encode(xs[r], crits[r]) for r in range(world)]
+        ok = ok and torch.equal(got, O.a2a_dispatch(encs)[rank])
+        ok = ok and torch.equal(net.all_to_all(got, 0, 1), enc)
+        ok = ok and torch.equal(net.all_to_all(enc, 1, 0, use_2dh=True), got)
+        # dropless capacity is agreed on across ranks (all-reduce MAX, fast_dispatch.py:192-193)
+        with torch.no_grad():
+            layer(xs[rank], capacity_factor=0.0)
+        caps = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+        dist.all_gather(caps, torch.tensor([layer.protected_shape[1]]))
+        ok = ok and len({int(c) for c in caps}) == 1
+        q.put((rank, bool(ok), float((y - want[rank]).abs().max())))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("degree,use_2dh", [(1, False), (2, False), (1, True)])
+def test_expert_parallel_world2_gloo(degree, use_2dh):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ep_worker, args=(r, 2, port, degree, use_2dh, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, info in res:
+        assert ok, f"rank {rank}: {info}"

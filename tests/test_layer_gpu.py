@@ -1,0 +1,207 @@
+"""GPU parity tests, layer level: tutel.moe.moe_layer / the low-level tutel.moe API on the
+MI355X against (a) fixtures produced by the reference itself and (b) the CPU oracle.
+
+Tolerances (BASELINE.json north_star: 1e-5 fp32 / 1e-3 fp16, bit-exact index assignment):
+  fp32 / fp64 : |y - y_ref| <= 1e-5 * max(1, |y_ref|_inf)   (ATen fp32/fp64 GEMMs on both sides,
+                summation order differs between CPU and GPU BLAS)
+  fp16        : <= 1e-3 absolute
+  bf16        : bf16 has 8 significand bits; the bar is 2 bf16 ulps of the result magnitude
+                (rtol 2^-7) + 2e-3 absolute against an fp32-accumulated oracle on the same
+                bf16-rounded inputs (SURVEY section 7 hard part 7)
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DT = {"float32": torch.float32, "float64": torch.float64, "bfloat16": torch.bfloat16, "float16": torch.float16}
+
+
+def _t(a, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.view(torch.bfloat16) if dtype == torch.bfloat16 else t
+
+
+def make_layer(M, H, E, k, cf, dtype, weights=None, **kw):
+    from tutel import moe
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        gate = {"type": "top", "k": k, "capacity_factor": cf}
+        gate.update(kw.pop("gate", {}))
+        layer = moe.moe_layer(gate_type=gate,
+                              experts={"type": "ffn", "num_experts_per_device": E, "hidden_size_per_expert": H,
+                                       "activation_fn": lambda t: torch.nn.functional.relu(t)},
+                              model_dim=M, **kw)
+    finally:
+        torch.set_default_dtype(old)
+    if weights is not None:
+        wg, w1, b1, w2, b2 = weights
+        with torch.no_grad():
+            layer.gates[0].wg.weight.copy_(wg.to(layer.gates[0].wg.weight.dtype))
+            layer.experts.batched_fc1_w.copy_(w1)
+            layer.experts.batched_fc1_bias.copy_(b1)
+            layer.experts.batched_fc2_w.copy_(w2)
+            layer.experts.batched_fc2_bias.copy_(b2)
+    return layer.cuda()
+
+
+def _close(y, ref, dtype):
+    y, ref = y.double().cpu(), ref.double().cpu()
+    err = (y - ref).abs()
+    if dtype in (torch.float32, torch.float64):
+        assert float(err.max()) <= 1e-5 * max(1.0, float(ref.abs().max())), float(err.max())
+    elif dtype == torch.float16:
+        assert float(err.max()) <= 1e-3, float(err.max())
+    else:
+        assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), float(err.max())
+
+
+def test_hip_library_is_the_loaded_code():
+    from tutel_amd import _lib
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "tutel_amd/lib/libtutel_amd.so" in maps
+
+
+CASES = sorted(glob.glob(os.path.join(GOLD, "layer_*.npz")))
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[6:-4])
+def test_layer_vs_reference_fixture(oracle, path):
+    z = np.load(path)
+    T, M, H, E, k, fp32_gate, post, norm, seed = [int(v) for v in z["meta"]]
+    dtype, cf = DT[str(z["dtype"][0])], float(z["cf"][0])
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed)
+    layer = make_layer(M, H, E, k, cf, dtype, weights, is_postscore=bool(post), normalize_gate=bool(norm),
+                       gate={"fp32_gate": bool(fp32_gate)}).eval()
+    with torch.no_grad():
+        y = layer(x.cuda())
+    stride = int(z["y_row_stride"][0])
+    # token -> expert/slot assignment: bit-exact (dispatch_count is its order-free digest; the
+    # low-level test below checks idx/loc element-wise on the fixture's own scores)
+    assert torch.equal(layer.dispatch_count.cpu(), torch.from_numpy(z["dispatch_count"]))
+    assert y.dtype == dtype and y.shape == (T, M)
+    _close(y[::stride], _t(z["y"], dtype), dtype)
+    assert abs(float(y.l_aux) - float(z["l_aux"][0])) <= (1e-5 if dtype == torch.float32 or fp32_gate else 1e-2)
+
+
+@pytest.mark.parametrize("path", [p for p in CASES if "c0_" not in p], ids=lambda p: os.path.basename(p)[6:-4])
+def test_low_level_api_vs_reference_fixture(oracle, path):
+    """tutel.moe.top_k_routing / fast_encode / fast_decode on the fixture's scores."""
+    from tutel import moe
+    z = np.load(path)
+    T, M, H, E, k, fp32_gate, post, norm, seed = [int(v) for v in z["meta"]]
+    dtype, cf = DT[str(z["dtype"][0])], float(z["cf"][0])
+    gdt = torch.float32 if fp32_gate else dtype
+    scores = _t(z["scores"], gdt).cuda()
+    crit, l_aux = moe.top_k_routing(scores, k, capacity_factor=cf, normalize_gate=bool(norm))
+    assert torch.equal(torch.stack(crit[1]).cpu(), torch.from_numpy(z["idx"]))
+    assert torch.equal(torch.stack(crit[2]).cpu(), torch.from_numpy(z["loc"]))
+    assert crit[4] == int(z["capacity"][0]) and crit[0] == E
+    assert torch.equal(crit[5].cpu(), torch.from_numpy(z["dispatch_count"]))
+    if gdt != torch.float64:
+        assert torch.equal(torch.stack(crit[3]).cpu(), _t(z["gates"], gdt)), "gates bit-exact"
+    assert abs(float(l_aux) - float(z["l_aux"][0])) <= (1e-6 if gdt in (torch.float32, torch.float64) else 1e-2)
+    if "encoded" in z.files:
+        x = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed)[0]
+        enc = moe.fast_encode(x.cuda(), crit, bool(post))
+        assert torch.equal(enc.cpu(), _t(z["encoded"], dtype)), "fast_encode bit-exact"
+        # decode of the REFERENCE's expert output must reproduce the reference's layer output
+        ffn = _t(z["expert_out"], dtype).cuda()
+        dec = moe.fast_decode(ffn.to(gdt), crit, bool(post)).to(dtype)
+        assert torch.equal(dec.cpu().float(), _t(z["y"], dtype).float()), "fast_decode reproduces the reference exactly"
+
+
+def test_headline_integer_fixture_on_gpu():
+    """BASELINE configs[1] routing (T=4096, E=64, k=2): reference's assignment, bit-exact."""
+    from tutel import moe
+    z = np.load(os.path.join(GOLD, "headline_integers.npz"))
+    g = torch.Generator().manual_seed(int(z["seed"][0]))
+    scores = torch.softmax(torch.randn([4096, 64], generator=g), dim=1).cuda()
+    for tag, cf in (("cf1", 1.0), ("dropless", 0.0)):
+        crit, l_aux = moe.top_k_routing(scores, 2, capacity_factor=cf)
+        assert torch.equal(torch.stack(crit[1]).cpu(), torch.from_numpy(z[f"idx_{tag}"]))
+        assert torch.equal(torch.stack(crit[2]).cpu(), torch.from_numpy(z[f"loc_{tag}"]))
+        assert crit[4] == int(z[f"capacity_{tag}"][0])
+        assert torch.equal(crit[5].cpu(), torch.from_numpy(z[f"count_{tag}"]))
+        assert abs(float(l_aux) - float(z[f"l_aux_{tag}"][0])) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_headline_shape_layer_vs_oracle(oracle, dtype):
+    """BASELINE configs[1]: T=4096, M=H=2048, E=64, top-2, cf=1 -- the HIP path end to end
+    (fused routing, encode, 2 MFMA grouped GEMMs, decode) vs the fp32-accumulating oracle."""
+    T, M, H, E, k = 4096, 2048, 2048, 64, 2
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=0)
+    layer = make_layer(M, H, E, k, 1.0, dtype, weights, gate={"fp32_gate": True}).eval()
+    with torch.no_grad():
+        y = layer(x.cuda().view(16, 256, M))
+    yo, lo, crit, _ = oracle.moe_forward(x, *weights, top_k=k, capacity_factor=1.0, fp32_gate=True, accum_fp32=True)
+    assert crit[4] == 128 and y.shape == (16, 256, M)
+    # fp32 gate: GPU and CPU logits differ by GEMM summation order only; assignment must agree
+    assert torch.equal(layer.dispatch_count.cpu(), crit[5])
+    _close(y.view(T, M), yo, dtype)
+    assert abs(float(y.l_aux) - float(lo)) < 1e-5
+
+
+def test_dropless_megablocks_equals_dense(oracle):
+    """BASELINE configs[2]: capacity_factor=0 + megablocks_size>0 == the same problem with the
+    dense expert GEMM on every row decode reads."""
+    T, M, H, E, k = 2048, 256, 256, 16, 2
+    dtype = torch.bfloat16
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=2)
+    layer = make_layer(M, H, E, k, 0.0, dtype, weights, gate={"fp32_gate": True}).eval()
+    with torch.no_grad():
+        dense = layer(x.cuda())
+        cap_dense = layer.protected_shape[1]
+        mega = layer(x.cuda(), megablocks_size=4)
+        assert layer.megablocks_size == 4 and layer.protected_shape[1] % 4 == 0 and layer.protected_shape[1] >= cap_dense
+    assert torch.equal(dense, mega)
+    yo, _, crit, _ = oracle.moe_forward(x, *weights, top_k=k, capacity_factor=0.0, fp32_gate=True, accum_fp32=True)
+    assert cap_dense == crit[4] == int(crit[5].max())
+    _close(dense, yo, dtype)
+
+
+@pytest.mark.parametrize("name,E_loc,k", [("train_losses_top2_e2", 2, 2), ("train_losses_top1_e4", 4, 1)])
+def test_training_replay_matches_reference_losses(oracle, name, E_loc, k):
+    """fwd + bwd + SGD for a few steps (the style of the reference's golden-loss tests,
+    tests/test_tutel.py:94-148): dispatch/combine backward on the HIP kernels."""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    T, M, H, E, k_, steps, seed = [int(v) for v in z["meta"]]
+    x, *weights = oracle.make_problem(T, M, H, E, seed=seed)
+    layer = make_layer(M, H, E, k, 1.0, torch.float32, weights).train()
+    opt = torch.optim.SGD(layer.parameters(), lr=1e-2)
+    xb = x.cuda().view(4, T // 4, M)
+    target = torch.zeros(4, dtype=torch.long, device="cuda")
+    got = []
+    for _ in range(steps):
+        opt.zero_grad()
+        out = layer(xb)
+        loss = torch.nn.functional.nll_loss(torch.log_softmax(out.sum(dim=2), dim=1), target) + 0.01 * out.l_aux
+        loss.backward()
+        opt.step()
+        got.append(float(loss))
+    ref = z["losses"]
+    assert np.allclose(np.array(got), ref, rtol=2e-4, atol=2e-4), (got, ref.tolist())
+
+
+def test_autocast_and_misc_paths(oracle):
+    T, M, H, E, k = 512, 128, 128, 8, 2
+    x, *weights = oracle.make_problem(T, M, H, E, seed=4)
+    layer = make_layer(M, H, E, k, 1.0, torch.float32, weights).eval()
+    with torch.no_grad():
+        ref = layer(x.cuda())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = layer(x.cuda())
+        assert y.dtype == torch.float32
+        assert float((y - ref).abs().max()) < 0.05 * float(ref.abs().max())
+        y3 = layer(x.cuda().view(2, 4, T // 8, M), top_k=1, capacity_factor=2.0)  # per-call overrides, N-d input
+        assert y3.shape == (2, 4, T // 8, M)
+    res = make_layer(M, H, E, k, 1.0, torch.float32, weights, result_func=lambda t: t * 2).eval()
+    with torch.no_grad():
+        assert torch.equal(res(x.cuda()), ref * 2)

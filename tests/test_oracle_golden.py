@@ -1,0 +1,80 @@
+"""The oracle replayed against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  Runs on any box: this is what pins the oracle on the GPU box,
+where /root/reference does not exist."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DT = {"float32": torch.float32, "float64": torch.float64, "bfloat16": torch.bfloat16, "float16": torch.float16}
+
+
+def _t(a, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.view(torch.bfloat16) if dtype == torch.bfloat16 else t
+
+
+CASES = sorted(glob.glob(os.path.join(GOLD, "layer_*.npz")))
+
+
+def test_fixtures_present():
+    assert len(CASES) >= 10 and os.path.exists(os.path.join(GOLD, "headline_integers.npz"))
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[6:-4])
+def test_oracle_layer_matches_reference_fixture(oracle, path):
+    z = np.load(path)
+    T, M, H, E, k, fp32_gate, post, norm, seed = [int(v) for v in z["meta"]]
+    dtype, cf = DT[str(z["dtype"][0])], float(z["cf"][0])
+    x, wg, w1, b1, w2, b2 = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed)
+    chk = float(sum(t.double().abs().sum() for t in (x, wg, w1, b1, w2, b2)))
+    assert chk == float(z["in_checksum"][0]), "seeded inputs must regenerate bit-identically"
+    y, l_aux, crit, st = oracle.moe_forward(x, wg, w1, b1, w2, b2, top_k=k, capacity_factor=cf,
+                                            fp32_gate=bool(fp32_gate), normalize_gate=bool(norm), is_postscore=bool(post))
+    stride = int(z["y_row_stride"][0])
+    assert torch.equal(torch.stack(crit[1]), torch.from_numpy(z["idx"])), "expert indices"
+    assert torch.equal(torch.stack(crit[2]), torch.from_numpy(z["loc"])), "locations"
+    assert crit[4] == int(z["capacity"][0])
+    assert torch.equal(crit[5], torch.from_numpy(z["dispatch_count"]))
+    gdt = torch.float32 if fp32_gate else dtype
+    assert torch.equal(torch.stack(crit[3]), _t(z["gates"], gdt)), "gates"
+    assert torch.equal(st["scores"][::stride], _t(z["scores"], gdt))
+    assert float(l_aux) == float(z["l_aux"][0])
+    assert torch.equal(y[::stride], _t(z["y"], dtype)), "layer output must equal the reference bit for bit"
+    assert float(y.double().abs().sum()) == float(z["y_abs_sum"][0])
+    if "encoded" in z.files:
+        assert torch.equal(st["encoded"], _t(z["encoded"], dtype))
+        assert torch.equal(st["expert_out"], _t(z["expert_out"], dtype))
+
+
+def test_headline_integer_fixture(oracle):
+    """BASELINE configs[1] shape: token->expert/slot assignment of the reference, bit-exact."""
+    z = np.load(os.path.join(GOLD, "headline_integers.npz"))
+    g = torch.Generator().manual_seed(int(z["seed"][0]))
+    scores = torch.softmax(torch.randn([4096, 64], generator=g), dim=1)
+    for tag, cf in (("cf1", 1.0), ("dropless", 0.0)):
+        crit, l_aux = oracle.extract_critical(scores, 2, cf)
+        assert torch.equal(torch.stack(crit[1]), torch.from_numpy(z[f"idx_{tag}"]))
+        assert torch.equal(torch.stack(crit[2]), torch.from_numpy(z[f"loc_{tag}"]))
+        assert crit[4] == int(z[f"capacity_{tag}"][0])
+        assert torch.equal(crit[5], torch.from_numpy(z[f"count_{tag}"]))
+        assert float(l_aux) == float(z[f"l_aux_{tag}"][0])
+
+
+def test_oracle_edge_cases(oracle):
+    # every token dropped for one choice (capacity 1), empty experts, k > E clamps, T < E
+    scores = torch.softmax(torch.randn(5, 9), dim=1)
+    crit, _ = oracle.extract_critical(scores, 20, 1.0)
+    assert len(crit[1]) == 9 and crit[4] == 9 * int(1.0 * 1)
+    x = torch.randn(5, 6)
+    enc = oracle.fast_encode(x, crit)
+    dec = oracle.fast_decode(enc, crit, is_postscore=False)
+    kept = torch.stack([l < crit[4] for l in crit[2]]).sum(0).float()
+    torch.testing.assert_close(dec, x * kept.unsqueeze(1), rtol=1e-6, atol=1e-6)  # 9 sequential fp32 adds
+    # a2a layout round trip
+    per_rank = [torch.randn(4, 3, 5) for _ in range(2)]
+    back = oracle.a2a_combine(oracle.a2a_dispatch(per_rank), 3)
+    assert all(torch.equal(a, b) for a, b in zip(per_rank, back))

@@ -36,16 +36,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-  __device__ static __forceinline__ f32x16 run(const vec16 &a, const vec16 &b, f32x16 c) {
+  __device__ static __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
 };
 template <> struct Mma<f16_t> {
-  __device__ static __forceinline__ f32x16 run(const vec16 &a, const vec16 &b, f32x16 c) {
+  __device__ static __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
@@ -143,23 +145,6 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_kernel(GemmArgs p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  vec16 ra[4], rw[4];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const vec16 *>(a_src[i] + (size_t)kt * GM_BK);
-      rw[i] = *reinterpret_cast<const vec16 *>(w_src[i] + (size_t)kt * w_step);
-    }
-  };
-  auto lstore = [&](int buf) {
-    uint16_t *da = sA + buf * A_TILE, *dw = sW + buf * W_TILE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<vec16 *>(da + a_dst[i]) = ra[i];
-      *reinterpret_cast<vec16 *>(dw + w_dst[i]) = rw[i];
-    }
-  };
-
   // fragment read offsets (elements), constant over the K loop
   const int l31 = lane & 31, kg = lane >> 5;
   const int a_frag_off = (wm * 64 + l31) * GM_LDK + kg * 8;             // + mi*32*LDK + kk*16
@@ -171,35 +156,67 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_kernel(GemmArgs p) 
   const int wt_frag_off = ((g16 >> 1) * 8 + (i16 >> 2)) * GM_LDN + wn * 64 + (g16 & 1) * 16 + 4 * (i16 & 3);
 
   const int nk = p.K / GM_BK;
-  gload(0);
-  lstore(0);
+
+  // Prefetch registers: plain named vectors, straight-line code (no lambdas / conditionals --
+  // hipcc demotes captured aggregates to scratch and then waits vmcnt(0) after every load).
+  u32x4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define GM_GLOAD(KT)                                                                   \
+  do {                                                                                 \
+    const size_t ao_ = (size_t)(KT) * GM_BK, wo_ = (size_t)(KT) * w_step;              \
+    ra0 = *reinterpret_cast<const u32x4 *>(a_src[0] + ao_);                            \
+    ra1 = *reinterpret_cast<const u32x4 *>(a_src[1] + ao_);                            \
+    ra2 = *reinterpret_cast<const u32x4 *>(a_src[2] + ao_);                            \
+    ra3 = *reinterpret_cast<const u32x4 *>(a_src[3] + ao_);                            \
+    rw0 = *reinterpret_cast<const u32x4 *>(w_src[0] + wo_);                            \
+    rw1 = *reinterpret_cast<const u32x4 *>(w_src[1] + wo_);                            \
+    rw2 = *reinterpret_cast<const u32x4 *>(w_src[2] + wo_);                            \
+    rw3 = *reinterpret_cast<const u32x4 *>(w_src[3] + wo_);                            \
+  } while (0)
+#define GM_LSTORE(BUF)                                                                 \
+  do {                                                                                 \
+    uint16_t *da_ = sA + (BUF) * A_TILE, *dw_ = sW + (BUF) * W_TILE;                   \
+    *reinterpret_cast<u32x4 *>(da_ + a_dst[0]) = ra0;                                  \
+    *reinterpret_cast<u32x4 *>(da_ + a_dst[1]) = ra1;                                  \
+    *reinterpret_cast<u32x4 *>(da_ + a_dst[2]) = ra2;                                  \
+    *reinterpret_cast<u32x4 *>(da_ + a_dst[3]) = ra3;                                  \
+    *reinterpret_cast<u32x4 *>(dw_ + w_dst[0]) = rw0;                                  \
+    *reinterpret_cast<u32x4 *>(dw_ + w_dst[1]) = rw1;                                  \
+    *reinterpret_cast<u32x4 *>(dw_ + w_dst[2]) = rw2;                                  \
+    *reinterpret_cast<u32x4 *>(dw_ + w_dst[3]) = rw3;                                  \
+  } while (0)
+
+  GM_GLOAD(0);
+  GM_LSTORE(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    // prefetch the next K-tile (the last iteration re-reads its own tile: harmless, keeps the
+    // loop body branch-free so the loads stay in flight across the MFMA block)
+    const int kn = (kt + 1 < nk) ? kt + 1 : kt;
+    GM_GLOAD(kn);
+    __builtin_amdgcn_sched_barrier(0);  // keep the 8 loads ABOVE the MFMA block (hipcc sinks them)
 
     const uint16_t *ca = sA + buf * A_TILE, *cw = sW + buf * W_TILE;
 #pragma unroll
     for (int kk = 0; kk < GM_BK / 16; ++kk) {
-      vec16 fa[2], fw[2];
+      u32x4 fa[2], fw[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
-        fa[mi] = *reinterpret_cast<const vec16 *>(ca + a_frag_off + mi * 32 * GM_LDK + kk * 16);
+        fa[mi] = *reinterpret_cast<const u32x4 *>(ca + a_frag_off + mi * 32 * GM_LDK + kk * 16);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         if (W_KMAJOR) {
-          fw[ni] = *reinterpret_cast<const vec16 *>(cw + wk_frag_off + ni * 32 * GM_LDK + kk * 16);
+          fw[ni] = *reinterpret_cast<const u32x4 *>(cw + wk_frag_off + ni * 32 * GM_LDK + kk * 16);
         } else {
           const uint16_t *ptr = cw + wt_frag_off + kk * 16 * GM_LDN + ni * 32;
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4_t *)(ptr));
           s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4_t *)(ptr + 4 * GM_LDN));
-          union { s16x4_t h[2]; vec16 v; } u;
-          u.h[0] = lo;
-          u.h[1] = hi;
-          fw[ni] = u.v;
+          u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+          u32x4 f = {lo2[0], lo2[1], hi2[0], hi2[1]};
+          fw[ni] = f;
         }
       }
 #pragma unroll
@@ -208,9 +225,12 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_kernel(GemmArgs p) 
         for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = Mma<T>::run(fw[ni], fa[mi], acc[ni][mi]);
     }
 
-    if (kt + 1 < nk) lstore(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    GM_LSTORE(buf ^ 1);
     __syncthreads();
   }
+#undef GM_GLOAD
+#undef GM_LSTORE
 
   // ---- epilogue: lane holds, per accumulator, row m = l31, features 8*rg + 4*kg + 0..3
   uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;

@@ -17,12 +17,14 @@
 //                         experts present (a counting-sort rank, no one-hot, no scan of [T,E]).
 //                         Emits loc, the bucket->token slot map, dispatch_count, max count and
 //                         the gshard loss.
-// Index outputs are integers and bit-exact against the oracle; gates follow the reference's
+// Index outputs are integers and bit-exact against the reference CPU path; gates follow its
 // per-op rounding in the scores dtype.
 #include "common.h"
 
 #define RT_THREADS 256
 #define RT_WAVES 4
+#define GT_THREADS 1024  // gate_topk: 16 waves per tile, 4 interleaved tokens per wave
+#define GT_WAVES 16
 #define RT_MAX_TILES 128
 #define RT_MAX_K 16
 #define RT_MAX_E 1024
@@ -43,102 +45,143 @@ extern "C" size_t tutel_amd_routing_workspace_bytes(int T, int E, int k) {
 // -------------------------------------------------------------------------------------------
 // K1: softmax (optional) + top-k + tile histogram + tile column sums
 // -------------------------------------------------------------------------------------------
-template <typename T, int EPL>
-__global__ __launch_bounds__(RT_THREADS) void gate_topk_kernel(
+template <typename T, int EPL, int GT_BATCH>
+__global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
     const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);             // [k][E]
-  float *s_col = reinterpret_cast<float *>(smem) + (size_t)k * E;  // [RT_WAVES][E]
+  float *s_col = reinterpret_cast<float *>(smem) + (size_t)k * E;  // [GT_WAVES][E]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.x;
   const int t0 = b * tile, t1 = min(Tn, t0 + tile);
 
-  for (int i = tid; i < k * E; i += RT_THREADS) s_hist[i] = 0;
+  for (int i = tid; i < k * E; i += GT_THREADS) s_hist[i] = 0;
   __syncthreads();
 
   float colacc[EPL];
 #pragma unroll
   for (int j = 0; j < EPL; ++j) colacc[j] = 0.f;
 
-  for (int t = t0 + wid; t < t1; t += RT_WAVES) {
-    float v[EPL];
-    const T *row = in + (size_t)t * E;
+  // wave `wid` owns tokens t0 + wid + GT_WAVES*i.  GT_BATCH tokens are processed INTERLEAVED:
+  // every cross-lane step below is issued for all of them before the next step, so the
+  // ~36 dependent ds_bpermute round trips per token overlap instead of adding up.
+  for (int tb = t0 + wid; tb < t1; tb += GT_WAVES * GT_BATCH) {
+    float v[GT_BATCH][EPL];
+    bool live[GT_BATCH];
+    int tt[GT_BATCH];
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      int e = lane + 64 * j;
-      float x = (e < E) ? Elem<T>::to_f32(row[e]) : -INFINITY;
-      v[j] = x;
+    for (int u = 0; u < GT_BATCH; ++u) {
+      tt[u] = tb + u * GT_WAVES;
+      live[u] = tt[u] < t1;  // wave-uniform
+      const T *row = in + (size_t)min(tt[u], Tn - 1) * E;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        int e = lane + 64 * j;
+        v[u][j] = (e < E) ? Elem<T>::to_f32(row[e]) : -INFINITY;
+      }
     }
     if (apply_softmax) {
-      float m = -INFINITY;
+      float m[GT_BATCH], s[GT_BATCH];
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) m = fmaxf(m, v[j]);
-      m = wave_max(m);
-      float s = 0.f;
+      for (int u = 0; u < GT_BATCH; ++u) {
+        m[u] = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        int e = lane + 64 * j;
-        v[j] = (e < E) ? expf(v[j] - m) : 0.f;
-        s += v[j];
+        for (int j = 0; j < EPL; ++j) m[u] = fmaxf(m[u], v[u][j]);
       }
-      s = wave_sum(s);
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        int e = lane + 64 * j;
-        if (e < E) {
-          T r = Elem<T>::from_f32(v[j] / s);
-          v[j] = Elem<T>::to_f32(r);
-          if (scores_out) scores_out[(size_t)t * E + e] = r;
-        } else {
-          v[j] = -INFINITY;
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < GT_BATCH; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], o, 64));
+#pragma unroll
+      for (int u = 0; u < GT_BATCH; ++u) {
+        s[u] = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+          int e = lane + 64 * j;
+          v[u][j] = (e < E) ? expf(v[u][j] - m[u]) : 0.f;
+          s[u] += v[u][j];
         }
       }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < GT_BATCH; ++u) s[u] += __shfl_xor(s[u], o, 64);
+#pragma unroll
+      for (int u = 0; u < GT_BATCH; ++u)
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+          int e = lane + 64 * j;
+          if (e < E) {
+            T r = Elem<T>::from_f32(v[u][j] / s[u]);
+            v[u][j] = Elem<T>::to_f32(r);
+            if (scores_out && live[u]) scores_out[(size_t)tt[u] * E + e] = r;
+          } else {
+            v[u][j] = -INFINITY;
+          }
+        }
     }
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      int e = lane + 64 * j;
-      if (e < E) colacc[j] += v[j];
-      if (v[j] != v[j]) v[j] = -INFINITY;  // NaN sorts last
-    }
-
-    // k rounds of wave arg-max, order: score desc, expert index asc.
-    uint32_t taken = 0;
-    float myg = 0.f;
-    int myidx = -1;
-    for (int c = 0; c < k; ++c) {
-      float bv = -INFINITY;
-      int be = 0x7fffffff;
+    for (int u = 0; u < GT_BATCH; ++u)
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
         int e = lane + 64 * j;
-        bool ok = (e < E) && !((taken >> j) & 1u);
-        if (ok && (v[j] > bv || (v[j] == bv && e < be))) { bv = v[j]; be = e; }
+        if (e < E && live[u]) colacc[j] += v[u][j];  // token order u = 0..3: deterministic
+        if (v[u][j] != v[u][j]) v[u][j] = -INFINITY;  // NaN sorts last
+      }
+
+    // k rounds of wave arg-max, order: score desc, expert index asc.
+    uint32_t taken[GT_BATCH];
+    float myg[GT_BATCH];
+    int myidx[GT_BATCH];
+#pragma unroll
+    for (int u = 0; u < GT_BATCH; ++u) { taken[u] = 0; myg[u] = 0.f; myidx[u] = -1; }
+    for (int c = 0; c < k; ++c) {
+      float bv[GT_BATCH];
+      int be[GT_BATCH];
+#pragma unroll
+      for (int u = 0; u < GT_BATCH; ++u) {
+        bv[u] = -INFINITY;
+        be[u] = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+          int e = lane + 64 * j;
+          bool ok = (e < E) && !((taken[u] >> j) & 1u);
+          if (ok && (v[u][j] > bv[u] || (v[u][j] == bv[u] && e < be[u]))) { bv[u] = v[u][j]; be[u] = e; }
+        }
       }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(bv, o, 64);
-        int oe = __shfl_xor(be, o, 64);
-        if (ov > bv || (ov == bv && oe < be)) { bv = ov; be = oe; }
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < GT_BATCH; ++u) {
+          float ov = __shfl_xor(bv[u], o, 64);
+          int oe = __shfl_xor(be[u], o, 64);
+          if (ov > bv[u] || (ov == bv[u] && oe < be[u])) { bv[u] = ov; be[u] = oe; }
+        }
+#pragma unroll
+      for (int u = 0; u < GT_BATCH; ++u) {
+        if ((be[u] & 63) == lane) taken[u] |= 1u << (be[u] >> 6);
+        if (lane == c) { myg[u] = bv[u]; myidx[u] = be[u]; }
       }
-      if ((be & 63) == lane) taken |= 1u << (be >> 6);
-      if (lane == c) { myg = bv; myidx = be; }
     }
     // gates: raw score, optionally normalised by clamp(((0+g0)+g1)+..., eps) in dtype T.
-    float denom = __shfl(myg, 0, 64);
-    for (int c = 1; c < k; ++c) denom = round_to<T>(denom + __shfl(myg, c, 64));
-    if (lane < k) {
-      float g = myg;
-      if (normalize && k > 1) {
-        float d = fmaxf(denom, Elem<T>::eps());
-        if (denom != denom) d = denom;  // torch.clamp keeps NaN
-        g = g / d;
+#pragma unroll
+    for (int u = 0; u < GT_BATCH; ++u) {
+      float denom = __shfl(myg[u], 0, 64);
+      for (int c = 1; c < k; ++c) denom = round_to<T>(denom + __shfl(myg[u], c, 64));
+      if (lane < k && live[u]) {
+        float g = myg[u];
+        if (normalize && k > 1) {
+          float d = fmaxf(denom, Elem<T>::eps());
+          if (denom != denom) d = denom;  // torch.clamp keeps NaN
+          g = g / d;
+        }
+        gates[(size_t)lane * Tn + tt[u]] = Elem<T>::from_f32(g);
+        idx[(size_t)lane * Tn + tt[u]] = myidx[u];
+        atomicAdd(&s_hist[lane * E + myidx[u]], 1);
       }
-      gates[(size_t)lane * Tn + t] = Elem<T>::from_f32(g);
-      idx[(size_t)lane * Tn + t] = myidx;
-      atomicAdd(&s_hist[lane * E + myidx], 1);
     }
   }
 
@@ -148,11 +191,11 @@ __global__ __launch_bounds__(RT_THREADS) void gate_topk_kernel(
     if (e < E) s_col[wid * E + e] = colacc[j];
   }
   __syncthreads();
-  for (int i = tid; i < k * E; i += RT_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
-  for (int e = tid; e < E; e += RT_THREADS) {
+  for (int i = tid; i < k * E; i += GT_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
+  for (int e = tid; e < E; e += GT_THREADS) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < RT_WAVES; ++w) s += s_col[w * E + e];
+    for (int w = 0; w < GT_WAVES; ++w) s += s_col[w * E + e];
     ws_colsum[(size_t)b * E + e] = s;
   }
 }
@@ -197,16 +240,28 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
   const int t0 = b * tile, t1 = min(Tn, t0 + tile);
   const int kE = k * E;
 
-  // 1. base[j][e] = sum over earlier tiles, tot[j][e] = sum over all tiles
-  for (int i = tid; i < kE; i += RT_THREADS) {
+  // 1. base[j][e] = sum over earlier tiles, tot[j][e] = sum over all tiles.  The tile axis is
+  //    split over the waves and unrolled so the (<=128) dependent-free L2 loads overlap.
+  for (int i = tid; i < kE; i += RT_THREADS) { s_cur[i] = 0; s_tot[i] = 0; }
+  __syncthreads();
+  for (int i = lane; i < kE; i += 64) {
     int base = 0, tot = 0;
-    for (int tl = 0; tl < ntiles; ++tl) {
-      int h = ws_hist[(size_t)tl * kE + i];
-      if (tl < b) base += h;
-      tot += h;
+    for (int tl0 = wid; tl0 < ntiles; tl0 += RT_WAVES * 8) {
+      int h[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int tl = tl0 + u * RT_WAVES;
+        h[u] = (tl < ntiles) ? ws_hist[(size_t)tl * kE + i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int tl = tl0 + u * RT_WAVES;
+        tot += h[u];
+        if (tl < b) base += h[u];
+      }
     }
-    s_cur[i] = base;
-    s_tot[i] = tot;
+    atomicAdd(&s_cur[i], base);
+    atomicAdd(&s_tot[i], tot);
   }
   __syncthreads();
   // 2. choice j is queued after ALL tokens' choices < j (fast_dispatch.py:165-169)
@@ -251,20 +306,43 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
     }
   }
 
-  // 4. block 0: max count and gshard loss
+  // 4. block 0: max count and gshard loss.  Column sums: `parts` threads per expert, each a
+  //    contiguous tile range in fixed order, combined in fixed order (deterministic).
   if (b == 0) {
     int mx = 0;
-    float part = 0.f;
     for (int e = tid; e < E; e += RT_THREADS) {
       int acc = 0;
       for (int j = 0; j < k; ++j) acc += s_tot[j * E + e];
       mx = max(mx, acc);
-      if (l_aux != nullptr) {
+    }
+    float part = 0.f;
+    if (l_aux != nullptr) {
+      float *s_me = reinterpret_cast<float *>(s_cur);  // s_cur is dead after step 3 (k*E >= E floats)
+      __syncthreads();
+      const int parts = (E >= RT_THREADS) ? 1 : (RT_THREADS / E);
+      const int per = (ntiles + parts - 1) / parts;
+      float *s_parts = reinterpret_cast<float *>(smem) + (size_t)2 * kE;  // [parts][E], see launch
+      for (int w = tid; w < parts * E; w += RT_THREADS) {
+        const int e = w % E, pt = w / E;
+        const int a = pt * per, z = min(ntiles, a + per);
         float me = 0.f;
-        for (int tl = 0; tl < ntiles; ++tl) me += ws_colsum[(size_t)tl * E + e];
+        for (int tl0 = a; tl0 < z; tl0 += 16) {
+          float cs[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) cs[u] = (tl0 + u < z) ? ws_colsum[(size_t)(tl0 + u) * E + e] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) me += cs[u];
+        }
+        s_parts[pt * E + e] = me;
+      }
+      __syncthreads();
+      for (int e = tid; e < E; e += RT_THREADS) {
+        float me = 0.f;
+        for (int pt = 0; pt < parts; ++pt) me += s_parts[pt * E + e];
         float ce = (float)s_tot[e] * ((float)E / (float)Tn);
         part += me * ce;
       }
+      (void)s_me;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -333,12 +411,17 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
   const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
-  size_t lds = ((size_t)k * E + (size_t)RT_WAVES * E) * 4;
+  size_t lds = ((size_t)k * E + (size_t)GT_WAVES * E) * 4;
   const int epl = (E + 63) / 64;
 #define GT_LAUNCH(EPL)                                                                          \
-  hipLaunchKernelGGL((gate_topk_kernel<T, EPL>), dim3(nt), dim3(RT_THREADS), lds, st,           \
-                     (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,  \
-                     idx, (T *)gates, ws_hist, ws_col)
+  do {                                                                                          \
+    if (lds > 65536)                                                                            \
+      (void)hipFuncSetAttribute((const void *)gate_topk_kernel<T, EPL, (EPL <= 4 ? 4 : (EPL <= 8 ? 2 : 1))>,                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+    hipLaunchKernelGGL((gate_topk_kernel<T, EPL, (EPL <= 4 ? 4 : (EPL <= 8 ? 2 : 1))>), dim3(nt), dim3(GT_THREADS), lds, st,         \
+                       (const T *)in, apply_softmax, Tn, E, k, normalize, tile,                 \
+                       (T *)scores_out, idx, (T *)gates, ws_hist, ws_col);                      \
+  } while (0)
   if (epl <= 1) GT_LAUNCH(1);
   else if (epl <= 2) GT_LAUNCH(2);
   else if (epl <= 4) GT_LAUNCH(4);
@@ -398,7 +481,7 @@ extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int 
     slot_map = nullptr;
     capacity = 0;
   }
-  hipLaunchKernelGGL(location_kernel, dim3(nt), dim3(RT_THREADS), (size_t)2 * k * E * 4, st, idx, T, E, k,
+  hipLaunchKernelGGL(location_kernel, dim3(nt), dim3(RT_THREADS), ((size_t)2 * k * E + (size_t)(E > RT_THREADS ? E : RT_THREADS)) * 4, st, idx, T, E, k,
                      tile, nt, ws_hist, ws_col, loc, dispatch_count, stats, l_aux, capacity, slot_map);
   TUTEL_CHECK_LAUNCH("tutel_amd_compute_location");
   return 0;

@@ -1,0 +1,182 @@
+"""Fused per-expert FFN (reference: tutel/experts/ffn.py, FusedExpertsNetwork).
+
+Parameters keep the reference's names and shapes (checkpoint compatible):
+    batched_fc1_w    [E_loc, H/s, M]        batched_fc1_bias [E_loc, H/s]
+    batched_fc2_w    [E_loc, H/s, M_out]    batched_fc2_bias [E_loc, ceil(M_out/s)]
+
+Forward, y = act(x @ W1^T + b1) @ W2 + b2 per local expert, x [E_loc, R, M]:
+  * bf16 / fp16, no autograd, recognised activation -> two launches of the MFMA grouped GEMM
+    (tutel_amd_expert_gemm): bias + activation fused into the first, bias into the second,
+    W2 consumed in its stored [H, M_out] layout, dropless row counts honoured on device;
+  * anything else (fp32/fp64 experts, training, arbitrary python activation, sharded experts)
+    -> ATen batched matmul (rocBLAS / hipBLASLt library GEMMs), op for op as the reference.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .. import net, ops
+
+_PROBE = torch.tensor([-3.0, -1.0, -0.25, 0.0, 0.25, 0.5, 1.0, 2.0, 4.0])
+
+
+def classify_activation(fn):
+    """Name of the fused epilogue equivalent to `fn`, or None.  Decided by evaluating `fn` on a
+    probe vector (twice, to reject stochastic functions such as dropout in training mode)."""
+    if isinstance(fn, str):
+        return fn if fn in ops.ACT_CODES else None
+    tag = getattr(fn, "_tutel_amd_act", None)
+    if tag in ops.ACT_CODES:
+        return tag
+    try:
+        with torch.no_grad():
+            a, b = fn(_PROBE.clone()), fn(_PROBE.clone())
+        if not (torch.is_tensor(a) and a.shape == _PROBE.shape and torch.equal(a, b)):
+            return None
+        for name, ref in (("relu", F.relu), ("gelu", F.gelu), ("silu", F.silu), ("none", lambda t: t)):
+            if torch.allclose(a, ref(_PROBE), rtol=0, atol=1e-7):
+                return name
+    except Exception:
+        pass
+    return None
+
+
+class FusedExpertsNetwork(torch.nn.Module):
+    def __init__(self, model_dim, hidden_size_per_expert, num_experts_per_device, sharded_count,
+                 activation_fn=None, activation_fn_with_self=None, output_dim=None,
+                 has_fc1_bias=True, has_fc2_bias=True):
+        super().__init__()
+        self.skip_expert = int(os.environ.get("SKIP_EXPERT", "0")) != 0
+        assert hidden_size_per_expert % sharded_count == 0, \
+            f"Can't evenly divide hidden_size_per_expert ({hidden_size_per_expert}) to {sharded_count} slices."
+        self.model_dim = model_dim
+        self.hidden_size_per_expert = hidden_size_per_expert
+        self.local_experts = num_experts_per_device
+        self.sharded_count = sharded_count
+        self.hidden_size = hidden_size_per_expert // sharded_count
+        self.output_dim = output_dim or model_dim
+
+        if activation_fn_with_self is not None:
+            assert activation_fn is None, "Option `activation_fn_with_self` has been specified, please keep exactly one of them."
+            activation_fn = lambda x: activation_fn_with_self(x, self)  # noqa: E731
+        if activation_fn is None:
+            activation_fn = F.relu
+        self.activation_fn = activation_fn
+        self._act_cache = {}
+
+        E, H = num_experts_per_device, self.hidden_size
+        self.batched_fc1_w = torch.nn.Parameter(torch.empty(E, H, model_dim))
+        self.batched_fc2_w = torch.nn.Parameter(torch.empty(E, H, self.output_dim))
+        if has_fc1_bias:
+            self.batched_fc1_bias = torch.nn.Parameter(torch.empty(E, H))
+        else:
+            self.register_parameter("batched_fc1_bias", None)
+        if has_fc2_bias:
+            self.batched_fc2_bias = torch.nn.Parameter(torch.empty(E, (self.output_dim + sharded_count - 1) // sharded_count))
+        else:
+            self.register_parameter("batched_fc2_bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # per-expert nn.Linear initialisation, in the same RNG order as the reference
+        # (ffn.py:39-49) so that seeded runs produce the same weights.
+        with torch.no_grad():
+            for i in range(self.batched_fc1_w.size(0)):
+                fc1 = torch.nn.Linear(self.model_dim, self.hidden_size, bias=self.batched_fc1_bias is not None)
+                fc2 = torch.nn.Linear(self.hidden_size, self.output_dim, bias=self.batched_fc2_bias is not None)
+                self.batched_fc1_w[i] = fc1.weight
+                self.batched_fc2_w[i] = fc2.weight.t()
+                if self.batched_fc1_bias is not None:
+                    self.batched_fc1_bias[i] = fc1.bias
+                if self.batched_fc2_bias is not None:
+                    self.batched_fc2_bias[i] = fc2.bias[:self.batched_fc2_bias.size(-1)]
+
+    def extra_repr(self):
+        return "model_dim=%d, hidden_size=%d, output_dim=%d, num_experts_per_device=%d. has_fc1_bias=%s, has_fc2_bias=%s." % (
+            self.batched_fc1_w.size(2), self.batched_fc1_w.size(1), self.batched_fc2_w.size(2), self.batched_fc1_w.size(0),
+            self.batched_fc1_bias is not None, self.batched_fc2_bias is not None)
+
+    # -- fused path -------------------------------------------------------------------------
+    def fused_activation(self):
+        key = self.training
+        if key not in self._act_cache:
+            self._act_cache[key] = classify_activation(self.activation_fn)
+        return self._act_cache[key]
+
+    def can_fuse(self, x, ctx):
+        if self.skip_expert or not x.is_cuda or torch.is_grad_enabled() and (
+                x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        if getattr(ctx, "adaptive_degree", 1) == 0 or getattr(ctx, "sharded_count", 1) > 1:
+            return False
+        w1, w2 = self.batched_fc1_w, self.batched_fc2_w
+        if x.dtype != w1.dtype or torch.is_autocast_enabled():
+            return False
+        return (ops.gemm_supported(w1.dtype, w1.size(1), w1.size(2)) and
+                ops.gemm_supported(w2.dtype, w2.size(2), w2.size(1)) and self.fused_activation() is not None)
+
+    def forward_fused(self, x, ctx, a_layout=None, R=None, out=None, d_layout=None):
+        """x [E_loc,R,M] (or the raw all-to-all buffer described by a_layout) -> [E_loc,R,M_out]
+        (or written into `out` in d_layout).  Two MFMA grouped-GEMM launches."""
+        counts, align = None, 1
+        if getattr(ctx, "megablocks_size", 0) > 0:
+            counts, align = ctx.dispatch_count, int(ctx.megablocks_size)
+        h = ops.expert_gemm(x, self.batched_fc1_w, self.batched_fc1_bias, True, act=self.fused_activation(),
+                            E_loc=self.batched_fc1_w.size(0), R=R, a_layout=a_layout,
+                            row_counts=counts, row_align=align)
+        b2 = self.batched_fc2_bias
+        if b2 is not None and b2.size(-1) != self.output_dim:
+            b2 = b2[:, :self.output_dim].contiguous()
+        return ops.expert_gemm(h, self.batched_fc2_w, b2, False, out=out, d_layout=d_layout,
+                               row_counts=counts, row_align=align)
+
+    # -- reference-equivalent ATen path -----------------------------------------------------
+    def forward(self, x, ctx):
+        if self.skip_expert:
+            return x
+        if self.can_fuse(x, ctx):
+            return self.forward_fused(x.contiguous(), ctx)
+
+        w1, w2 = self.batched_fc1_w, self.batched_fc2_w
+        b1 = self.batched_fc1_bias.unsqueeze(1) if self.batched_fc1_bias is not None else None
+        b2 = self.batched_fc2_bias.unsqueeze(1) if self.batched_fc2_bias is not None else None
+
+        if ctx.adaptive_degree == 0:  # data-parallel experts: gather every rank's weights (ffn.py:83-89)
+            E = ctx.num_global_experts
+            w1 = net.zero_gather(w1, group=ctx.group).view(E, -1, w1.size(2))
+            w2 = net.zero_gather(w2, group=ctx.group).view(E, -1, w2.size(2))
+            if b1 is not None:
+                b1 = net.zero_gather(b1, group=ctx.group).view(E, 1, -1)
+            if b2 is not None:
+                b2 = net.zero_gather(b2, group=ctx.group).view(E, 1, -1)
+        elif ctx.sharded_count > 1:  # one expert's hidden dim sliced over ranks (ffn.py:91-109)
+            mesh = net.get_world_size(ctx.group)
+            if 1 < mesh < net.get_world_size():
+                ctx.adaptive_degree = ctx.sharded_count
+            group_size = ctx.sharded_count // ctx.adaptive_degree
+            if group_size > 1:
+                zg = net.create_groups_from_world(group_count=-group_size, parent_group=ctx.group).model_group
+                w1 = net.zero_gather(w1, group=zg).view(1, -1, ctx.model_dim)
+                w2 = net.zero_gather(w2, group=zg).view(1, -1, self.output_dim)
+                if b1 is not None:
+                    b1 = net.zero_gather(b1, group=zg).view(1, 1, -1)
+            if b2 is not None:
+                bg = net.create_groups_from_world(group_count=ctx.num_global_experts, parent_group=ctx.group).model_group
+                b2 = net.zero_gather(b2, group=bg).view(1, 1, -1)
+                if ctx.adaptive_degree > 1:
+                    b2 = b2 * (1.0 / ctx.adaptive_degree)
+        if b2 is not None and b2.size(-1) != self.output_dim:
+            b2 = b2[:, :, :self.output_dim]
+
+        y = torch.matmul(x, w1.permute(0, 2, 1))
+        if b1 is not None:
+            y = y + b1
+        y = self.activation_fn(y)
+        y = torch.matmul(y, w2)
+        if b2 is not None:
+            y = y + b2
+        return y
+
+
+ExpertModule = FusedExpertsNetwork

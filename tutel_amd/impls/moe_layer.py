@@ -1,0 +1,320 @@
+"""MOELayer -- the drop-in for tutel.moe.moe_layer (reference: tutel/impls/moe_layer.py).
+
+Forward on MI355X (one process per GPU):
+
+    x[..., M] -> gate logits (library GEMM)                                   gates/top.py
+      -> fused softmax + top-k + stable-rank locations + l_aux (2 HIP kernels)  fast_dispatch.extract_critical
+      -> fast_encode: bucket-major scatter into [E, C, M] (1 HIP kernel)
+      -> all_to_all_single over RCCL/xGMI (W > 1)            raw layout [W, E_loc, C, M]
+      -> expert FFN: 2 MFMA grouped-GEMM launches that READ and WRITE the raw all-to-all
+         layout directly (the reference's two permute+contiguous copies are folded into the
+         GEMM's row addressing), bias/activation fused, dropless row counts on device
+      -> all_to_all_single back -> fast_decode: k-way gather, fp32 combine (1 HIP kernel)
+
+The constructor / forward signatures, attributes, env switches (SKIP_MOE, BATCH_PRIO, CAP_FACTOR)
+and error behaviour follow the reference so existing user code runs unchanged.
+"""
+import importlib
+import logging
+import os
+import re
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch.nn import ModuleList
+
+from . import communicate as C
+from . import losses
+from .fast_dispatch import extract_critical, fast_decode, fast_encode, get_dispatch_count
+from .overlap import a2a_ffn_overlap_forward
+from ..experts.ffn import FusedExpertsNetwork
+
+
+def _autocast_dtype(t):
+    return torch.get_autocast_dtype(t.device.type)
+
+
+class MOELayer(torch.nn.Module):
+    """Tutel-compatible Mixture-of-Experts layer."""
+
+    @staticmethod
+    def global_expert_count(num_local_experts, group=None):
+        if not isinstance(num_local_experts, int):  # a fraction 1/n: n devices share one expert
+            num_local_experts = -int(1 / (num_local_experts + 1e-5))
+        world = C.get_world_size(group)
+        if num_local_experts == 0:
+            raise Exception("Invalid value of num_local_experts: %d" % num_local_experts)
+        if num_local_experts > 0:
+            return num_local_experts * world
+        assert world % -num_local_experts == 0, \
+            f"Excepting {-num_local_experts} devices to share an expert param, while global device count is {world}."
+        return world // -num_local_experts
+
+    @property
+    def num_global_experts(self):
+        return int(self._num_global_experts)
+
+    def __init__(self, gate_type, model_dim: int, experts=None, scan_expert_func=None, result_func=None,
+                 group=None, seeds=None, a2a_ffn_overlap_degree=1, is_postscore=True,
+                 batch_prioritized_routing=False, normalize_gate=True, is_gshard_loss=True,
+                 parallel_type="adaptive:1", use_2dh=False, **kwargs):
+        super().__init__()
+        assert model_dim % 2 == 0, "Model_dim (%s) must be even value, while this Model_dim mod 2 > 0." % model_dim
+        if "pad_samples" in kwargs:
+            logging.warning("`pad_samples` option in Tutel Moe-layer has been deprecated, as Tutel always assumes `pad_samples=False` for better efficiency.")
+            kwargs.pop("pad_samples")
+        for key in kwargs:
+            raise Exception("Unrecognized argument provided to Tutel Moe-layer: %s" % key)
+
+        self.group = group or (dist.group.WORLD if dist.is_available() and dist.is_initialized() else None)
+        self.result_func = result_func
+        self.skip_moe = int(os.environ.get("SKIP_MOE", "0")) != 0
+        self.model_dim = model_dim
+        self.is_postscore = is_postscore
+        self.batch_prioritized_routing = batch_prioritized_routing or int(os.environ.get("BATCH_PRIO", 0)) != 0
+        self.normalize_gate = normalize_gate
+        self.is_gshard_loss = is_gshard_loss
+        self.a2a_ffn_overlap_degree = a2a_ffn_overlap_degree
+        self.use_2dh = use_2dh
+        self.megablocks_size = 0
+        self.protected_shape = None
+
+        experts = dict(experts)
+        n_local = experts.pop("count_per_node", 1) if "count_per_node" in experts else experts.pop("num_experts_per_device", 1)
+        self.num_local_experts = 1 if n_local == -1 else n_local
+        self.register_buffer("_num_global_experts", torch.tensor(MOELayer.global_expert_count(self.num_local_experts, self.group)))
+        self.world_size = C.get_world_size(self.group)
+        if self.num_global_experts < self.world_size:
+            self.sharded_count = self.world_size // self.num_global_experts
+            self.num_local_experts = 1
+        else:
+            self.sharded_count = 1
+
+        self.auto_parallel, self.adaptive_degree, self.use_model_parallel = False, self.sharded_count, True
+        self.valid_rs = [0] + [i for i in range(1, self.sharded_count + 1) if self.sharded_count % i == 0]
+        if parallel_type.startswith("adaptive:"):
+            r = int(parallel_type[parallel_type.index(":") + 1:])
+            self.adaptive_degree = min(max(r, 0), self.sharded_count)
+            if self.adaptive_degree not in self.valid_rs:
+                raise Exception("Unexpected value of adaptive_degree: %d, expecting a candidate within %s." % (self.adaptive_degree, self.valid_rs))
+        elif self.sharded_count == 1:
+            pass
+        elif parallel_type in ("data", "model"):
+            self.adaptive_degree = 1 if parallel_type == "data" else self.sharded_count
+        elif parallel_type == "auto":
+            self.adaptive_degree = 1
+        else:
+            raise Exception("Unrecognized parallel type specified: %s" % parallel_type)
+
+        if seeds is not None and seeds[1] is not None:
+            torch.manual_seed(seeds[1])
+        self.experts = self._build_experts(experts)
+        if scan_expert_func is not None:
+            for n, p in self.experts.named_parameters():
+                scan_expert_func(n, p)
+        for _, p in self.experts.named_parameters():
+            setattr(p, "_tutel_expert", True)
+
+        if isinstance(gate_type, str):
+            assert re.match(r"^Top[0-9]+Gate$", gate_type), "Unrecognized gate_type: %s" % gate_type
+            k = int(gate_type[3:-4])
+            logging.warning(f"gate_type value `{gate_type}` in Tutel Moe-layer has been deprecated, please use gate_type = {{'type': 'top', 'k': {k}}} instead.")
+            gate_type = {"type": "top", "k": k}
+        gate_specs = gate_type if isinstance(gate_type, list) else [gate_type]
+        self.gates = ModuleList([self._build_gate(dict(spec), gi, seeds) for gi, spec in enumerate(gate_specs)])
+
+        if seeds is not None and len(seeds) > 2 and seeds[2] is not None:
+            torch.manual_seed(seeds[2])
+
+    # ---- construction helpers -----------------------------------------------------------
+    def _build_experts(self, spec):
+        kind = spec.pop("type")
+        if kind == "custom":
+            module = spec.pop("module")
+        else:
+            assert re.match(r"[a-zA-Z0-9\_]+", kind), "Expert type must only include digits, letters and underline characters."
+            try:
+                module = importlib.import_module(f"...experts.{kind}", __name__).ExpertModule
+            except ModuleNotFoundError:
+                raise Exception("Builtin expert type is not recognized: %s" % kind)
+            if kind == "ffn":
+                assert "fused_custom_fn" not in spec, "`fused_custom_fn` option for Tutel Moe-layer has been deprecated, please follows helloworld_from_scratch.py for custom construction instead."
+                assert "implicit_dropout_p" not in spec, "`implicit_dropout_p` option for Tutel Moe-layer has been deprecated, please use torch.nn.Dropout(p=implicit_dropout_p) on custom activation_fn (for fc1_dropout) and after Tutel Moe-layer (for fc2_dropout) instead."
+        spec.update(model_dim=self.model_dim, num_experts_per_device=self.num_local_experts, sharded_count=self.sharded_count)
+        try:
+            return module(**spec)
+        except TypeError:
+            logging.warning("\nExpertModule.__init__(.., local_experts, ..) has been deprecated, please rename `local_experts` to `num_experts_per_device` in init methods.\n")
+            spec["local_experts"] = spec.pop("num_experts_per_device")
+            return module(**spec)
+
+    def _build_gate(self, spec, gi, seeds):
+        kind = spec.pop("type")
+        assert re.match(r"[a-zA-Z0-9\_]+", kind), "Gate type must only include digits, letters and underline characters."
+        if seeds is not None and seeds[0] is not None:
+            torch.manual_seed(seeds[0] + gi)
+        if kind == "custom":
+            factory = spec.pop("module")
+        else:
+            try:
+                factory = importlib.import_module(f"...gates.{kind}", __name__).Gate
+            except ModuleNotFoundError:
+                raise Exception("Unrecognized gate_type: %s" % kind)
+        gate = factory(model_dim=self.model_dim, num_global_experts=self.num_global_experts, **spec)
+        if not hasattr(gate, "gate_noise"):
+            gate.gate_noise = spec.get("gate_noise", 0.0)
+        if not hasattr(gate, "capacity_factor"):
+            gate.capacity_factor = spec.get("capacity_factor", float(os.environ.get("CAP_FACTOR", 1.0)))
+        return gate
+
+    # ---- checkpoint compatibility (reference moe_layer.py:57-78) ---------------------------
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        key = prefix + "_num_global_experts"
+        if key not in state_dict:
+            logging.warning("Loading a legacy Tutel checkpoint without `_num_global_experts`; it will be written in the new format next time.")
+            state_dict[key] = self._num_global_experts
+        else:
+            have, want = int(state_dict[key]), self.num_global_experts
+            assert have == want, "Failed to load state from checkpoint: the number of global experts mismatch (%s <- %s)" % (want, have)
+        for name, param in self.experts.named_parameters():
+            k = prefix + "experts." + name
+            if k not in state_dict:
+                logging.warning("Could not find parameter `%s` in state_dict, zero values will be filled into this parameter." % k)
+                state_dict[k] = torch.zeros_like(param)
+            if state_dict[k].numel() == param.numel():
+                state_dict[k] = state_dict[k].view(param.shape)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def extra_repr(self):
+        return "Top-K(s) = %s, Total-Experts = %d [managed by %d device(s)]," % (
+            [f"k={g.top_k}, noise={g.gate_noise}" for g in self.gates], self.num_global_experts, self.world_size)
+
+    def get_parameter_iterator(self, param_type):
+        if param_type == "gate":
+            return self.gates.named_parameters()
+        if param_type == "local_experts":
+            return self.experts.named_parameters()
+        raise Exception("Specified parameter type is not recognized: %s. Valid `param_type` includes: gate, local_experts." % param_type)
+
+    # ---- experts ------------------------------------------------------------------------
+    def expert_local(self, x, reserve_shape):
+        y = self.experts(x.view(x.size(0), x.size(1), *reserve_shape), self)
+        self.protected_shape = y.shape
+        return y.reshape(y.size(0), y.size(1), -1)
+
+    def _experts_on_raw_a2a(self, y, reserve_shape):
+        """W > 1 fast path: all-to-all the [E,C,M] buckets as they are and let the grouped GEMM
+        address the raw [W,E_loc,C,M] exchange buffers on both sides (no permute copies)."""
+        W, E_loc = self.world_size, self.num_local_experts
+        E, Cc, M = y.shape
+        recv = C.simple_all_to_all(y, group=self.group)  # [W(src), E_loc, C, M] flat
+        Mo = self.experts.output_dim
+        send = torch.empty([E, Cc, Mo], dtype=y.dtype, device=y.device)
+        self.experts.forward_fused(recv, self, a_layout=(Cc * M, E_loc * Cc * M, Cc, M), R=W * Cc,
+                                   out=send, d_layout=(Cc * Mo, E_loc * Cc * Mo, Cc, Mo))
+        self.protected_shape = torch.Size([E_loc, W * Cc, Mo])
+        return C.simple_all_to_all(send, group=self.group)
+
+    # ---- forward ------------------------------------------------------------------------
+    def forward(self, input, gate_index=0, capacity_factor=None, top_k=None, a2a_ffn_overlap_degree=None,
+                reserve_dims=1, inequivalent_tokens=False, adaptive_r=None, megablocks_size=0):
+        if self.skip_moe:
+            out = input
+            out.l_aux = None
+            return self.result_func(out) if self.result_func is not None else out
+
+        original_shape, original_dtype = input.shape, input.dtype
+        assert len(original_shape) >= 2, "Input data must be at least 2D tensor: (s)amples, .., (m)odel_dim"
+        reserve_shape = original_shape[-reserve_dims:]
+
+        x = input.reshape(-1, reserve_shape.numel())
+        if torch.is_autocast_enabled():
+            x = x.to(_autocast_dtype(x))  # so the all-to-all moves low-precision bytes
+        else:
+            for p in self.experts.parameters():
+                x = x.to(p.dtype)
+                break
+        gate = self.gates[gate_index]
+        if a2a_ffn_overlap_degree is not None:
+            self.a2a_ffn_overlap_degree = a2a_ffn_overlap_degree
+        degree = self.a2a_ffn_overlap_degree
+        top_k = top_k or gate.top_k
+        if megablocks_size > 0 and (self.num_local_experts <= 1 or torch.is_grad_enabled() or self.world_size > 1):
+            megablocks_size = 0
+
+        mega = max(megablocks_size, 1)
+        alignment = (self.sharded_count * degree + mega - 1) // mega * mega
+        if alignment > 256:
+            alignment = (alignment + 127) // 128 * 128
+
+        def routing():
+            logits = gate(x)
+            noisy = logits
+            if self.training and gate.gate_noise > 0:
+                noisy = logits + gate.gate_noise * torch.randn_like(logits) / self.num_global_experts
+            if self.is_gshard_loss:
+                loss_fn = losses.gshard_loss
+            else:
+                def loss_fn(scores, topk_ids):
+                    return losses.load_importance_loss(F.softmax(logits, dim=1), noisy.gather(index=topk_ids, dim=1),
+                                                       self.num_global_experts, gate.gate_noise)
+            return logits.dtype, extract_critical(
+                None, top_k=top_k, loss_fn=loss_fn, capacity_factor=capacity_factor or gate.capacity_factor,
+                batch_prioritized_routing=self.batch_prioritized_routing, normalize_gate=self.normalize_gate,
+                group=self.group, alignment=alignment, inequivalent_tokens=inequivalent_tokens, _logits=noisy)
+
+        if x.is_cuda:
+            with torch.autocast("cuda", enabled=False):
+                logits_dtype, (crit, l_aux) = routing()
+        else:
+            logits_dtype, (crit, l_aux) = routing()
+
+        self.megablocks_size = megablocks_size
+        self.dispatch_count = get_dispatch_count(crit)
+        # encode: with is_postscore the bucket rows are verbatim copies, so the reference's
+        # round trip through logits_dtype (moe_layer.py:327) is value-preserving and skipped.
+        if self.is_postscore or x.dtype == logits_dtype:
+            y = fast_encode(x.contiguous(), crit, self.is_postscore)
+        else:
+            y = fast_encode(x.to(logits_dtype), crit, self.is_postscore).to(x.dtype)
+
+        if adaptive_r is not None:
+            self.adaptive_degree = adaptive_r
+
+        if self.adaptive_degree == 0:
+            y = self.expert_local(y, reserve_shape)
+        else:
+            if self.auto_parallel:
+                self.use_model_parallel = (y.numel() * (self.sharded_count - 1) * 2 < sum(p.numel() for p in self.experts.parameters()))
+            if self.num_global_experts < self.world_size:
+                if self.use_model_parallel:
+                    y = y.repeat(1, self.adaptive_degree, 1).view(self.world_size, -1, y.size(2))
+                else:
+                    y = y.view(self.world_size, -1, y.size(2))
+
+            fused = (isinstance(self.experts, FusedExpertsNetwork) and self.world_size > 1 and len(reserve_shape) == 1
+                     and self.num_global_experts >= self.world_size and not C.SKIP_A2A and self.experts.can_fuse(y, self))
+            if degree > 1 and y.is_cuda:
+                y = a2a_ffn_overlap_forward(y, expert_fn=lambda t: self.expert_local(t, reserve_shape),
+                                            a2a_ffn_overlap_degree=degree, use_2dh=self.use_2dh, group=self.group)
+            elif fused:
+                y = self._experts_on_raw_a2a(y, reserve_shape)
+            else:
+                y = C.all_to_all(y, 1, 0, use_2dh=self.use_2dh, group=self.group)
+                y = self.expert_local(y, reserve_shape)
+                y = C.all_to_all(y, 0, 1, use_2dh=self.use_2dh, group=self.group)
+
+            if self.num_global_experts < self.world_size:
+                if self.use_model_parallel:
+                    y = torch.sum(y.view(self.num_global_experts, self.adaptive_degree, -1, y.size(2)), dim=1)
+                else:
+                    y = y.view(self.num_global_experts, -1, y.size(2))
+
+        y = fast_decode(y.contiguous() if y.dtype == logits_dtype else y.to(logits_dtype), crit, self.is_postscore)
+        y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
+        self.l_aux = y.l_aux = l_aux
+        return self.result_func(y) if self.result_func is not None else y
+
+
+moe_layer = MOELayer
