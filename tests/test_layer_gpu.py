@@ -7,7 +7,9 @@ Tolerances (BASELINE.json north_star: 1e-5 fp32 / 1e-3 fp16, bit-exact index ass
   fp16        : <= 1e-3 absolute
   bf16        : bf16 has 8 significand bits; the bar is 2 bf16 ulps of the result magnitude
                 (rtol 2^-7) + 2e-3 absolute against an fp32-accumulated oracle on the same
-                bf16-rounded inputs (SURVEY section 7 hard part 7)
+                bf16-rounded inputs (SURVEY section 7 hard part 7).  Against the reference's OWN
+                bf16 fixture (which rounds to bf16 after each of its 4 ATen ops: bmm, +bias, bmm,
+                +bias) the bar is 4 bf16 ulps of the output scale: 2^-6 * |y_ref|_inf.
 """
 import glob
 import os
@@ -50,9 +52,12 @@ def make_layer(M, H, E, k, cf, dtype, weights=None, **kw):
     return layer.cuda()
 
 
-def _close(y, ref, dtype):
+def _close(y, ref, dtype, vs_lowprec_reference=False):
     y, ref = y.double().cpu(), ref.double().cpu()
     err = (y - ref).abs()
+    if vs_lowprec_reference and dtype == torch.bfloat16:
+        assert float(err.max()) <= 2 ** -6 * float(ref.abs().max()), (float(err.max()), float(ref.abs().max()))
+        return
     if dtype in (torch.float32, torch.float64):
         assert float(err.max()) <= 1e-5 * max(1.0, float(ref.abs().max())), float(err.max())
     elif dtype == torch.float16:
@@ -86,7 +91,7 @@ def test_layer_vs_reference_fixture(oracle, path):
     # low-level test below checks idx/loc element-wise on the fixture's own scores)
     assert torch.equal(layer.dispatch_count.cpu(), torch.from_numpy(z["dispatch_count"]))
     assert y.dtype == dtype and y.shape == (T, M)
-    _close(y[::stride], _t(z["y"], dtype), dtype)
+    _close(y[::stride], _t(z["y"], dtype), dtype, vs_lowprec_reference=True)
     assert abs(float(y.l_aux) - float(z["l_aux"][0])) <= (1e-5 if dtype == torch.float32 or fp32_gate else 1e-2)
 
 
@@ -104,8 +109,7 @@ def test_low_level_api_vs_reference_fixture(oracle, path):
     assert torch.equal(torch.stack(crit[2]).cpu(), torch.from_numpy(z["loc"]))
     assert crit[4] == int(z["capacity"][0]) and crit[0] == E
     assert torch.equal(crit[5].cpu(), torch.from_numpy(z["dispatch_count"]))
-    if gdt != torch.float64:
-        assert torch.equal(torch.stack(crit[3]).cpu(), _t(z["gates"], gdt)), "gates bit-exact"
+    assert torch.equal(torch.stack(crit[3]).cpu(), _t(z["gates"], gdt)), "gates bit-exact"
     assert abs(float(l_aux) - float(z["l_aux"][0])) <= (1e-6 if gdt in (torch.float32, torch.float64) else 1e-2)
     if "encoded" in z.files:
         x = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed)[0]
@@ -196,10 +200,13 @@ def test_autocast_and_misc_paths(oracle):
     layer = make_layer(M, H, E, k, 1.0, torch.float32, weights).eval()
     with torch.no_grad():
         ref = layer(x.cuda())
+        # autocast casts the tokens to bf16 before routing (moe_layer.py:26-39,265-266): compare
+        # with the un-autocast layer on the same bf16-rounded tokens so the routing is identical
+        ref_rounded = layer(x.bfloat16().float().cuda())
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = layer(x.cuda())
         assert y.dtype == torch.float32
-        assert float((y - ref).abs().max()) < 0.05 * float(ref.abs().max())
+        assert float((y - ref_rounded).abs().max()) < 0.05 * float(ref_rounded.abs().max())
         y3 = layer(x.cuda().view(2, 4, T // 8, M), top_k=1, capacity_factor=2.0)  # per-call overrides, N-d input
         assert y3.shape == (2, 4, T // 8, M)
     res = make_layer(M, H, E, k, 1.0, torch.float32, weights, result_func=lambda t: t * 2).eval()

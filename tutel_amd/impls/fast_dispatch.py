@@ -194,8 +194,13 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
 
     # gates / loss: kernel values on the inference path; differentiable torch forms when training
     gate_list = None
-    if needs_grad:
+    if needs_grad or not ops.supported_dtype(src.dtype):
+        # training (autograd through the gates) or fp64 scores (the kernels select on the fp32
+        # image; the gate VALUES must be computed in the scores' own precision, as the reference
+        # does before its fp32 dispatch cast, fast_dispatch.py:151,173-175,105)
         sc = scores if scores is not None else torch.softmax(_logits, dim=1)
+        if not needs_grad:
+            sc = sc.detach()
         gate_list = [sc.gather(1, idx2d[j].long().unsqueeze(-1)).squeeze(-1) for j in range(k)]
         if k > 1 and normalize_gate:
             denom = torch.clamp(sum(gate_list), min=torch.finfo(gate_list[0].dtype).eps)
@@ -215,7 +220,7 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
         spe = (T + E - 1) // E
         logging.info("Capacity = %d, real-time capacity-factor for top-%d = %s", capacity, k_req, capacity / max(1, k * spe))
 
-    return RoutingPlan(E, idx2d, loc2d, gates2d, capacity, cnt, smap, gate_list), l_aux
+    return RoutingPlan(E, idx2d, loc2d, gates2d if gate_list is None else None, capacity, cnt, smap, gate_list), l_aux
 
 
 def get_dispatch_count(critial_data):
