@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""helloworld driver with the reference's flag surface (tutel/examples/helloworld.py:17-42):
+one MoE layer on synthetic tokens, training (fwd+bwd+SGD) or --eval forward, prints loss /
+step_time / tflops per step and the average of the last 10 steps.
+
+    python -m tutel_amd.examples.helloworld --eval --dtype=bfloat16 --num_local_experts=64 \
+           --batch_size=16 --num_tokens=256                         # BASELINE configs[1]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
+           -m tutel_amd.examples.helloworld --eval --num_local_experts=8 --a2a_ffn_overlap_degree=2
+"""
+import argparse
+
+import torch
+import torch.nn.functional as F
+
+from tutel import moe as tutel_moe
+from tutel import net, system
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--local_rank", type=int, default=-1)
+    ap.add_argument("--batch_size", type=int, default=16)
+    ap.add_argument("--num_tokens", type=int, default=512)
+    ap.add_argument("--model_dim", type=int, default=2048)
+    ap.add_argument("--hidden_size", type=int, default=2048)
+    ap.add_argument("--num_local_experts", type=int, default=2)
+    ap.add_argument("--dtype", type=str, default="float32")
+    ap.add_argument("--fp32_gate", default=False, action="store_true")
+    ap.add_argument("--top", type=int, default=2)
+    ap.add_argument("--l_aux_wt", type=float, default=0.0)
+    ap.add_argument("--a2a_ffn_overlap_degree", type=int, default=1)
+    ap.add_argument("--allreduce_degree", type=int, default=1)
+    ap.add_argument("--num_steps", type=int, default=100)
+    ap.add_argument("--parallel_type", type=str, default="adaptive:1")
+    ap.add_argument("--device", type=str, default="cuda")
+    ap.add_argument("--use_2dh", default=False, action="store_true")
+    ap.add_argument("--eval", default=False, action="store_true")
+    ap.add_argument("--capacity_factor", type=float, default=1.0)
+    ap.add_argument("--megablocks_size", type=int, default=0)
+    args = ap.parse_args()
+
+    env = system.init_data_model_parallel(backend="nccl" if args.device == "cuda" else "gloo")
+    rank, world, dprint, device = env.global_rank, env.global_size, env.dist_print, env.local_device
+    dtype = {"float32": torch.float32, "float64": torch.float64, "float16": torch.float16, "bfloat16": torch.bfloat16}[args.dtype]
+    torch.set_default_dtype(dtype)
+
+    layer = tutel_moe.moe_layer(
+        gate_type={"type": "top", "k": args.top, "fp32_gate": args.fp32_gate, "capacity_factor": args.capacity_factor},
+        experts={"type": "ffn", "num_experts_per_device": args.num_local_experts, "hidden_size_per_expert": args.hidden_size,
+                 "activation_fn": lambda x: F.relu(x)},
+        model_dim=args.model_dim, scan_expert_func=lambda n, p: setattr(p, "skip_allreduce", True),
+        seeds=(1, rank + 1, 1), a2a_ffn_overlap_degree=args.a2a_ffn_overlap_degree,
+        parallel_type=args.parallel_type, use_2dh=args.use_2dh).to(device)
+    dprint(layer)
+
+    def model(inp):
+        out = layer(inp, megablocks_size=args.megablocks_size) if args.megablocks_size > 0 else layer(inp)
+        return F.log_softmax(torch.sum(out, dim=2), dim=1)
+
+    opt = torch.optim.SGD(layer.parameters(), lr=1e-5)
+    torch.manual_seed(0)
+    x = torch.randn([args.batch_size, args.num_tokens, args.model_dim], dtype=torch.float32, device="cpu").to(dtype).to(device)
+    y = torch.zeros(args.batch_size, dtype=torch.long, device=device)
+    shared = [p for p in layer.parameters() if not hasattr(p, "skip_allreduce") and p.requires_grad]
+    dprint("[Benchmark] world_size = %s, dtype = %s, model_dim = %s, hidden_size = %s, samples = %s, num_local_experts = %s, topK = %s, a2a_ffn_overlap_degree = %s, device = `%s`"
+           % (world, args.dtype, args.model_dim, args.hidden_size, args.batch_size * args.num_tokens, args.num_local_experts, args.top, args.a2a_ffn_overlap_degree, device))
+
+    avg = 0.0
+    for i in range(args.num_steps):
+        t0 = system.record_time()
+        if not args.eval:
+            opt.zero_grad()
+            loss = F.nll_loss(model(x), y)
+            if args.l_aux_wt:
+                loss = loss + args.l_aux_wt * layer.l_aux
+            loss.backward()
+            if world > 1:
+                for p in shared:
+                    p.grad /= world
+                    p.grad = net.simple_all_reduce(p.grad)
+            opt.step()
+        else:
+            with torch.no_grad():
+                loss = F.nll_loss(model(x), y)
+        t1 = system.record_time()
+        E = tutel_moe.moe_layer.global_expert_count(args.num_local_experts, group=system.get_local_session().model_group)
+        tflops = (args.batch_size * args.num_tokens * args.model_dim * args.hidden_size) * 4 * (1 if args.eval else 3) * min(args.top, E) * 1e-12 / (t1 - t0)
+        dprint("STEP-%s: loss = %.5f, step_time = %.6f sec, perf = %.2f tflops." % (i, float(loss.data), t1 - t0, tflops))
+        if i + 10 >= args.num_steps:
+            avg += t1 - t0
+    dprint("\n[Summary] Average synchronized step_time = %s sec." % (avg / 10))
+
+
+if __name__ == "__main__":
+    main()

@@ -53,7 +53,10 @@ class MOELayer(torch.nn.Module):
 
     @property
     def num_global_experts(self):
-        return int(self._num_global_experts)
+        # The buffer `_num_global_experts` (checkpoint format, reference moe_layer.py:119) lives on
+        # the device after .cuda(); int() of it is a D2H copy + stream sync.  The forward path
+        # reads this value several times, so it is mirrored in a host int.
+        return self._num_global_experts_host
 
     def __init__(self, gate_type, model_dim: int, experts=None, scan_expert_func=None, result_func=None,
                  group=None, seeds=None, a2a_ffn_overlap_degree=1, is_postscore=True,
@@ -83,7 +86,8 @@ class MOELayer(torch.nn.Module):
         experts = dict(experts)
         n_local = experts.pop("count_per_node", 1) if "count_per_node" in experts else experts.pop("num_experts_per_device", 1)
         self.num_local_experts = 1 if n_local == -1 else n_local
-        self.register_buffer("_num_global_experts", torch.tensor(MOELayer.global_expert_count(self.num_local_experts, self.group)))
+        self._num_global_experts_host = int(MOELayer.global_expert_count(self.num_local_experts, self.group))
+        self.register_buffer("_num_global_experts", torch.tensor(self._num_global_experts_host))
         self.world_size = C.get_world_size(self.group)
         if self.num_global_experts < self.world_size:
             self.sharded_count = self.world_size // self.num_global_experts
