@@ -23,13 +23,13 @@
 //     MFMA wants is produced by gfx950's transposing LDS read, no transposed weight copy in HBM;
 //   * row addressing folds the expert-parallel [W,E_loc,C,M] <-> [E_loc,W*C,M] permutes
 //     (communicate.py:606-622) into the loads/stores.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define GM_BM 128
 #define GM_BN 128
-#define GM_BK 64
 #define GM_THREADS 256
-#define GM_LDK (GM_BK + 8)    // elements per LDS row of a [rows][k] tile   (144 B)
 #define GM_LDN (GM_BN + 32)   // elements per LDS row of the [k][n] weight tile (320 B)
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -70,14 +70,27 @@ struct GemmArgs {
   int ntm, ntn;
 };
 
-template <typename T, bool W_KMAJOR, int ACT>
-__global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_kernel(GemmArgs p) {
-  // LDS: activations [2][BM][LDK], weights [2][BN][LDK] (k-major) or [2][BK][LDN] (n-major)
+// streamed-once weight loads may bypass cache allocation (each W byte is read by exactly one CU)
+template <bool NT> __device__ __forceinline__ u32x4 ld16(const uint16_t *p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+  return *reinterpret_cast<const u32x4 *>(p);
+}
+
+// Tile configuration: BK = K-tile depth (64 | 128); NBUF = LDS buffers (2: one barrier per K-tile;
+// 1: two barriers, half the LDS -> more blocks per CU); OCC = blocks per CU the register
+// allocator is asked to allow; NT = non-temporal weight loads.
+template <typename T, bool W_KMAJOR, int ACT, int BK, int NBUF, int OCC, bool NT, bool ROT>
+__global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p) {
+  constexpr int LDK = BK + 8;                                       // padded [rows][k] LDS row (elements)
+  constexpr int A_TILE = GM_BM * LDK;                               // elements
+  constexpr int W_TILE = W_KMAJOR ? GM_BN * LDK : BK * GM_LDN;      // elements
+  constexpr int CPR = BK / 8;                                       // 16-byte chunks per [rows][k] row
+  constexpr int RPP = GM_THREADS / CPR;                             // rows per load pass
+  constexpr int NLA = GM_BM / RPP;                                  // A loads per thread per K-tile
+  constexpr int NLW = W_KMAJOR ? GM_BN / RPP : BK / 16;             // W loads per thread per K-tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int A_TILE = GM_BM * GM_LDK;                               // elements
-  constexpr int W_TILE = W_KMAJOR ? GM_BN * GM_LDK : GM_BK * GM_LDN;   // elements
   uint16_t *sA = reinterpret_cast<uint16_t *>(smem);
-  uint16_t *sW = sA + 2 * A_TILE;
+  uint16_t *sW = sA + NBUF * A_TILE;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -107,35 +120,38 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_kernel(GemmArgs p) 
   const uint16_t *We = reinterpret_cast<const uint16_t *>(p.W) + (size_t)e * p.w_stride_e;
 
   // ---- per-thread global source pointers (advance by BK along k each tile)
-  const uint16_t *a_src[4];
-  const uint16_t *w_src[4];
-  int a_dst[4], w_dst[4];  // LDS element offsets inside a tile
+  const uint16_t *a_src[NLA];
+  const uint16_t *w_src[NLW];
+  int a_dst[NLA], w_dst[NLW];  // LDS element offsets inside a tile
   {
-    const int kc = tid & 7, rbase = tid >> 3;  // [rows][k] tiles: 8 x 16B chunks per row
+    const int kc = tid % CPR, rbase = tid / CPR;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int r = rbase + 32 * i;
+    for (int i = 0; i < NLA; ++i) {
+      int r = rbase + RPP * i;
       int gr = min(m0 + r, p.R - 1);
       a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + kc * 8;
-      a_dst[i] = r * GM_LDK + kc * 8;
-      if (W_KMAJOR) {
+      a_dst[i] = r * LDK + kc * 8;
+    }
+    if (W_KMAJOR) {
+#pragma unroll
+      for (int i = 0; i < NLW; ++i) {
+        int r = rbase + RPP * i;
         int gn = min(n0 + r, p.N - 1);
         w_src[i] = We + (size_t)gn * p.ldw + kc * 8;
-        w_dst[i] = r * GM_LDK + kc * 8;
+        w_dst[i] = r * LDK + kc * 8;
       }
-    }
-    if (!W_KMAJOR) {
+    } else {
       const int nc = tid & 15, kbase = tid >> 4;  // [k][n] tile: 16 x 16B chunks per row
       int gn = min(n0 + nc * 8, p.N - 8);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NLW; ++i) {
         int kr = kbase + 16 * i;
         w_src[i] = We + (size_t)kr * p.ldw + gn;
         w_dst[i] = kr * GM_LDN + nc * 8;
       }
     }
   }
-  const size_t w_step = W_KMAJOR ? (size_t)GM_BK : (size_t)GM_BK * p.ldw;
+  const size_t w_step = W_KMAJOR ? (size_t)BK : (size_t)BK * p.ldw;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -147,42 +163,34 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_kernel(GemmArgs p) 
 
   // fragment read offsets (elements), constant over the K loop
   const int l31 = lane & 31, kg = lane >> 5;
-  const int a_frag_off = (wm * 64 + l31) * GM_LDK + kg * 8;             // + mi*32*LDK + kk*16
-  const int wk_frag_off = (wn * 64 + l31) * GM_LDK + kg * 8;            // k-major W
+  const int a_frag_off = (wm * 64 + l31) * LDK + kg * 8;                // + mi*32*LDK + kk*16
+  const int wk_frag_off = (wn * 64 + l31) * LDK + kg * 8;               // k-major W
   // n-major W via ds_read_b64_tr_b16: 16-lane group g reads the 4(k) x 16(n) block at
   // rows kk*16 + (g>>1)*8 + h*4, cols wn*64 + ni*32 + (g&1)*16; lane i of the group supplies the
   // address of row (i>>2), cols 4*(i&3)..+3 and receives column i, rows 0..3.
   const int g16 = lane >> 4, i16 = lane & 15;
   const int wt_frag_off = ((g16 >> 1) * 8 + (i16 >> 2)) * GM_LDN + wn * 64 + (g16 & 1) * 16 + 4 * (i16 & 3);
 
-  const int nk = p.K / GM_BK;
+  const int nk = p.K / BK;
+  // ROT: stagger the K-tile order per block so concurrently running blocks (same expert, other
+  // N-tiles; other experts) are not all at the same k offset of 4 KB-strided rows at once.
+  const int rot = ROT ? (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk) : 0;
 
-  // Prefetch registers: plain named vectors, straight-line code (no lambdas / conditionals --
-  // hipcc demotes captured aggregates to scratch and then waits vmcnt(0) after every load).
-  u32x4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+  // Prefetch registers: straight-line unrolled code over fixed-size arrays (no lambdas, no
+  // conditionals around the loads -- hipcc otherwise demotes them to scratch / waits vmcnt(0)).
+  u32x4 ra[NLA], rw[NLW];
 #define GM_GLOAD(KT)                                                                   \
   do {                                                                                 \
-    const size_t ao_ = (size_t)(KT) * GM_BK, wo_ = (size_t)(KT) * w_step;              \
-    ra0 = *reinterpret_cast<const u32x4 *>(a_src[0] + ao_);                            \
-    ra1 = *reinterpret_cast<const u32x4 *>(a_src[1] + ao_);                            \
-    ra2 = *reinterpret_cast<const u32x4 *>(a_src[2] + ao_);                            \
-    ra3 = *reinterpret_cast<const u32x4 *>(a_src[3] + ao_);                            \
-    rw0 = *reinterpret_cast<const u32x4 *>(w_src[0] + wo_);                            \
-    rw1 = *reinterpret_cast<const u32x4 *>(w_src[1] + wo_);                            \
-    rw2 = *reinterpret_cast<const u32x4 *>(w_src[2] + wo_);                            \
-    rw3 = *reinterpret_cast<const u32x4 *>(w_src[3] + wo_);                            \
+    int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
+    const size_t ao_ = (size_t)kr_ * BK, wo_ = (size_t)kr_ * w_step;                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLA; ++i_) ra[i_] = ld16<false>(a_src[i_] + ao_); \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) rw[i_] = ld16<NT>(w_src[i_] + wo_);    \
   } while (0)
 #define GM_LSTORE(BUF)                                                                 \
   do {                                                                                 \
     uint16_t *da_ = sA + (BUF) * A_TILE, *dw_ = sW + (BUF) * W_TILE;                   \
-    *reinterpret_cast<u32x4 *>(da_ + a_dst[0]) = ra0;                                  \
-    *reinterpret_cast<u32x4 *>(da_ + a_dst[1]) = ra1;                                  \
-    *reinterpret_cast<u32x4 *>(da_ + a_dst[2]) = ra2;                                  \
-    *reinterpret_cast<u32x4 *>(da_ + a_dst[3]) = ra3;                                  \
-    *reinterpret_cast<u32x4 *>(dw_ + w_dst[0]) = rw0;                                  \
-    *reinterpret_cast<u32x4 *>(dw_ + w_dst[1]) = rw1;                                  \
-    *reinterpret_cast<u32x4 *>(dw_ + w_dst[2]) = rw2;                                  \
-    *reinterpret_cast<u32x4 *>(dw_ + w_dst[3]) = rw3;                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLA; ++i_) *reinterpret_cast<u32x4 *>(da_ + a_dst[i_]) = ra[i_]; \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) *reinterpret_cast<u32x4 *>(dw_ + w_dst[i_]) = rw[i_]; \
   } while (0)
 
   GM_GLOAD(0);
@@ -190,24 +198,24 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_kernel(GemmArgs p) 
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+    const int buf = (NBUF == 2) ? (kt & 1) : 0;
     // prefetch the next K-tile (the last iteration re-reads its own tile: harmless, keeps the
     // loop body branch-free so the loads stay in flight across the MFMA block)
     const int kn = (kt + 1 < nk) ? kt + 1 : kt;
     GM_GLOAD(kn);
-    __builtin_amdgcn_sched_barrier(0);  // keep the 8 loads ABOVE the MFMA block (hipcc sinks them)
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads ABOVE the MFMA block (hipcc sinks them)
 
     const uint16_t *ca = sA + buf * A_TILE, *cw = sW + buf * W_TILE;
 #pragma unroll
-    for (int kk = 0; kk < GM_BK / 16; ++kk) {
+    for (int kk = 0; kk < BK / 16; ++kk) {
       u32x4 fa[2], fw[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
-        fa[mi] = *reinterpret_cast<const u32x4 *>(ca + a_frag_off + mi * 32 * GM_LDK + kk * 16);
+        fa[mi] = *reinterpret_cast<const u32x4 *>(ca + a_frag_off + mi * 32 * LDK + kk * 16);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         if (W_KMAJOR) {
-          fw[ni] = *reinterpret_cast<const u32x4 *>(cw + wk_frag_off + ni * 32 * GM_LDK + kk * 16);
+          fw[ni] = *reinterpret_cast<const u32x4 *>(cw + wk_frag_off + ni * 32 * LDK + kk * 16);
         } else {
           const uint16_t *ptr = cw + wt_frag_off + kk * 16 * GM_LDN + ni * 32;
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -226,8 +234,14 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_kernel(GemmArgs p) 
     }
 
     __builtin_amdgcn_sched_barrier(0);
-    GM_LSTORE(buf ^ 1);
-    __syncthreads();
+    if (NBUF == 2) {
+      GM_LSTORE(buf ^ 1);
+      __syncthreads();
+    } else {
+      __syncthreads();  // every wave is done reading the single buffer
+      GM_LSTORE(0);
+      __syncthreads();
+    }
   }
 #undef GM_GLOAD
 #undef GM_LSTORE
@@ -297,17 +311,57 @@ extern "C" int tutel_amd_probe_tr16(uint16_t *out, tutel_stream_t stream) {
 // -------------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------------
-template <typename T, bool KM>
-static int launch_gemm_act(const GemmArgs &a, int act, int grid, size_t lds, hipStream_t st) {
-  switch (act) {
-    case TUTEL_ACT_NONE: hipLaunchKernelGGL((expert_gemm_kernel<T, KM, TUTEL_ACT_NONE>), dim3(grid), dim3(GM_THREADS), lds, st, a); break;
-    case TUTEL_ACT_RELU: hipLaunchKernelGGL((expert_gemm_kernel<T, KM, TUTEL_ACT_RELU>), dim3(grid), dim3(GM_THREADS), lds, st, a); break;
-    case TUTEL_ACT_GELU: hipLaunchKernelGGL((expert_gemm_kernel<T, KM, TUTEL_ACT_GELU>), dim3(grid), dim3(GM_THREADS), lds, st, a); break;
-    case TUTEL_ACT_SILU: hipLaunchKernelGGL((expert_gemm_kernel<T, KM, TUTEL_ACT_SILU>), dim3(grid), dim3(GM_THREADS), lds, st, a); break;
-    default: tutel_set_error("tutel_amd_expert_gemm: unknown activation %d", act); return -1;
+template <int BK, int NBUF>
+static constexpr size_t gemm_lds_bytes(bool kmajor) {
+  return (size_t)(NBUF * GM_BM * (BK + 8) + NBUF * (kmajor ? GM_BN * (BK + 8) : BK * GM_LDN)) * 2;
+}
+
+template <typename T, bool KM, int ACT, int BK, int NBUF, int OCC, bool NT, bool ROT>
+static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
+  const size_t lds = gemm_lds_bytes<BK, NBUF>(KM);
+  auto kern = expert_gemm_kernel<T, KM, ACT, BK, NBUF, OCC, NT, ROT>;
+  static bool optin = false;  // one flag per instantiation: > 64 KiB of dynamic LDS needs the opt-in
+  if (!optin) {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    optin = true;
   }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_THREADS), lds, st, a);
   TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
   return 0;
+}
+
+// Tile configuration per weight layout, from on-hardware A/B at the headline shape
+// (tools/gemm_sweep.py; fc1 158.6 -> 136.2 us, fc2 129.0 -> 126.9 us):
+//   k-major W (fc1): non-temporal weight loads + rotated K order.  Rows are 4 KB apart and every
+//     concurrently running block would otherwise sit at the same k offset of its 128 rows --
+//     HBM channel hot-spotting; staggering the start tile per (expert, N-tile) removes it.
+//   n-major W (fc2): non-temporal weight loads, natural K order (256 B row chunks, 64 rows).
+// TUTEL_AMD_GEMM_PLAIN=1 selects the plain variant (cached loads, natural order) for A/B runs.
+static bool gemm_plain() {
+  static int v = -1;
+  if (v < 0) {
+    const char *s = getenv("TUTEL_AMD_GEMM_PLAIN");
+    v = (s && atoi(s) != 0) ? 1 : 0;
+  }
+  return v == 1;
+}
+
+template <typename T, bool KM, int ACT>
+static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
+  if (gemm_plain()) return launch_cfg<T, KM, ACT, 64, 2, 2, false, false>(a, grid, st);
+  return launch_cfg<T, KM, ACT, 64, 2, 2, true, KM>(a, grid, st);
+}
+
+template <typename T, bool KM>
+static int launch_gemm_act(const GemmArgs &a, int act, int grid, hipStream_t st) {
+  switch (act) {
+    case TUTEL_ACT_NONE: return launch_gemm<T, KM, TUTEL_ACT_NONE>(a, grid, st);
+    case TUTEL_ACT_RELU: return launch_gemm<T, KM, TUTEL_ACT_RELU>(a, grid, st);
+    case TUTEL_ACT_GELU: return launch_gemm<T, KM, TUTEL_ACT_GELU>(a, grid, st);
+    case TUTEL_ACT_SILU: return launch_gemm<T, KM, TUTEL_ACT_SILU>(a, grid, st);
+    default: tutel_set_error("tutel_amd_expert_gemm: unknown activation %d", act); return -1;
+  }
 }
 
 extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t a_stride_w,
@@ -320,10 +374,10 @@ extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t 
                                      tutel_stream_t stream) {
   TUTEL_REQUIRE(dtype == TUTEL_BF16 || dtype == TUTEL_F16, "tutel_amd_expert_gemm: dtype must be bf16 or fp16 (got %d)", dtype);
   TUTEL_REQUIRE(E_loc >= 0 && R >= 0 && N >= 1 && K >= 1, "tutel_amd_expert_gemm: bad sizes E_loc=%d R=%d N=%d K=%d", E_loc, R, N, K);
+  TUTEL_REQUIRE(K % 64 == 0, "tutel_amd_expert_gemm: K=%d must be a multiple of 64", K);
+  TUTEL_REQUIRE(N % 8 == 0, "tutel_amd_expert_gemm: N=%d must be a multiple of 8", N);
   if (E_loc == 0 || R == 0) return 0;
   TUTEL_REQUIRE(A && W && D, "tutel_amd_expert_gemm: null pointer");
-  TUTEL_REQUIRE(K % GM_BK == 0, "tutel_amd_expert_gemm: K=%d must be a multiple of %d", K, GM_BK);
-  TUTEL_REQUIRE(N % 8 == 0, "tutel_amd_expert_gemm: N=%d must be a multiple of 8", N);
   TUTEL_REQUIRE(a_rows_per_w >= 1 && d_rows_per_w >= 1, "tutel_amd_expert_gemm: rows_per_w must be >= 1");
   TUTEL_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldd % 4 == 0 && a_stride_e % 8 == 0 && a_stride_w % 8 == 0 &&
                     w_stride_e % 8 == 0 && d_stride_e % 4 == 0 && d_stride_w % 4 == 0 && bias_stride_e % 4 == 0,
@@ -345,26 +399,7 @@ extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t 
   TUTEL_REQUIRE(grid_ll < 0x7fffffffLL, "tutel_amd_expert_gemm: grid too large");
   const int grid = (int)grid_ll;
   hipStream_t st = (hipStream_t)stream;
-
-  const size_t lds_k = (size_t)(2 * GM_BM * GM_LDK + 2 * GM_BN * GM_LDK) * 2;
-  const size_t lds_n = (size_t)(2 * GM_BM * GM_LDK + 2 * GM_BK * GM_LDN) * 2;
-  static bool attr_done = false;
-  if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-#define OPTIN(T, KM, ACT, BYTES) (void)hipFuncSetAttribute((const void *)expert_gemm_kernel<T, KM, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))
-#define OPTIN_ALL(T)                                                              \
-  OPTIN(T, true, TUTEL_ACT_NONE, lds_k); OPTIN(T, true, TUTEL_ACT_RELU, lds_k);   \
-  OPTIN(T, true, TUTEL_ACT_GELU, lds_k); OPTIN(T, true, TUTEL_ACT_SILU, lds_k);   \
-  OPTIN(T, false, TUTEL_ACT_NONE, lds_n); OPTIN(T, false, TUTEL_ACT_RELU, lds_n); \
-  OPTIN(T, false, TUTEL_ACT_GELU, lds_n); OPTIN(T, false, TUTEL_ACT_SILU, lds_n)
-    OPTIN_ALL(bf16_t);
-    OPTIN_ALL(f16_t);
-#undef OPTIN_ALL
-#undef OPTIN
-    (void)hipGetLastError();
-    attr_done = true;
-  }
-
   if (dtype == TUTEL_BF16)
-    return w_kmajor ? launch_gemm_act<bf16_t, true>(a, act, grid, lds_k, st) : launch_gemm_act<bf16_t, false>(a, act, grid, lds_n, st);
-  return w_kmajor ? launch_gemm_act<f16_t, true>(a, act, grid, lds_k, st) : launch_gemm_act<f16_t, false>(a, act, grid, lds_n, st);
+    return w_kmajor ? launch_gemm_act<bf16_t, true>(a, act, grid, st) : launch_gemm_act<bf16_t, false>(a, act, grid, st);
+  return w_kmajor ? launch_gemm_act<f16_t, true>(a, act, grid, st) : launch_gemm_act<f16_t, false>(a, act, grid, st);
 }
