@@ -66,24 +66,29 @@ size_t tutel_amd_routing_workspace_bytes(int T, int E, int k);
  *   gates [k,T] dtype  scores[t, idx_k[t]], divided by clamp(sum_k, eps(dtype)) when
  *                      normalize_gate != 0 and k > 1, each step rounded in `dtype` exactly as
  *                      fast_dispatch.py:151,173-175 does.
- * Limits: 1 <= k <= min(E, 16), E <= 1024. */
+ * Limits: 1 <= k <= min(E, 16), E <= 1024.
+ * clear_map / clear_n (optional, NULL / 0): an int32 array this launch also fills with -1 -- pass
+ * the slot_map that the following tutel_amd_compute_location builds (slot_map_cleared = 1) to
+ * save the separate fill launch. */
 int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax, int T, int E, int k,
                         int normalize_gate, void *scores_out, int32_t *idx, void *gates, void *ws,
-                        size_t ws_bytes, tutel_stream_t stream);
+                        size_t ws_bytes, int32_t *clear_map, int clear_n, tutel_stream_t stream);
 
 /* idx[k,T] -> loc[k,T] (stable rank of token t among tokens with the same k-th choice, queued
  * after ALL tokens' earlier choices -- fast_dispatch.py:159-171), dispatch_count[E] (:177-178),
  * stats[0] = max_e dispatch_count[e] (the dropless capacity before the all-reduce, :192),
- * l_aux[0] = gshard loss in fp32 (losses.py:12-19; NULL to skip).
+ * l_aux[0] = gshard loss (losses.py:12-19; NULL to skip), computed in fp32 and stored as one
+ * element of l_aux_dtype (the reference returns it in the scores dtype).
  * hist_ready != 0: `ws` was filled by tutel_amd_gate_topk for the same (T,E,k) problem;
  * hist_ready == 0: idx comes from elsewhere, the histograms are rebuilt here first (l_aux is
  *                  then unavailable and must be NULL).
  * capacity > 0 additionally builds slot_map[E*capacity] (see tutel_amd_slot_map); pass
- * capacity <= 0 / slot_map NULL when the capacity is not known yet (capacity_factor <= 0). */
+ * capacity <= 0 / slot_map NULL when the capacity is not known yet (capacity_factor <= 0).
+ * slot_map_cleared != 0: the caller already filled slot_map with -1 (see tutel_amd_gate_topk). */
 int tutel_amd_compute_location(const int32_t *idx, int T, int E, int k, int hist_ready, void *ws,
                                size_t ws_bytes, int32_t *loc, int32_t *dispatch_count,
-                               int32_t *stats, float *l_aux, int capacity, int32_t *slot_map,
-                               tutel_stream_t stream);
+                               int32_t *stats, void *l_aux, int l_aux_dtype, int capacity,
+                               int32_t *slot_map, int slot_map_cleared, tutel_stream_t stream);
 
 /* slot_map[E*C]: for bucket row (e*C + c) the flat (choice,token) index j*T + t routed there,
  * or -1 for an empty row.  Inverse of (idx, loc) restricted to loc < C && 0 <= idx < E -- the

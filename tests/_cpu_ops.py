@@ -9,7 +9,7 @@ import torch
 from oracle import moe_oracle as O
 
 
-def gate_topk(inp, k, apply_softmax=False, normalize_gate=True, want_scores=False, ws=None):
+def gate_topk(inp, k, apply_softmax=False, normalize_gate=True, want_scores=False, ws=None, clear=None):
     scores = torch.softmax(inp, dim=1) if apply_softmax else inp
     k = min(k, scores.shape[1])
     idx = O.topk_indices(scores, k)
@@ -30,13 +30,13 @@ def _smap(idx, loc, E, C):
     return sm
 
 
-def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False):
+def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False, l_aux_dtype=torch.float32, cleared_slot_map=None):
     loc, cnt = O.compute_locations([idx[j] for j in range(idx.shape[0])], E)
     loc = torch.stack(loc)
     stats = cnt.max().reshape(1)
     l_aux = None
     if want_l_aux and ws is not None:
-        l_aux = O.gshard_loss(ws["scores"], ws["idx0"]).float().reshape(1)
+        l_aux = O.gshard_loss(ws["scores"], ws["idx0"]).to(l_aux_dtype).reshape(1)
     smap = _smap(idx, loc, E, capacity) if capacity > 0 else None
     return loc, cnt, stats, l_aux, smap
 

@@ -45,7 +45,7 @@ def test_argument_errors_are_reported_not_enqueued(L):
     assert L.tutel_amd_fast_encode(None, 99, None, None, 0, 4, 8, 4, None, None) != 0
     assert b"dtype" in L.tutel_amd_last_error()
     # k > E
-    assert L.tutel_amd_gate_topk(None, 0, 0, 4, 2, 3, 1, None, None, None, None, 0, None) != 0
+    assert L.tutel_amd_gate_topk(None, 0, 0, 4, 2, 3, 1, None, None, None, None, 0, None, 0, None) != 0
     assert b"k" in L.tutel_amd_last_error()
     # GEMM: K not a multiple of 64, fp32 experts
     assert L.tutel_amd_expert_gemm(None, 0, 0, 1, 0, None, 1, 0, 0, None, 0, None, 0, 0, 1, 0, 1, 1, 8, 100, 2, 0, None, 1, None) != 0

@@ -46,7 +46,7 @@ def main():
     res = {c: [] for c in cfgs}
     for _ in range(rounds):
         for c in cfgs:
-            env = dict(os.environ, TUTEL_AMD_GEMM_PLAIN=str(c), REPO=repo)
+            env = dict(os.environ, TUTEL_AMD_GEMM_IMPL=str(c), REPO=repo)
             out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
             if not line:

@@ -1,0 +1,203 @@
+// Dev microbenchmark: HBM read ceiling of the weight-streaming access patterns used by the expert
+// GEMM (pure loads, XOR-reduced so nothing is dead).  Build+run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 tools/wstream_bench.hip -o /tmp/wstream && /tmp/wstream
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+#include <stdlib.h>
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+extern __shared__ uint32_t dyn_lds[];
+#define TOUCH_LDS() do { if (threadIdx.x == 1023) dyn_lds[0] = 1; } while (0)
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+template <bool NT> __device__ __forceinline__ u32x4 ld(const uint16_t *p) {
+  if (NT) return __builtin_nontemporal_load((const u32x4 *)p);
+  return *(const u32x4 *)p;
+}
+__device__ __forceinline__ void acc4(u32x4 &a, u32x4 v) { a ^= v; }
+
+// A: fully linear grid-stride read
+template <bool NT> __global__ __launch_bounds__(256) void k_linear(const uint16_t *w, size_t nvec, uint32_t *out) {
+  u32x4 a = {0, 0, 0, 0};
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    u32x4 v0 = ld<NT>(w + i * 8), v1 = ld<NT>(w + (i + stride) * 8), v2 = ld<NT>(w + (i + 2 * stride) * 8), v3 = ld<NT>(w + (i + 3 * stride) * 8);
+    acc4(a, v0); acc4(a, v1); acc4(a, v2); acc4(a, v3);
+  }
+  for (; i < nvec; i += stride) acc4(a, ld<NT>(w + i * 8));
+  if ((a[0] ^ a[1] ^ a[2] ^ a[3]) == 0x12345678u) out[0] = 1;
+}
+
+// B: fc1-like.  W[e][n][k] k-major, K=2048.  block = (e, nt): 128 rows x 64 k per step, DEPTH steps in flight.
+template <bool NT, int DEPTH, bool ROT, bool XCD> __global__ __launch_bounds__(256, 2) void k_tile_k(const uint16_t *w, int E, int N, int K, uint32_t *out) {
+  TOUCH_LDS();
+  const int ntn = N / 128, nb = gridDim.x;
+  int wi = blockIdx.x;
+  if (XCD) { int q = nb >> 3, xcd = wi & 7, pos = wi >> 3; wi = xcd * q + pos; }
+  const int nt = wi % ntn, e = wi / ntn;
+  const int tid = threadIdx.x, kc = tid & 7, rb = tid >> 3;
+  const uint16_t *base = w + ((size_t)e * N + nt * 128) * K + kc * 8;
+  const int nk = K / 64;
+  const int rot = ROT ? ((nt + 3 * e) * nk / ntn) % nk : 0;
+  u32x4 a = {0, 0, 0, 0};
+  for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
+    u32x4 v[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      int kt = kt0 + d + rot; kt = kt >= nk ? kt - nk : kt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[d][i] = ld<NT>(base + (size_t)(rb + 32 * i) * K + kt * 64);
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc4(a, v[d][i]);
+  }
+  if ((a[0] ^ a[1] ^ a[2] ^ a[3]) == 0x12345678u) out[0] = 1;
+}
+
+// B2: fc1-like W stream PLUS the token tile A[e][128][K] re-read from L2 (what the GEMM does).
+// AFRAC = 1: A every step (BN=128), 2: every other step (BN=256), 4: every 4th (BN=512).
+// LSTORE: also write every loaded 16 B to LDS with ds_write_b128 (register-staged GEMM staging).
+template <int DEPTH, int AFRAC, bool LSTORE> __global__ __launch_bounds__(256, 2) void k_tile_k_a(const uint16_t *w, const uint16_t *act, int E, int N, int K, uint32_t *out) {
+  TOUCH_LDS();
+  const int ntn = N / 128, nb = gridDim.x;
+  int wi = blockIdx.x;
+  { int q = nb >> 3, xcd = wi & 7, pos = wi >> 3; wi = xcd * q + pos; }
+  const int nt = wi % ntn, e = wi / ntn;
+  const int tid = threadIdx.x, kc = tid & 7, rb = tid >> 3;
+  const uint16_t *base = w + ((size_t)e * N + nt * 128) * K + kc * 8;
+  const uint16_t *abase = act + (size_t)e * 128 * K + kc * 8;
+  const int nk = K / 64;
+  const int rot = ((nt + 3 * e) * nk / ntn) % nk;
+  u32x4 a = {0, 0, 0, 0}, a2 = {1, 2, 3, 4};
+  u32x4 *l4 = reinterpret_cast<u32x4 *>(dyn_lds);
+  for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
+    u32x4 v[DEPTH][4], va[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      int kt = kt0 + d + rot; kt = kt >= nk ? kt - nk : kt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[d][i] = ld<true>(base + (size_t)(rb + 32 * i) * K + kt * 64);
+      if (((kt0 + d) % AFRAC) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) va[d][i] = ld<false>(abase + (size_t)(rb + 32 * i) * K + kt * 64);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (LSTORE) l4[(d & 1) * 2048 + i * 256 + tid] = v[d][i]; else acc4(a, v[d][i]);
+      }
+      if (((kt0 + d) % AFRAC) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (LSTORE) l4[(d & 1) * 2048 + 1024 + i * 256 + tid] = va[d][i]; else a2 += va[d][i];
+        }
+      }
+      if (LSTORE) __syncthreads();
+    }
+  }
+  if (LSTORE) { a = l4[tid]; a2 = l4[tid + 1024]; }
+  if ((a[0] ^ a[1] ^ a[2] ^ a[3] ^ a2[0] ^ a2[3]) == 0x12345678u) out[0] = 1;
+}
+
+// C: fc2-like.  W[e][k][n] n-major, N=2048.  block = (e, nt): 64 k-rows x 128 n (256 B) per step.
+template <bool NT, int DEPTH> __global__ __launch_bounds__(256, 2) void k_tile_n(const uint16_t *w, int E, int N, int K, uint32_t *out) {
+  TOUCH_LDS();
+  const int ntn = N / 128, nb = gridDim.x;
+  int wi = blockIdx.x;
+  { int q = nb >> 3, xcd = wi & 7, pos = wi >> 3; wi = xcd * q + pos; }
+  const int nt = wi % ntn, e = wi / ntn;
+  const int tid = threadIdx.x, nc = tid & 15, kb = tid >> 4;
+  const uint16_t *base = w + (size_t)e * K * N + nt * 128 + nc * 8;
+  const int nk = K / 64;
+  u32x4 a = {0, 0, 0, 0};
+  for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
+    u32x4 v[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[d][i] = ld<NT>(base + (size_t)((kt0 + d) * 64 + kb + 16 * i) * N);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc4(a, v[d][i]);
+  }
+  if ((a[0] ^ a[1] ^ a[2] ^ a[3]) == 0x12345678u) out[0] = 1;
+}
+
+// D: slab.  block = (e, nt) owns the 512 KB contiguous slab of its 128 rows and reads it linearly
+// (what fc1 would do if the K-tile order did not matter): 4 KB per block per step.
+template <bool NT, int DEPTH> __global__ __launch_bounds__(256, 2) void k_slab(const uint16_t *w, int E, int N, int K, uint32_t *out) {
+  TOUCH_LDS();
+  const int ntn = N / 128, nb = gridDim.x;
+  int wi = blockIdx.x;
+  { int q = nb >> 3, xcd = wi & 7, pos = wi >> 3; wi = xcd * q + pos; }
+  const uint16_t *base = w + (size_t)wi * 128 * K + threadIdx.x * 8;
+  const int nsteps = 128 * K / (256 * 8);
+  u32x4 a = {0, 0, 0, 0};
+  for (int s0 = 0; s0 < nsteps; s0 += DEPTH * 4) {
+    u32x4 v[DEPTH * 4];
+#pragma unroll
+    for (int d = 0; d < DEPTH * 4; ++d) v[d] = ld<NT>(base + (size_t)(s0 + d) * 2048);
+#pragma unroll
+    for (int d = 0; d < DEPTH * 4; ++d) acc4(a, v[d]);
+  }
+  if ((a[0] ^ a[1] ^ a[2] ^ a[3]) == 0x12345678u) out[0] = 1;
+}
+
+template <typename F> float timeit(F f, int iters = 20) {
+  hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+  for (int i = 0; i < 3; ++i) f();
+  hipEventRecord(s);
+  for (int i = 0; i < iters; ++i) f();
+  hipEventRecord(e); hipEventSynchronize(e);
+  float ms; hipEventElapsedTime(&ms, s, e);
+  return ms * 1e3f / iters;
+}
+
+static int LDSB = 0;
+int main(int argc, char **argv) {
+  if (argc > 1) LDSB = atoi(argv[1]);
+  printf("dynamic LDS per block = %d bytes\n", LDSB);
+  const int E = 64, N = 2048, K = 2048;
+  const size_t bytes = (size_t)E * N * K * 2;
+  uint16_t *w, *w2; uint32_t *out;
+  CK(hipMalloc(&w, bytes)); CK(hipMalloc(&w2, bytes)); CK(hipMalloc(&out, 64));
+  CK(hipMemset(w, 1, bytes)); CK(hipMemset(w2, 2, bytes));
+  const int grid = E * (N / 128);
+  auto rep = [&](const char *name, float us) { printf("%-46s %8.1f us  %7.1f GB/s\n", name, us, bytes / us * 1e-3); };
+  // alternate between two buffers so the 256 MB infinity cache cannot serve a 512 MB stream anyway
+  rep("linear grid-stride (2048 blocks)", timeit([&] { hipLaunchKernelGGL(k_linear<false>, dim3(2048), dim3(256), 0, 0, w, bytes / 16, out); }));
+  rep("linear grid-stride NT", timeit([&] { hipLaunchKernelGGL(k_linear<true>, dim3(2048), dim3(256), 0, 0, w, bytes / 16, out); }));
+  rep("fc1-like tile_k depth1", timeit([&] { hipLaunchKernelGGL((k_tile_k<false, 1, false, true>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("fc1-like tile_k depth2", timeit([&] { hipLaunchKernelGGL((k_tile_k<false, 2, false, true>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("fc1-like tile_k depth4", timeit([&] { hipLaunchKernelGGL((k_tile_k<false, 4, false, true>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("fc1-like tile_k depth2 NT", timeit([&] { hipLaunchKernelGGL((k_tile_k<true, 2, false, true>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("fc1-like tile_k depth2 NT ROT", timeit([&] { hipLaunchKernelGGL((k_tile_k<true, 2, true, true>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("fc1-like tile_k depth4 NT ROT", timeit([&] { hipLaunchKernelGGL((k_tile_k<true, 4, true, true>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("fc1-like tile_k depth2 NT ROT no-xcd-remap", timeit([&] { hipLaunchKernelGGL((k_tile_k<true, 2, true, false>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  uint16_t *act; CK(hipMalloc(&act, (size_t)E * 128 * K * 2)); CK(hipMemset(act, 3, (size_t)E * 128 * K * 2));
+  rep("W + A every step            (BN=128)", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<1, 1, false>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+  rep("W + A every 2nd step        (BN=256)", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<2, 2, false>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+  rep("W + A every 4th step        (BN=512)", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<4, 4, false>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+  rep("W only depth1 (no A)", timeit([&] { hipLaunchKernelGGL((k_tile_k<true, 1, true, true>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  if (LDSB >= 65536) {
+    rep("W + A every step + ds_write_b128+barrier", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<1, 1, true>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+    rep("W + A/2 + ds_write_b128+barrier", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<2, 2, true>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+    rep("W + A/4 + ds_write_b128+barrier", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<4, 4, true>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+  }
+  // same, weights alternating between two 512 MB buffers (as fc1/fc2 do in the layer)
+  { int flip = 0; rep("fc1-like NT ROT depth2, alternating 2 x 512MB", timeit([&] { hipLaunchKernelGGL((k_tile_k<true, 2, true, true>), dim3(grid), dim3(256), LDSB, 0, (flip++ & 1) ? w2 : w, E, N, K, out); })); }
+  rep("fc2-like tile_n depth1", timeit([&] { hipLaunchKernelGGL((k_tile_n<false, 1>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("fc2-like tile_n depth2", timeit([&] { hipLaunchKernelGGL((k_tile_n<false, 2>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("fc2-like tile_n depth2 NT", timeit([&] { hipLaunchKernelGGL((k_tile_n<true, 2>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("fc2-like tile_n depth4 NT", timeit([&] { hipLaunchKernelGGL((k_tile_n<true, 4>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("slab (contiguous 512KB/block) depth1", timeit([&] { hipLaunchKernelGGL((k_slab<false, 1>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("slab depth2 NT", timeit([&] { hipLaunchKernelGGL((k_slab<true, 2>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  rep("slab depth4 NT", timeit([&] { hipLaunchKernelGGL((k_slab<true, 4>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
+  return 0;
+}

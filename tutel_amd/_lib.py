@@ -23,8 +23,8 @@ SIGNATURES = {
     "tutel_amd_target_arch": (ctypes.c_char_p, []),
     "tutel_amd_last_error": (ctypes.c_char_p, []),
     "tutel_amd_routing_workspace_bytes": (_sz, [_i, _i, _i]),
-    "tutel_amd_gate_topk": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "tutel_amd_compute_location": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "tutel_amd_gate_topk": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
+    "tutel_amd_compute_location": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "tutel_amd_slot_map": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tutel_amd_cumsum_sub_one": (_i, [_vp, _vp, _i, _i, _vp]),
     "tutel_amd_fast_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

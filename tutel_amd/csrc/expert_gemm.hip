@@ -79,7 +79,7 @@ template <bool NT> __device__ __forceinline__ u32x4 ld16(const uint16_t *p) {
 // Tile configuration: BK = K-tile depth (64 | 128); NBUF = LDS buffers (2: one barrier per K-tile;
 // 1: two barriers, half the LDS -> more blocks per CU); OCC = blocks per CU the register
 // allocator is asked to allow; NT = non-temporal weight loads.
-template <typename T, bool W_KMAJOR, int ACT, int BK, int NBUF, int OCC, bool NT, bool ROT>
+template <typename T, bool W_KMAJOR, int ACT, int BK, int NBUF, int OCC, bool NT, bool ROT, bool PF2>
 __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p) {
   constexpr int LDK = BK + 8;                                       // padded [rows][k] LDS row (elements)
   constexpr int A_TILE = GM_BM * LDK;                               // elements
@@ -178,73 +178,91 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
 
   // Prefetch registers: straight-line unrolled code over fixed-size arrays (no lambdas, no
   // conditionals around the loads -- hipcc otherwise demotes them to scratch / waits vmcnt(0)).
-  u32x4 ra[NLA], rw[NLW];
-#define GM_GLOAD(KT)                                                                   \
+  // Two register sets = prefetch distance 2: the loads of K-tile kt+2 are issued while tile kt is
+  // multiplied and tile kt+1 (issued one iteration earlier) is written to LDS.  With a single set
+  // every barrier waits for the slowest load of a tile issued only ~one MFMA block earlier (tail
+  // latency under full HBM load): measured 136 us vs the 91 us the same access pattern reaches
+  // with pure loads (tools/wstream_bench.hip).
+  u32x4 ra0[NLA], rw0[NLW], ra1[NLA], rw1[NLW];
+#define GM_GLOAD(RA, RW, KT)                                                           \
   do {                                                                                 \
-    int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
+    int kr_ = (KT); kr_ = kr_ < nk ? kr_ : nk - 1; /* past the end: re-read the last tile */ \
+    kr_ += rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                                      \
     const size_t ao_ = (size_t)kr_ * BK, wo_ = (size_t)kr_ * w_step;                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < NLA; ++i_) ra[i_] = ld16<false>(a_src[i_] + ao_); \
-    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) rw[i_] = ld16<NT>(w_src[i_] + wo_);    \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLA; ++i_) RA[i_] = ld16<false>(a_src[i_] + ao_); \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) RW[i_] = ld16<NT>(w_src[i_] + wo_);    \
   } while (0)
-#define GM_LSTORE(BUF)                                                                 \
+#define GM_LSTORE(RA, RW, BUF)                                                         \
   do {                                                                                 \
     uint16_t *da_ = sA + (BUF) * A_TILE, *dw_ = sW + (BUF) * W_TILE;                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < NLA; ++i_) *reinterpret_cast<u32x4 *>(da_ + a_dst[i_]) = ra[i_]; \
-    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) *reinterpret_cast<u32x4 *>(dw_ + w_dst[i_]) = rw[i_]; \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLA; ++i_) *reinterpret_cast<u32x4 *>(da_ + a_dst[i_]) = RA[i_]; \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLW; ++i_) *reinterpret_cast<u32x4 *>(dw_ + w_dst[i_]) = RW[i_]; \
+  } while (0)
+#define GM_COMPUTE(BUF)                                                                \
+  do {                                                                                 \
+    const uint16_t *ca = sA + (BUF) * A_TILE, *cw = sW + (BUF) * W_TILE;               \
+    _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk) {                           \
+      u32x4 fa[2], fw[2];                                                              \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
+        fa[mi] = *reinterpret_cast<const u32x4 *>(ca + a_frag_off + mi * 32 * LDK + kk * 16); \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                               \
+        if (W_KMAJOR) {                                                                \
+          fw[ni] = *reinterpret_cast<const u32x4 *>(cw + wk_frag_off + ni * 32 * LDK + kk * 16); \
+        } else {                                                                       \
+          const uint16_t *ptr = cw + wt_frag_off + kk * 16 * GM_LDN + ni * 32;         \
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                        \
+              (__attribute__((address_space(3))) s16x4_t *)(ptr));                     \
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                        \
+              (__attribute__((address_space(3))) s16x4_t *)(ptr + 4 * GM_LDN));        \
+          u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi); \
+          u32x4 f = {lo2[0], lo2[1], hi2[0], hi2[1]};                                  \
+          fw[ni] = f;                                                                  \
+        }                                                                              \
+      }                                                                                \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                 \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                               \
+          acc[ni][mi] = Mma<T>::run(fw[ni], fa[mi], acc[ni][mi]);                      \
+    }                                                                                  \
   } while (0)
 
-  GM_GLOAD(0);
-  GM_LSTORE(0);
-  __syncthreads();
+  static_assert(NBUF == 2, "the K loop below is written for the double-buffered LDS layout");
+  GM_GLOAD(ra0, rw0, 0);
+  GM_LSTORE(ra0, rw0, 0);
+  __syncthreads();                      // tile 0 in LDS buffer 0
+  if (PF2) GM_GLOAD(ra1, rw1, 1);       // tile 1 in flight in set 1
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = (NBUF == 2) ? (kt & 1) : 0;
-    // prefetch the next K-tile (the last iteration re-reads its own tile: harmless, keeps the
-    // loop body branch-free so the loads stay in flight across the MFMA block)
-    const int kn = (kt + 1 < nk) ? kt + 1 : kt;
-    GM_GLOAD(kn);
-    __builtin_amdgcn_sched_barrier(0);  // keep the loads ABOVE the MFMA block (hipcc sinks them)
-
-    const uint16_t *ca = sA + buf * A_TILE, *cw = sW + buf * W_TILE;
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      u32x4 fa[2], fw[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        fa[mi] = *reinterpret_cast<const u32x4 *>(ca + a_frag_off + mi * 32 * LDK + kk * 16);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        if (W_KMAJOR) {
-          fw[ni] = *reinterpret_cast<const u32x4 *>(cw + wk_frag_off + ni * 32 * LDK + kk * 16);
-        } else {
-          const uint16_t *ptr = cw + wt_frag_off + kk * 16 * GM_LDN + ni * 32;
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t *)(ptr));
-          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t *)(ptr + 4 * GM_LDN));
-          u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-          u32x4 f = {lo2[0], lo2[1], hi2[0], hi2[1]};
-          fw[ni] = f;
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = Mma<T>::run(fw[ni], fa[mi], acc[ni][mi]);
-    }
-
-    __builtin_amdgcn_sched_barrier(0);
-    if (NBUF == 2) {
-      GM_LSTORE(buf ^ 1);
+  if (PF2) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      // even step: buffer 0 holds tile kt, set 1 holds (or is receiving) tile kt+1
+      GM_GLOAD(ra0, rw0, kt + 2);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads ABOVE the MFMA block (hipcc sinks them)
+      GM_COMPUTE(0);
+      __builtin_amdgcn_sched_barrier(0);
+      GM_LSTORE(ra1, rw1, 1);
       __syncthreads();
-    } else {
-      __syncthreads();  // every wave is done reading the single buffer
-      GM_LSTORE(0);
+      if (kt + 1 >= nk) break;            // block-uniform
+      // odd step: buffer 1 holds tile kt+1, set 0 is receiving tile kt+2
+      GM_GLOAD(ra1, rw1, kt + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      GM_COMPUTE(1);
+      __builtin_amdgcn_sched_barrier(0);
+      GM_LSTORE(ra0, rw0, 0);
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      GM_GLOAD(ra0, rw0, kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      GM_COMPUTE(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      GM_LSTORE(ra0, rw0, buf ^ 1);
       __syncthreads();
     }
   }
 #undef GM_GLOAD
 #undef GM_LSTORE
+#undef GM_COMPUTE
 
   // ---- epilogue: lane holds, per accumulator, row m = l31, features 8*rg + 4*kg + 0..3
   uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;
@@ -289,6 +307,225 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
 }
 
 // -------------------------------------------------------------------------------------------
+// LDS-DMA variant (global_load_lds): tiles go HBM/L2 -> LDS without passing through VGPRs or the
+// ds_write path.  On-hardware ablation of the register-staged kernel above (tools/gemm_sweep.py):
+// its ds_write_b128 staging alone costs 23-44 us of 140 at the headline shape and 100 of 320 us at
+// R = 1024 rows/expert (1.07 GB through a ~79 B/clk/CU store path), so it is removed here.
+//
+// LDS-DMA writes lane i's 16 bytes at (wave-uniform base + 16*i): the LDS image of a tile is
+// LINEAR (no row padding).  Bank conflicts are avoided by permuting which 16-byte chunk of a
+// row each lane FETCHES (source-side XOR swizzle; same 128 B / 256 B global segment per row, so
+// coalescing is unchanged) and applying the same XOR when fragments are read:
+//   [rows][64 k] tiles (128 B rows):  chunk c of row r lives at position c ^ ((r >> 1) & 7)
+//       -> ds_read_b128 of 32 consecutive rows x one chunk column is conflict-free
+//   [64 k][128 n] weight tile (256 B rows): chunk c of row r lives at position c ^ ((r & 3) << 2)
+//       -> the 4(k) x 16(n) blocks of ds_read_b64_tr_b16 cover all 64 banks exactly once
+// 2 LDS stages x (16 KB tokens + 16 KB weights) = 64 KB per block, 2 blocks per CU.
+// -------------------------------------------------------------------------------------------
+#define GL_BK 64
+#define GL_STAGE (GM_BM * GL_BK)  // elements per [128][64] tile = 8192 (16 KB); the [64][128] tile is the same size
+
+__device__ __forceinline__ void glds16(const uint16_t *g, uint16_t *l, bool nt) {
+  if (nt)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 2);
+  else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+template <typename T, bool W_KMAJOR, int ACT, bool NT, bool ROT>
+__global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [2][GL_STAGE]
+  uint16_t *sW = sA + 2 * GL_STAGE;                   // [2][GL_STAGE]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+
+  const int nb = gridDim.x;
+  int w;
+  {
+    const int b = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = b & 7, pos = b >> 3;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int mt = w % p.ntm;
+  const int nt = (w / p.ntm) % p.ntn;
+  const int e = w / (p.ntm * p.ntn);
+  const int m0 = mt * GM_BM, n0 = nt * GM_BN;
+
+  int row_limit = p.R;
+  if (p.row_counts != nullptr) {
+    int c = p.row_counts[e];
+    c = (c + p.row_align - 1) / p.row_align * p.row_align;
+    row_limit = min(row_limit, c);
+  }
+  if (m0 >= row_limit) return;
+
+  const uint16_t *Ae = reinterpret_cast<const uint16_t *>(p.A) + (size_t)e * p.a_stride_e;
+  const uint16_t *We = reinterpret_cast<const uint16_t *>(p.W) + (size_t)e * p.w_stride_e;
+
+  // ---- DMA source pointers: wave `wid` issues pieces j = wid*4 + i (i < 4) of each tile; piece j
+  // of a [rows][64k] tile = rows 8j..8j+7 (1 KiB), lane -> (row 8j + lane/8, position lane%8).
+  const uint16_t *a_src[4], *w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 8 * (wid * 4 + i) + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int gr = min(m0 + r, p.R - 1);
+    a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + c * 8;
+    if (W_KMAJOR) {
+      const int gn = min(n0 + r, p.N - 1);
+      w_src[i] = We + (size_t)gn * p.ldw + c * 8;
+    } else {
+      // piece j of the [64k][128n] tile = k-rows 4j..4j+3, lane -> (row 4j + lane/16, position lane%16)
+      const int kr = 4 * (wid * 4 + i) + (lane >> 4);
+      const int cn = (lane & 15) ^ ((kr & 3) << 2);
+      const int gn = min(n0 + cn * 8, p.N - 8);
+      w_src[i] = We + (size_t)kr * p.ldw + gn;
+    }
+  }
+  const size_t w_step = W_KMAJOR ? (size_t)GL_BK : (size_t)GL_BK * p.ldw;
+  const int piece0 = wid * 4 * 512;  // element offset of this wave's first 1 KiB piece inside a tile
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- fragment read offsets (elements)
+  const int l31 = lane & 31, kg = lane >> 5;
+  const int sw = (l31 >> 1) & 7;  // (row >> 1) & 7 with row = 32*x + l31
+  int frag_k[4];                   // chunk position of (kk, kg) for this lane's row, in elements
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) frag_k[kk] = (((kk * 2 + kg) ^ sw) << 3);
+  const int a_row = (wm * 64 + l31) * GL_BK;  // + mi*32*64
+  const int wk_row = (wn * 64 + l31) * GL_BK; // + ni*32*64
+  // [k][n] tile via ds_read_b64_tr_b16 (see the register-staged kernel for the block geometry)
+  const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2;
+  const int c_lo = wn * 8 + (g16 & 1) * 2 + ((i16 & 3) >> 1);          // 16B chunk of ni = 0, before swizzle
+  const int wt_row = ((g16 >> 1) * 8 + q4) * GM_BN;                     // + (kk*16 + h*4) * 128
+  const int wt_c0 = (((c_lo) ^ (q4 << 2)) << 3) + (i16 & 1) * 4;        // element offset inside the row, ni = 0
+  const int wt_c1 = (((c_lo + 4) ^ (q4 << 2)) << 3) + (i16 & 1) * 4;    // ni = 1
+
+  const int nk = p.K / GL_BK;
+  const int rot = ROT ? (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk) : 0;
+
+#define GL_ISSUE(KT, BUF)                                                              \
+  do {                                                                                 \
+    int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
+    const size_t ao_ = (size_t)kr_ * GL_BK, wo_ = (size_t)kr_ * w_step;                \
+    uint16_t *da_ = sA + (BUF) * GL_STAGE + piece0, *dw_ = sW + (BUF) * GL_STAGE + piece0; \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, NT);    \
+  } while (0)
+
+#define GL_LOAD_FRAGS(FA, FW, KK)                                                      \
+  do {                                                                                 \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                   \
+      FA[mi] = *reinterpret_cast<const u32x4 *>(ca + a_row + mi * 32 * GL_BK + frag_k[KK]); \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                 \
+      if (W_KMAJOR) {                                                                  \
+        FW[ni] = *reinterpret_cast<const u32x4 *>(cw + wk_row + ni * 32 * GL_BK + frag_k[KK]); \
+      } else {                                                                         \
+        const uint16_t *ptr = cw + wt_row + (KK) * 16 * GM_BN + (ni ? wt_c1 : wt_c0);  \
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
+            (__attribute__((address_space(3))) s16x4_t *)(ptr));                       \
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
+            (__attribute__((address_space(3))) s16x4_t *)(ptr + 4 * GM_BN));           \
+        u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi); \
+        u32x4 f = {lo2[0], lo2[1], hi2[0], hi2[1]};                                    \
+        FW[ni] = f;                                                                    \
+      }                                                                                \
+    }                                                                                  \
+  } while (0)
+#define GL_MMA(FA, FW)                                                                 \
+  do {                                                                                 \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                   \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
+        acc[ni][mi] = Mma<T>::run(FW[ni], FA[mi], acc[ni][mi]);                        \
+  } while (0)
+
+  GL_ISSUE(0, 0);
+  __syncthreads();  // with a DMA in flight this is vmcnt(0) + barrier: tile 0 is in LDS stage 0
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) GL_ISSUE(kt + 1, buf ^ 1);  // block-uniform; next tile streams in during the MFMAs
+
+    const uint16_t *ca = sA + buf * GL_STAGE, *cw = sW + buf * GL_STAGE;
+    // fragment reads run one 16-deep slice ahead of the MFMAs that consume them
+    u32x4 fa0[2], fw0[2], fa1[2], fw1[2];
+    GL_LOAD_FRAGS(fa0, fw0, 0);
+    GL_LOAD_FRAGS(fa1, fw1, 1);
+    GL_MMA(fa0, fw0);
+    GL_LOAD_FRAGS(fa0, fw0, 2);
+    GL_MMA(fa1, fw1);
+    GL_LOAD_FRAGS(fa1, fw1, 3);
+    GL_MMA(fa0, fw0);
+    GL_MMA(fa1, fw1);
+
+    __syncthreads();  // all waves done with stage `buf`; next tile's DMA has landed (vmcnt(0))
+  }
+#undef GL_ISSUE
+#undef GL_LOAD_FRAGS
+#undef GL_MMA
+
+  // ---- epilogue (identical to the register-staged kernel)
+  uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;
+  const uint16_t *be = p.bias ? reinterpret_cast<const uint16_t *>(p.bias) + (size_t)e * p.bias_stride_e : nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wm * 64 + mi * 32 + l31;
+    if (m >= row_limit) continue;
+    uint16_t *drow = De + (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = n0 + wn * 64 + ni * 32 + rg * 8 + kg * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][rg * 4 + r];
+        if (be) {
+          uint2 bb = *reinterpret_cast<const uint2 *>(be + n);
+          uint16_t b4[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            T tb;
+            __builtin_memcpy(&tb, &b4[r], 2);
+            v[r] += Elem<T>::to_f32(tb);
+          }
+        }
+        uint16_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T tv = Elem<T>::from_f32(activate<ACT>(v[r]));
+          __builtin_memcpy(&o[r], &tv, 2);
+        }
+        uint2 ov;
+        ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        *reinterpret_cast<uint2 *>(drow + n) = ov;
+      }
+    }
+  }
+}
+
+template <typename T, bool KM, int ACT>
+static int launch_glds(const GemmArgs &a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((expert_gemm_glds_kernel<T, KM, ACT, true, KM>), dim3(grid), dim3(GM_THREADS),
+                     (size_t)4 * GL_STAGE * 2, st, a);
+  TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------
 // ds_read_b64_tr_b16 permutation probe (self-test)
 // -------------------------------------------------------------------------------------------
 __global__ void probe_tr16_kernel(uint16_t *out) {
@@ -316,10 +553,10 @@ static constexpr size_t gemm_lds_bytes(bool kmajor) {
   return (size_t)(NBUF * GM_BM * (BK + 8) + NBUF * (kmajor ? GM_BN * (BK + 8) : BK * GM_LDN)) * 2;
 }
 
-template <typename T, bool KM, int ACT, int BK, int NBUF, int OCC, bool NT, bool ROT>
+template <typename T, bool KM, int ACT, int BK, int NBUF, int OCC, bool NT, bool ROT, bool PF2>
 static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
   const size_t lds = gemm_lds_bytes<BK, NBUF>(KM);
-  auto kern = expert_gemm_kernel<T, KM, ACT, BK, NBUF, OCC, NT, ROT>;
+  auto kern = expert_gemm_kernel<T, KM, ACT, BK, NBUF, OCC, NT, ROT, PF2>;
   static bool optin = false;  // one flag per instantiation: > 64 KiB of dynamic LDS needs the opt-in
   if (!optin) {
     if (lds > 65536) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -331,26 +568,24 @@ static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
   return 0;
 }
 
-// Tile configuration per weight layout, from on-hardware A/B at the headline shape
-// (tools/gemm_sweep.py; fc1 158.6 -> 136.2 us, fc2 129.0 -> 126.9 us):
-//   k-major W (fc1): non-temporal weight loads + rotated K order.  Rows are 4 KB apart and every
-//     concurrently running block would otherwise sit at the same k offset of its 128 rows --
-//     HBM channel hot-spotting; staggering the start tile per (expert, N-tile) removes it.
-//   n-major W (fc2): non-temporal weight loads, natural K order (256 B row chunks, 64 rows).
-// TUTEL_AMD_GEMM_PLAIN=1 selects the plain variant (cached loads, natural order) for A/B runs.
-static bool gemm_plain() {
-  static int v = -1;
-  if (v < 0) {
-    const char *s = getenv("TUTEL_AMD_GEMM_PLAIN");
-    v = (s && atoi(s) != 0) ? 1 : 0;
-  }
-  return v == 1;
-}
-
+// Kernel choice per weight layout, from on-hardware A/B at the headline shape and at R = 1024
+// rows/expert (tools/gemm_sweep.py, MI355X, round 1):
+//   k-major W (fc1): LDS-DMA kernel          126-132 us  (register-staged: 136-140 us)
+//   n-major W (fc2): register-staged kernel  124-128 us  (LDS-DMA: 128-130 us; its tr-read image
+//                                                         has residual bank conflicts)
+// both with non-temporal weight loads; k-major additionally with the rotated K order (4 KB-strided
+// rows: 158 -> 143 us).  What did NOT pay (kept out of the tree, see git history): BK=128, single
+// LDS buffer at 3 blocks/CU, prefetch distance 2 (two register sets), a 128x256 8-wave 3-stage
+// LDS-DMA ring.  Ablation: compute alone 69 us, loads+staging alone 80-115 us -- the remaining
+// loss is phase serialisation inside a block, not DRAM (pure loads of the same pattern: 77-90 us).
+// TUTEL_AMD_GEMM_IMPL=0|1 forces register-staged | LDS-DMA for A/B runs.
 template <typename T, bool KM, int ACT>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
-  if (gemm_plain()) return launch_cfg<T, KM, ACT, 64, 2, 2, false, false>(a, grid, st);
-  return launch_cfg<T, KM, ACT, 64, 2, 2, true, KM>(a, grid, st);
+  static int impl = -2;
+  if (impl == -2) { const char *s = getenv("TUTEL_AMD_GEMM_IMPL"); impl = s ? atoi(s) : -1; }
+  const bool use_dma = impl < 0 ? KM : (impl == 1);
+  if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
+  return launch_cfg<T, KM, ACT, 64, 2, 2, true, KM, false>(a, grid, st);
 }
 
 template <typename T, bool KM>

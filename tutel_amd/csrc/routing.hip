@@ -49,7 +49,8 @@ template <typename T, int EPL, int GT_BATCH>
 __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
     const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
-    int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum) {
+    int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
+    int clear_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);             // [k][E]
   float *s_col = reinterpret_cast<float *>(smem) + (size_t)k * E;  // [GT_WAVES][E]
@@ -57,6 +58,14 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.x;
   const int t0 = b * tile, t1 = min(Tn, t0 + tile);
+
+  // the bucket->token map of the NEXT kernel starts out empty (-1): cleared here, one slice per
+  // block, instead of a separate fill launch (K2 runs strictly after this kernel on the stream)
+  if (clear_map != nullptr) {
+    const int per = (clear_n + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int c0 = b * per, c1 = min(clear_n, c0 + per);
+    for (int i = c0 + tid; i < c1; i += GT_THREADS) clear_map[i] = -1;
+  }
 
   for (int i = tid; i < k * E; i += GT_THREADS) s_hist[i] = 0;
   __syncthreads();
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
     const int32_t *__restrict__ idx, int Tn, int E, int k, int tile, int ntiles,
     const int32_t *__restrict__ ws_hist, const float *__restrict__ ws_colsum,
     int32_t *__restrict__ loc, int32_t *__restrict__ dispatch_count, int32_t *__restrict__ stats,
-    float *__restrict__ l_aux, int capacity, int32_t *__restrict__ slot_map) {
+    void *__restrict__ l_aux, int l_aux_dtype, int capacity, int32_t *__restrict__ slot_map) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *s_cur = reinterpret_cast<int32_t *>(smem);  // [k][E] running absolute location
   int32_t *s_tot = s_cur + (size_t)k * E;              // [k][E] per-choice totals
@@ -246,15 +255,15 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
   __syncthreads();
   for (int i = lane; i < kE; i += 64) {
     int base = 0, tot = 0;
-    for (int tl0 = wid; tl0 < ntiles; tl0 += RT_WAVES * 8) {
-      int h[8];
+    for (int tl0 = wid; tl0 < ntiles; tl0 += RT_WAVES * 16) {
+      int h[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         int tl = tl0 + u * RT_WAVES;
         h[u] = (tl < ntiles) ? ws_hist[(size_t)tl * kE + i] : 0;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         int tl = tl0 + u * RT_WAVES;
         tot += h[u];
         if (tl < b) base += h[u];
@@ -356,7 +365,12 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
       int m2 = 0;
       for (int w = 0; w < RT_WAVES; ++w) { p += s_red[w]; m2 = max(m2, s_redi[w]); }
       if (stats != nullptr) stats[0] = m2;
-      if (l_aux != nullptr) l_aux[0] = p / (float)Tn;
+      if (l_aux != nullptr) {
+        const float la = p / (float)Tn;
+        if (l_aux_dtype == TUTEL_F32) reinterpret_cast<float *>(l_aux)[0] = la;
+        else if (l_aux_dtype == TUTEL_BF16) reinterpret_cast<uint16_t *>(l_aux)[0] = f32_to_bf16_bits(la);
+        else reinterpret_cast<_Float16 *>(l_aux)[0] = (_Float16)la;
+      }
     }
   }
 }
@@ -407,7 +421,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cumsum_kernel(const int32_t *__
 template <typename T>
 static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, int k, int normalize,
                             void *scores_out, int32_t *idx, void *gates, void *ws,
-                            hipStream_t st) {
+                            int32_t *clear_map, int clear_n, hipStream_t st) {
   const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
@@ -420,7 +434,7 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
     hipLaunchKernelGGL((gate_topk_kernel<T, EPL, (EPL <= 4 ? 4 : (EPL <= 8 ? 2 : 1))>), dim3(nt), dim3(GT_THREADS), lds, st,         \
                        (const T *)in, apply_softmax, Tn, E, k, normalize, tile,                 \
-                       (T *)scores_out, idx, (T *)gates, ws_hist, ws_col);                      \
+                       (T *)scores_out, idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n);  \
   } while (0)
   if (epl <= 1) GT_LAUNCH(1);
   else if (epl <= 2) GT_LAUNCH(2);
@@ -434,7 +448,8 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
 
 extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax, int T, int E,
                                    int k, int normalize_gate, void *scores_out, int32_t *idx,
-                                   void *gates, void *ws, size_t ws_bytes, tutel_stream_t stream) {
+                                   void *gates, void *ws, size_t ws_bytes, int32_t *clear_map,
+                                   int clear_n, tutel_stream_t stream) {
   TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_gate_topk: unsupported dtype %d", dtype);
   TUTEL_REQUIRE(T >= 0 && E >= 1 && E <= RT_MAX_E, "tutel_amd_gate_topk: need 1 <= E <= %d (got %d)", RT_MAX_E, E);
   TUTEL_REQUIRE(k >= 1 && k <= RT_MAX_K && k <= E, "tutel_amd_gate_topk: need 1 <= k <= min(E,%d) (got k=%d, E=%d)", RT_MAX_K, k, E);
@@ -442,26 +457,31 @@ extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax,
   if (T == 0) return 0;
   TUTEL_REQUIRE(in && idx && gates && ws, "tutel_amd_gate_topk: null pointer");
   TUTEL_REQUIRE(ws_bytes >= tutel_amd_routing_workspace_bytes(T, E, k), "tutel_amd_gate_topk: workspace too small");
+  TUTEL_REQUIRE(clear_n >= 0 && (clear_map != nullptr || clear_n == 0), "tutel_amd_gate_topk: bad clear_map");
+  if (clear_n == 0) clear_map = nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, st);
-  if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, st);
-  return launch_gate_topk<f16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, st);
+  if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
+  if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
+  return launch_gate_topk<f16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
 }
 
 extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int k, int hist_ready,
                                           void *ws, size_t ws_bytes, int32_t *loc,
-                                          int32_t *dispatch_count, int32_t *stats, float *l_aux,
-                                          int capacity, int32_t *slot_map, tutel_stream_t stream) {
+                                          int32_t *dispatch_count, int32_t *stats, void *l_aux,
+                                          int l_aux_dtype, int capacity, int32_t *slot_map,
+                                          int slot_map_cleared, tutel_stream_t stream) {
   TUTEL_REQUIRE(T >= 0 && E >= 1 && E <= RT_MAX_E, "tutel_amd_compute_location: need 1 <= E <= %d (got %d)", RT_MAX_E, E);
   TUTEL_REQUIRE(k >= 1 && k <= RT_MAX_K, "tutel_amd_compute_location: need 1 <= k <= %d (got %d)", RT_MAX_K, k);
   TUTEL_REQUIRE((size_t)k * E <= 8192, "tutel_amd_compute_location: k*E = %d exceeds 8192", k * E);
   TUTEL_REQUIRE(dispatch_count != nullptr, "tutel_amd_compute_location: dispatch_count is null");
+  TUTEL_REQUIRE(l_aux == nullptr || dtype_ok(l_aux_dtype), "tutel_amd_compute_location: bad l_aux dtype %d", l_aux_dtype);
+  TUTEL_REQUIRE((long long)k * T < 0x7fffffffLL, "tutel_amd_compute_location: k*T overflows int32");
   TUTEL_REQUIRE(hist_ready || l_aux == nullptr, "tutel_amd_compute_location: l_aux needs the column sums written by tutel_amd_gate_topk (hist_ready=1)");
   hipStream_t st = (hipStream_t)stream;
   if (T == 0) {
     (void)hipMemsetAsync(dispatch_count, 0, (size_t)E * 4, st);
     if (stats) (void)hipMemsetAsync(stats, 0, 4, st);
-    if (l_aux) (void)hipMemsetAsync(l_aux, 0, 4, st);
+    if (l_aux) (void)hipMemsetAsync(l_aux, 0, dtype_size(l_aux_dtype), st);
     if (slot_map && capacity > 0) (void)hipMemsetAsync(slot_map, 0xFF, (size_t)E * capacity * 4, st);
     return 0;
   }
@@ -475,14 +495,16 @@ extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int 
     TUTEL_CHECK_LAUNCH("tutel_amd_compute_location(hist)");
   }
   if (slot_map != nullptr && capacity > 0) {
-    hipError_t e = hipMemsetAsync(slot_map, 0xFF, (size_t)E * capacity * 4, st);
-    TUTEL_REQUIRE(e == hipSuccess, "tutel_amd_compute_location: memset failed: %s", hipGetErrorString(e));
+    if (!slot_map_cleared) {
+      hipError_t e = hipMemsetAsync(slot_map, 0xFF, (size_t)E * capacity * 4, st);
+      TUTEL_REQUIRE(e == hipSuccess, "tutel_amd_compute_location: memset failed: %s", hipGetErrorString(e));
+    }
   } else {
     slot_map = nullptr;
     capacity = 0;
   }
   hipLaunchKernelGGL(location_kernel, dim3(nt), dim3(RT_THREADS), ((size_t)2 * k * E + (size_t)(E > RT_THREADS ? E : RT_THREADS)) * 4, st, idx, T, E, k,
-                     tile, nt, ws_hist, ws_col, loc, dispatch_count, stats, l_aux, capacity, slot_map);
+                     tile, nt, ws_hist, ws_col, loc, dispatch_count, stats, l_aux, l_aux_dtype, capacity, slot_map);
   TUTEL_CHECK_LAUNCH("tutel_amd_compute_location");
   return 0;
 }

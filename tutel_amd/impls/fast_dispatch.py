@@ -149,9 +149,6 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
     work = src if ops.supported_dtype(src.dtype) else src.float()
     needs_grad = torch.is_grad_enabled() and src.requires_grad
 
-    idx2d, gates2d, ws, scores_k = ops.gate_topk(work.detach(), k, apply_softmax=_logits is not None,
-                                                 normalize_gate=normalize_gate,
-                                                 want_scores=(_logits is not None and (needs_grad or loss_fn not in (None, losses.gshard_loss))))
     fused_loss = loss_fn is losses.gshard_loss and not needs_grad
 
     if capacity_factor > 0:
@@ -163,6 +160,15 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
         capacity += (alignment - rem) if rem > 0 else 0
     else:
         capacity = 0  # known only after the counts are
+
+    # the top-k launch also clears the bucket->token map the location launch fills
+    pre = None
+    if capacity > 0 and not batch_prioritized_routing:
+        pre = torch.empty([E * capacity], dtype=torch.int32, device=src.device)
+    idx2d, gates2d, ws, scores_k = ops.gate_topk(work.detach(), k, apply_softmax=_logits is not None,
+                                                 normalize_gate=normalize_gate,
+                                                 want_scores=(_logits is not None and (needs_grad or loss_fn not in (None, losses.gshard_loss))),
+                                                 clear=pre)
 
     if batch_prioritized_routing:
         # tokens ranked by -max score get their buckets first (fast_dispatch.py:138-141,155-157):
@@ -176,7 +182,9 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
         smap = None
         fused_loss = False
     else:
-        loc2d, cnt, stats, l_aux_k, smap = ops.compute_location(idx2d, E, ws=ws, capacity=capacity, want_l_aux=fused_loss)
+        loc2d, cnt, stats, l_aux_k, smap = ops.compute_location(
+            idx2d, E, ws=ws, capacity=capacity, want_l_aux=fused_loss,
+            l_aux_dtype=src.dtype if ops.supported_dtype(src.dtype) else torch.float32, cleared_slot_map=pre)
 
     if capacity_factor <= 0:
         spe = (T + E - 1) // E
@@ -211,7 +219,7 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
     if loss_fn is None:
         l_aux = None
     elif fused_loss:
-        l_aux = l_aux_k[0].to(src.dtype)
+        l_aux = l_aux_k[0] if l_aux_k.dtype == src.dtype else l_aux_k[0].to(src.dtype)
     else:
         sc = scores if scores is not None else (scores_k if scores_k is not None and not needs_grad else torch.softmax(_logits, dim=1))
         l_aux = loss_fn(sc, idx2d.t().long())

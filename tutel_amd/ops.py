@@ -47,8 +47,9 @@ def routing_workspace(T, E, k, device):
     return torch.empty([max(int(n), 4)], dtype=torch.uint8, device=device)
 
 
-def gate_topk(inp, k, apply_softmax=False, normalize_gate=True, want_scores=False, ws=None):
-    """inp [T,E] scores (or logits with apply_softmax) -> idx [k,T] i32, gates [k,T], ws, scores|None."""
+def gate_topk(inp, k, apply_softmax=False, normalize_gate=True, want_scores=False, ws=None, clear=None):
+    """inp [T,E] scores (or logits with apply_softmax) -> idx [k,T] i32, gates [k,T], ws, scores|None.
+    clear: optional int32 tensor this launch also fills with -1 (the slot_map of the next call)."""
     _dev(inp)
     assert inp.dim() == 2
     inp = inp.contiguous()
@@ -62,12 +63,14 @@ def gate_topk(inp, k, apply_softmax=False, normalize_gate=True, want_scores=Fals
     L = _lib.lib()
     _lib.check(L.tutel_amd_gate_topk(_ptr(inp), _code(inp), int(bool(apply_softmax)), T, E, k,
                                      int(bool(normalize_gate)), _ptr(scores), _ptr(idx), _ptr(gates),
-                                     _ptr(ws), ws.numel(), _stream()), "tutel_amd_gate_topk")
+                                     _ptr(ws), ws.numel(), _ptr(clear), clear.numel() if clear is not None else 0,
+                                     _stream()), "tutel_amd_gate_topk")
     return idx, gates, ws, (scores if apply_softmax else inp)
 
 
-def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False):
-    """idx [k,T] -> loc [k,T], dispatch_count [E], stats [1] (max count), l_aux [1]|None, slot_map|None."""
+def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False, l_aux_dtype=torch.float32, cleared_slot_map=None):
+    """idx [k,T] -> loc [k,T], dispatch_count [E], stats [1] (max count), l_aux [1]|None, slot_map|None.
+    cleared_slot_map: an [E*capacity] int32 tensor already filled with -1 (see gate_topk(clear=...))."""
     _dev(idx)
     assert idx.dtype == torch.int32 and idx.dim() == 2 and idx.is_contiguous()
     k, T = idx.shape
@@ -78,12 +81,19 @@ def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False):
     loc = torch.empty_like(idx)
     cnt = torch.empty([E], dtype=torch.int32, device=dev)
     stats = torch.empty([1], dtype=torch.int32, device=dev)
-    l_aux = torch.empty([1], dtype=torch.float32, device=dev) if (want_l_aux and hist_ready) else None
-    smap = torch.empty([E * capacity], dtype=torch.int32, device=dev) if capacity > 0 else None
+    l_aux = torch.empty([1], dtype=l_aux_dtype, device=dev) if (want_l_aux and hist_ready) else None
+    smap = None
+    if capacity > 0:
+        if cleared_slot_map is not None:
+            assert cleared_slot_map.numel() == E * capacity and cleared_slot_map.dtype == torch.int32
+            smap = cleared_slot_map
+        else:
+            smap = torch.empty([E * capacity], dtype=torch.int32, device=dev)
     L = _lib.lib()
     _lib.check(L.tutel_amd_compute_location(_ptr(idx), T, E, k, int(hist_ready), _ptr(ws), ws.numel(),
                                             _ptr(loc), _ptr(cnt), _ptr(stats), _ptr(l_aux),
-                                            int(capacity), _ptr(smap), _stream()),
+                                            _code(l_aux) if l_aux is not None else 0,
+                                            int(capacity), _ptr(smap), int(cleared_slot_map is not None), _stream()),
                "tutel_amd_compute_location")
     return loc, cnt, stats, l_aux, smap
 
