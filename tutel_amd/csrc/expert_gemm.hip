@@ -519,7 +519,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
 
 template <typename T, bool KM, int ACT>
 static int launch_glds(const GemmArgs &a, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((expert_gemm_glds_kernel<T, KM, ACT, true, KM>), dim3(grid), dim3(GM_THREADS),
+  hipLaunchKernelGGL((expert_gemm_glds_kernel<T, KM, ACT, true, true>), dim3(grid), dim3(GM_THREADS),
                      (size_t)4 * GL_STAGE * 2, st, a);
   TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
   return 0;
@@ -573,8 +573,10 @@ static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
 //   k-major W (fc1): LDS-DMA kernel          126-132 us  (register-staged: 136-140 us)
 //   n-major W (fc2): register-staged kernel  124-128 us  (LDS-DMA: 128-130 us; its tr-read image
 //                                                         has residual bank conflicts)
-// both with non-temporal weight loads; k-major additionally with the rotated K order (4 KB-strided
-// rows: 158 -> 143 us).  What did NOT pay (kept out of the tree, see git history): BK=128, single
+// both with non-temporal weight loads and the rotated K order (rows are 4 KB apart in both layouts;
+// without the per-block stagger all resident blocks sit at the same k offset: k-major 158 -> 143 us,
+// n-major 142 -> 130 us when the weights really come from HBM, i.e. fc1/fc2 alternating as in the
+// layer -- a warm Infinity Cache hides this, so A/B runs must alternate the two weight sets).  What did NOT pay (kept out of the tree, see git history): BK=128, single
 // LDS buffer at 3 blocks/CU, prefetch distance 2 (two register sets), a 128x256 8-wave 3-stage
 // LDS-DMA ring.  Ablation: compute alone 69 us, loads+staging alone 80-115 us -- the remaining
 // loss is phase serialisation inside a block, not DRAM (pure loads of the same pattern: 77-90 us).
@@ -585,7 +587,7 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   if (impl == -2) { const char *s = getenv("TUTEL_AMD_GEMM_IMPL"); impl = s ? atoi(s) : -1; }
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
-  return launch_cfg<T, KM, ACT, 64, 2, 2, true, KM, false>(a, grid, st);
+  return launch_cfg<T, KM, ACT, 64, 2, 2, true, true, false>(a, grid, st);
 }
 
 template <typename T, bool KM>
