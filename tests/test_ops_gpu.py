@@ -39,7 +39,8 @@ def test_probe_tr16_permutation():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("T,E,k", [(512, 16, 2), (4096, 64, 2), (300, 7, 3), (1000, 130, 4), (64, 64, 1), (5000, 256, 8)])
+@pytest.mark.parametrize("T,E,k", [(512, 16, 2), (4096, 64, 2), (300, 7, 3), (1000, 130, 4), (64, 64, 1), (5000, 256, 8),
+                                   (500, 32, 6), (900, 128, 8), (9000, 64, 2), (77, 2, 2), (130, 5, 5)])
 def test_gate_topk_and_location_vs_oracle(oracle, dtype, T, E, k):
     ops = _ops()
     g = torch.Generator().manual_seed(T * 131 + E * 7 + k)
@@ -89,7 +90,7 @@ def test_fused_softmax_topk(oracle, dtype):
     logits = (torch.randn([4096, 64], generator=g) * 2).to(dtype)
     idx, gates, ws, scores = ops.gate_topk(logits.cuda(), 2, apply_softmax=True, normalize_gate=True, want_scores=True)
     ref = torch.softmax(logits.float(), dim=1)
-    tol = {torch.float32: 2e-7, torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}[dtype]
+    tol = {torch.float32: 1e-6, torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}[dtype]  # a few ulps: softmax is not bit-specified
     assert (scores.cpu().float() - ref).abs().max() <= tol * max(1.0, float(ref.max())) + 1e-7
     # routing decisions are exact GIVEN the kernel's own (rounded) scores
     crit, _ = oracle.extract_critical(scores.cpu(), 2, 1.0)

@@ -210,6 +210,136 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
 }
 
 // -------------------------------------------------------------------------------------------
+// K1, small-E variant (E <= 128): SIXTEEN lanes per token instead of a whole wave.  Lane q of a
+// 16-lane row owns the contiguous expert slice [q*EPQ, (q+1)*EPQ) in registers (EPQ = ceil(E/16)
+// <= 8), so softmax max/sum and the top-k arg-max need four row-local exchange steps (xor 1,2,4,8:
+// DPP row operations, ALU latency) instead of six ds_bpermute round trips, and only EPQ elements
+// of serial per-lane work.  1024 threads = 64 tokens = one location tile; 16 waves per CU hide the
+// dependent-VALU latency that a 4-wave block exposes (measured: 9.2 us with 4 lanes/token and
+// 256-thread blocks vs the numbers in DESIGN.md for this layout).  Score column sums go through
+// an LDS tile and are summed per expert in token order (deterministic).  Outputs are identical,
+// bit for bit, to gate_topk_kernel.
+// -------------------------------------------------------------------------------------------
+#define GQ_LPT 16
+#define GQ_THREADS 1024
+template <typename T, int EPQ>
+__global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
+    const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
+    T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
+    int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
+    int clear_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ES = GQ_LPT * EPQ + 1;                                    // padded row of the score tile
+  int32_t *s_hist = reinterpret_cast<int32_t *>(smem);                // [k][E]
+  float *s_sc = reinterpret_cast<float *>(smem) + (size_t)k * E;      // [64][ES]
+
+  const int tid = threadIdx.x, q = tid & (GQ_LPT - 1), tl = tid / GQ_LPT;  // tl = token slot 0..63
+  const int b = blockIdx.x;
+  const int t0 = b * tile, t1 = min(Tn, t0 + tile);
+
+  if (clear_map != nullptr) {
+    const int per = (clear_n + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int c0 = b * per, c1 = min(clear_n, c0 + per);
+    for (int i = c0 + tid; i < c1; i += GQ_THREADS) clear_map[i] = -1;
+  }
+  for (int i = tid; i < k * E; i += GQ_THREADS) s_hist[i] = 0;
+  float colsum = 0.f;  // thread e < E accumulates column e over the tile, in token order
+  __syncthreads();
+
+  for (int ts = t0; ts < t1; ts += 64) {
+    const int t = ts + tl;
+    const bool live = t < t1;
+    float v[EPQ];
+    {
+      const T *row = in + (size_t)min(t, Tn - 1) * E + q * EPQ;
+#pragma unroll
+      for (int j = 0; j < EPQ; ++j) {
+        int e = q * EPQ + j;
+        v[j] = (e < E) ? Elem<T>::to_f32(row[j]) : -INFINITY;
+      }
+    }
+    if (apply_softmax) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < EPQ; ++j) m = fmaxf(m, v[j]);
+#pragma unroll
+      for (int o = 1; o < GQ_LPT; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPQ; ++j) {
+        int e = q * EPQ + j;
+        v[j] = (e < E) ? expf(v[j] - m) : 0.f;
+        s += v[j];
+      }
+#pragma unroll
+      for (int o = 1; o < GQ_LPT; o <<= 1) s += __shfl_xor(s, o, 64);  // fixed butterfly order
+#pragma unroll
+      for (int j = 0; j < EPQ; ++j) {
+        int e = q * EPQ + j;
+        if (e < E) {
+          T r = Elem<T>::from_f32(v[j] / s);
+          v[j] = Elem<T>::to_f32(r);
+          if (scores_out && live) scores_out[(size_t)t * E + e] = r;
+        } else {
+          v[j] = -INFINITY;
+        }
+      }
+    }
+    // score tile -> LDS for the deterministic column sums
+#pragma unroll
+    for (int j = 0; j < EPQ; ++j) {
+      int e = q * EPQ + j;
+      if (e < E) s_sc[tl * ES + e] = live ? v[j] : 0.f;
+      if (v[j] != v[j]) v[j] = -INFINITY;  // NaN sorts last
+    }
+
+    uint32_t taken = 0;
+    float myg = 0.f, denom = 0.f;
+    for (int c = 0; c < k; ++c) {
+      float bv = -INFINITY;
+      int be = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < EPQ; ++j) {
+        int e = q * EPQ + j;
+        bool ok = (e < E) && !((taken >> j) & 1u);
+        if (ok && (v[j] > bv || (v[j] == bv && e < be))) { bv = v[j]; be = e; }
+      }
+#pragma unroll
+      for (int o = 1; o < GQ_LPT; o <<= 1) {
+        float ov = __shfl_xor(bv, o, 64);
+        int oe = __shfl_xor(be, o, 64);
+        if (ov > bv || (ov == bv && oe < be)) { bv = ov; be = oe; }
+      }
+      if (be / EPQ == q) taken |= 1u << (be - q * EPQ);
+      denom = (c == 0) ? bv : round_to<T>(denom + bv);   // ((0+g0)+g1)+... rounded in dtype T
+      if (c == q) myg = bv;                              // choice c parked on lane c of the row (k <= 16)
+      if (q == 0 && live) {
+        idx[(size_t)c * Tn + t] = be;
+        atomicAdd(&s_hist[c * E + be], 1);
+      }
+    }
+    if (q < k && live) {
+      float g = myg;
+      if (normalize && k > 1) {
+        float d = fmaxf(denom, Elem<T>::eps());
+        if (denom != denom) d = denom;  // torch.clamp keeps NaN
+        g = g / d;
+      }
+      gates[(size_t)q * Tn + t] = Elem<T>::from_f32(g);
+    }
+    __syncthreads();
+    if (tid < E) {
+      float s = colsum;
+      for (int r = 0; r < 64; ++r) s += s_sc[r * ES + tid];
+      colsum = s;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < k * E; i += GQ_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
+  if (tid < E) ws_colsum[(size_t)b * E + tid] = colsum;
+}
+
+// -------------------------------------------------------------------------------------------
 // tile histograms from an externally supplied idx[k,T] (hist_ready == 0 path)
 // -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RT_THREADS) void tile_hist_kernel(const int32_t *__restrict__ idx,
@@ -285,26 +415,25 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
   __syncthreads();
 
   // 3. stable rank inside the tile: wave handles one choice, 64 tokens per step
+  int ebits = 0;
+  while ((1 << ebits) < E) ++ebits;
   for (int j = wid; j < k; j += RT_WAVES) {
     int32_t *cur = s_cur + j * E;
     for (int c0 = t0; c0 < t1; c0 += 64) {
       int t = c0 + lane;
       int e = (t < t1) ? idx[(size_t)j * Tn + t] : -1;
       bool valid = (e >= 0) && (e < E);
-      int rank = 0, cnt = 0;
-      bool leader = false;
-      unsigned long long remaining = __ballot(valid);
-      while (remaining) {
-        int first = __ffsll((long long)remaining) - 1;
-        int e0 = __shfl(e, first, 64);
-        unsigned long long m = __ballot(valid && e == e0);
-        if (valid && e == e0) {
-          rank = __popcll(m & ((1ull << lane) - 1ull));
-          cnt = __popcll(m);
-          leader = (lane == first);
-        }
-        remaining &= ~m;
+      // lanes holding the same expert: AND over the bits of the expert id of (ballot of that bit,
+      // complemented where my bit is 0) -- ceil(log2 E) ballots instead of one loop iteration per
+      // distinct expert present in the wave.
+      unsigned long long same = __ballot(valid);
+      for (int bit = 0; bit < ebits; ++bit) {
+        const unsigned long long bb = __ballot(valid && ((e >> bit) & 1));
+        same &= ((e >> bit) & 1) ? bb : ~bb;
       }
+      const int rank = __popcll(same & ((1ull << lane) - 1ull));
+      const int cnt = __popcll(same);
+      const bool leader = valid && (__ffsll((long long)same) - 1 == lane);
       int base = valid ? cur[e] : 0;
       int l = base + rank;
       if (leader) cur[e] = base + cnt;
@@ -426,6 +555,22 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
   size_t lds = ((size_t)k * E + (size_t)GT_WAVES * E) * 4;
+  if (E <= 128) {
+    const int epq = (E + GQ_LPT - 1) / GQ_LPT;                 // 1..8
+    const int epq_t = epq <= 1 ? 1 : (epq <= 2 ? 2 : (epq <= 4 ? 4 : 8));
+    const size_t lds_q = ((size_t)k * E + (size_t)64 * (GQ_LPT * epq_t + 1)) * 4;
+#define GQ_LAUNCH(EPQ)                                                                         \
+    hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ>), dim3(nt), dim3(GQ_THREADS), lds_q, st,  \
+                       (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out, \
+                       idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n)
+    if (epq_t == 1) GQ_LAUNCH(1);
+    else if (epq_t == 2) GQ_LAUNCH(2);
+    else if (epq_t == 4) GQ_LAUNCH(4);
+    else GQ_LAUNCH(8);
+#undef GQ_LAUNCH
+    TUTEL_CHECK_LAUNCH("tutel_amd_gate_topk");
+    return 0;
+  }
   const int epl = (E + 63) / 64;
 #define GT_LAUNCH(EPL)                                                                          \
   do {                                                                                          \
