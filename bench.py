@@ -19,7 +19,7 @@ value = N * 4096 / t.
 Timing: W untimed warm-up steps; barrier + synchronize; exactly K steps; synchronize + barrier;
 MAX over ranks.  Rank 0 prints ONE JSON line.
 
-`roofline`: the dominant kernel is the fc1 grouped GEMM (expert_gemm_kernel<bf16,k-major,relu>):
+`roofline`: the dominant kernel is the fc1 grouped GEMM (expert_gemm_glds_kernel<bf16,k-major,relu>):
 HBM-bound at this shape (each expert has only 128 rows).  achieved = algorithmic bytes per launch
 (E_loc*H*M weights + E_loc*R*M tokens + E_loc*R*H hidden out, x2 bytes) / its average duration,
 measured with HIP events on the launch stream inside the timed region.
@@ -62,6 +62,7 @@ class GemmTimer:
     def __init__(self):
         from tutel_amd import ops
         self.ops, self.real, self.events, self.on = ops, ops.expert_gemm, {True: [], False: []}, False
+        self.bytes, self.flops = {True: 0, False: 0}, {True: 0, False: 0}  # algorithmic, per launch (last seen)
         ops.expert_gemm = self
 
     def __call__(self, a, w, bias, w_kmajor, *args, **kw):
@@ -71,7 +72,12 @@ class GemmTimer:
         s.record()
         out = self.real(a, w, bias, w_kmajor, *args, **kw)
         e.record()
-        self.events[bool(w_kmajor)].append((s, e))
+        km = bool(w_kmajor)
+        self.events[km].append((s, e))
+        E_loc, N, K = (w.shape[0], w.shape[1], w.shape[2]) if km else (w.shape[0], w.shape[2], w.shape[1])
+        R = kw.get("R") or a.shape[1]
+        self.bytes[km] = (w.numel() + E_loc * R * K + E_loc * R * N) * w.element_size()
+        self.flops[km] = 2 * E_loc * R * N * K
         return out
 
     def avg_us(self, kmajor):
@@ -157,12 +163,11 @@ def main():
         elapsed = float(tt)
     assert torch.isfinite(y.float()).all()
 
-    C = layer.protected_shape[1] // world if layer.protected_shape is not None else k * T // E
-    R = world * C
+    C = k * ((T + E - 1) // E)
+    C = (C + overlap - 1) // overlap * overlap
     fc1_us, n1 = timer.avg_us(True)
     fc2_us, n2 = timer.avg_us(False)
-    fc1_bytes = (E_loc * H * M + E_loc * R * M + E_loc * R * H) * 2
-    fc2_bytes = (E_loc * H * M + E_loc * R * H + E_loc * R * M) * 2
+    fc1_bytes, fc2_bytes = timer.bytes[True], timer.bytes[False]  # per LAUNCH (one overlap chunk when N > 1)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1 and (T, M, H, E, k) == (4096, 2048, 2048, 64, 2):
@@ -182,13 +187,13 @@ def main():
                        "tokens_per_gpu": T, "model_dim": M, "hidden_size": H, "global_experts": E, "top_k": k,
                        "capacity": C, "parallelism": f"ep{world}" if world > 1 else "single-gpu",
                        "a2a_ffn_overlap_degree": overlap, "fp32_gate": bool(args.fp32_gate)},
-            "roofline": {"bound": "hbm", "kernel": "expert_gemm_kernel<bf16,k-major,relu> (fc1 grouped GEMM)",
+            "roofline": {"bound": "hbm", "kernel": "expert_gemm_glds_kernel<bf16,k-major,relu> (fc1 grouped GEMM, LDS-DMA)",
                          "achieved": round(fc1_bytes / fc1_us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(fc1_bytes / fc1_us * 1e-3 / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": fc1_bytes, "avg_launch_us": round(fc1_us, 2), "launches_timed": n1,
                          "fc2_gemm": {"avg_launch_us": round(fc2_us, 2), "achieved_GBs": round(fc2_bytes / max(fc2_us, 1e-9) * 1e-3, 1),
                                       "launches_timed": n2},
-                         "mfma_tflops_fc1": round(2 * E_loc * R * M * H / fc1_us * 1e-6, 1)},
+                         "mfma_tflops_fc1": round(timer.flops[True] / fc1_us * 1e-6, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, M, H, E, k)

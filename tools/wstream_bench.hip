@@ -7,6 +7,8 @@
 #include <vector>
 #include <stdlib.h>
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 extern __shared__ uint32_t dyn_lds[];
 #define TOUCH_LDS() do { if (threadIdx.x == 1023) dyn_lds[0] = 1; } while (0)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -104,6 +106,59 @@ template <int DEPTH, int AFRAC, bool LSTORE> __global__ __launch_bounds__(256, 2
   if ((a[0] ^ a[1] ^ a[2] ^ a[3] ^ a2[0] ^ a2[3]) == 0x12345678u) out[0] = 1;
 }
 
+// B3: the register-staged GEMM skeleton, component by component.  Per K-step: 8 global loads
+// (W NT+ROT, A from L2) for the NEXT tile -> [NREAD ds_read_b128 + NMFMA MFMAs on the current LDS
+// buffer] -> ds_write_b128 of the loaded tile into the other buffer -> barrier.
+template <int NREAD, int NMFMA> __global__ __launch_bounds__(256, 2) void k_skeleton(const uint16_t *w, const uint16_t *act, int E, int N, int K, uint32_t *out) {
+  const int ntn = N / 128, nb = gridDim.x;
+  int wi = blockIdx.x;
+  { int q = nb >> 3, xcd = wi & 7, pos = wi >> 3; wi = xcd * q + pos; }
+  const int nt = wi % ntn, e = wi / ntn;
+  const int tid = threadIdx.x, kc = tid & 7, rb = tid >> 3, lane = tid & 63;
+  const uint16_t *base = w + ((size_t)e * N + nt * 128) * K + kc * 8;
+  const uint16_t *abase = act + (size_t)e * 128 * K + kc * 8;
+  const int nk = K / 64;
+  const int rot = ((nt + 3 * e) * nk / ntn) % nk;
+  u32x4 *l4 = reinterpret_cast<u32x4 *>(dyn_lds);   // 2 buffers x 2048 x 16 B = 64 KB
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  u32x4 xr = {0, 0, 0, 0};
+  for (int kt0 = 0; kt0 < nk; ++kt0) {
+    const int buf = kt0 & 1;
+    int kt = kt0 + rot; kt = kt >= nk ? kt - nk : kt;
+    u32x4 v[4], va[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ld<true>(base + (size_t)(rb + 32 * i) * K + kt * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) va[i] = ld<false>(abase + (size_t)(rb + 32 * i) * K + kt * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    // "compute" on the current buffer
+    u32x4 fr[NREAD > 0 ? NREAD : 1];
+#pragma unroll
+    for (int i = 0; i < NREAD; ++i) fr[i] = l4[buf * 2048 + ((lane * 9 + i * 67) & 2047)];
+#pragma unroll
+    for (int i = 0; i < NMFMA; ++i) {
+      u32x4 a_ = NREAD > 0 ? fr[i % (NREAD > 0 ? NREAD : 1)] : xr, b_ = NREAD > 0 ? fr[(i + 1) % (NREAD > 0 ? NREAD : 1)] : xr;
+      acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a_), __builtin_bit_cast(bf16x8_t, b_), acc[i & 3], 0, 0, 0);
+    }
+    if (NMFMA == 0) {
+#pragma unroll
+      for (int i = 0; i < NREAD; ++i) acc4(xr, fr[i]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { l4[(buf ^ 1) * 2048 + i * 256 + tid] = v[i]; l4[(buf ^ 1) * 2048 + 1024 + i * 256 + tid] = va[i]; }
+    __syncthreads();
+  }
+  float z = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) z += acc[i][0] + acc[i][7];
+  if ((xr[0] ^ xr[1]) == 0x12345678u || z == 1234.5f) out[0] = 1;
+}
+
 // C: fc2-like.  W[e][k][n] n-major, N=2048.  block = (e, nt): 64 k-rows x 128 n (256 B) per step.
 template <bool NT, int DEPTH> __global__ __launch_bounds__(256, 2) void k_tile_n(const uint16_t *w, int E, int N, int K, uint32_t *out) {
   TOUCH_LDS();
@@ -186,6 +241,13 @@ int main(int argc, char **argv) {
   rep("W + A every 4th step        (BN=512)", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<4, 4, false>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
   rep("W only depth1 (no A)", timeit([&] { hipLaunchKernelGGL((k_tile_k<true, 1, true, true>), dim3(grid), dim3(256), LDSB, 0, w, E, N, K, out); }));
   if (LDSB >= 65536) {
+    rep("skeleton: loads+stores+barrier", timeit([&] { hipLaunchKernelGGL((k_skeleton<0, 0>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+    rep("skeleton + 16 ds_read_b128", timeit([&] { hipLaunchKernelGGL((k_skeleton<16, 0>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+    rep("skeleton + 16 MFMA (no LDS reads)", timeit([&] { hipLaunchKernelGGL((k_skeleton<0, 16>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+    rep("skeleton + 16 ds_read + 16 MFMA", timeit([&] { hipLaunchKernelGGL((k_skeleton<16, 16>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+    rep("skeleton + 8 ds_read + 16 MFMA", timeit([&] { hipLaunchKernelGGL((k_skeleton<8, 16>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+    rep("skeleton + 16 ds_read + 8 MFMA", timeit([&] { hipLaunchKernelGGL((k_skeleton<16, 8>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
+
     rep("W + A every step + ds_write_b128+barrier", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<1, 1, true>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
     rep("W + A/2 + ds_write_b128+barrier", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<2, 2, true>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));
     rep("W + A/4 + ds_write_b128+barrier", timeit([&] { hipLaunchKernelGGL((k_tile_k_a<4, 4, true>), dim3(grid), dim3(256), LDSB, 0, w, act, E, N, K, out); }));

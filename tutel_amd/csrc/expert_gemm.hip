@@ -201,13 +201,16 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
 #define GM_COMPUTE(BUF)                                                                \
   do {                                                                                 \
     const uint16_t *ca = sA + (BUF) * A_TILE, *cw = sW + (BUF) * W_TILE;               \
+    /* all 16 fragment reads of the K-tile are issued before the first MFMA: LDS latency is */ \
+    /* paid once per tile, not once per 16-deep slice (a skeleton with this shape streams  */ \
+    /* at 6 TB/s, tools/wstream_bench.hip; the 4-reads/4-MFMAs form stalled 4x per tile).  */ \
+    u32x4 fa[BK / 16][2], fw[BK / 16][2];                                              \
     _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk) {                           \
-      u32x4 fa[2], fw[2];                                                              \
       _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
-        fa[mi] = *reinterpret_cast<const u32x4 *>(ca + a_frag_off + mi * 32 * LDK + kk * 16); \
+        fa[kk][mi] = *reinterpret_cast<const u32x4 *>(ca + a_frag_off + mi * 32 * LDK + kk * 16); \
       _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                               \
         if (W_KMAJOR) {                                                                \
-          fw[ni] = *reinterpret_cast<const u32x4 *>(cw + wk_frag_off + ni * 32 * LDK + kk * 16); \
+          fw[kk][ni] = *reinterpret_cast<const u32x4 *>(cw + wk_frag_off + ni * 32 * LDK + kk * 16); \
         } else {                                                                       \
           const uint16_t *ptr = cw + wt_frag_off + kk * 16 * GM_LDN + ni * 32;         \
           s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                        \
@@ -216,13 +219,15 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
               (__attribute__((address_space(3))) s16x4_t *)(ptr + 4 * GM_LDN));        \
           u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi); \
           u32x4 f = {lo2[0], lo2[1], hi2[0], hi2[1]};                                  \
-          fw[ni] = f;                                                                  \
+          fw[kk][ni] = f;                                                              \
         }                                                                              \
       }                                                                                \
+    }                                                                                  \
+    __builtin_amdgcn_sched_barrier(0); /* hipcc otherwise re-interleaves reads and MFMAs */ \
+    _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk)                             \
       _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                 \
         _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                               \
-          acc[ni][mi] = Mma<T>::run(fw[ni], fa[mi], acc[ni][mi]);                      \
-    }                                                                                  \
+          acc[ni][mi] = Mma<T>::run(fw[kk][ni], fa[kk][mi], acc[ni][mi]);              \
   } while (0)
 
   static_assert(NBUF == 2, "the K loop below is written for the double-buffered LDS layout");
@@ -458,16 +463,17 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
     if (kt + 1 < nk) GL_ISSUE(kt + 1, buf ^ 1);  // block-uniform; next tile streams in during the MFMAs
 
     const uint16_t *ca = sA + buf * GL_STAGE, *cw = sW + buf * GL_STAGE;
-    // fragment reads run one 16-deep slice ahead of the MFMAs that consume them
-    u32x4 fa0[2], fw0[2], fa1[2], fw1[2];
-    GL_LOAD_FRAGS(fa0, fw0, 0);
-    GL_LOAD_FRAGS(fa1, fw1, 1);
-    GL_MMA(fa0, fw0);
-    GL_LOAD_FRAGS(fa0, fw0, 2);
-    GL_MMA(fa1, fw1);
-    GL_LOAD_FRAGS(fa1, fw1, 3);
-    GL_MMA(fa0, fw0);
-    GL_MMA(fa1, fw1);
+    // all fragment reads of the K-tile first, then the 16 MFMAs (LDS latency paid once per tile)
+    u32x4 fa[4][2], fw[4][2];
+    GL_LOAD_FRAGS(fa[0], fw[0], 0);
+    GL_LOAD_FRAGS(fa[1], fw[1], 1);
+    GL_LOAD_FRAGS(fa[2], fw[2], 2);
+    GL_LOAD_FRAGS(fa[3], fw[3], 3);
+    __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise re-interleaves reads and MFMAs
+    GL_MMA(fa[0], fw[0]);
+    GL_MMA(fa[1], fw[1]);
+    GL_MMA(fa[2], fw[2]);
+    GL_MMA(fa[3], fw[3]);
 
     __syncthreads();  // all waves done with stage `buf`; next tile's DMA has landed (vmcnt(0))
   }
@@ -587,6 +593,9 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   if (impl == -2) { const char *s = getenv("TUTEL_AMD_GEMM_IMPL"); impl = s ? atoi(s) : -1; }
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
+  static int pf2 = -1;
+  if (pf2 < 0) { const char *s = getenv("TUTEL_AMD_GEMM_PF2"); pf2 = s ? atoi(s) : 0; }
+  if (pf2) return launch_cfg<T, KM, ACT, 64, 2, 2, true, true, true>(a, grid, st);
   return launch_cfg<T, KM, ACT, 64, 2, 2, true, true, false>(a, grid, st);
 }
 

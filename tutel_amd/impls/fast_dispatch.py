@@ -123,7 +123,14 @@ class TutelMoeFastDispatcher:
 
     def _run(self, fn, data, with_gates):
         x = data if data.dtype == self.dtype else data.to(self.dtype)
-        out = fn.apply(self, x.contiguous(), self.gates2d if with_gates else None)
+        x = x if x.is_contiguous() else x.contiguous()
+        gates = self.gates2d if with_gates else None
+        if torch.is_grad_enabled() and (x.requires_grad or (gates is not None and gates.requires_grad)):
+            out = fn.apply(self, x, gates)
+        elif fn is _Encode:   # inference: straight to the kernel, no autograd node
+            out = ops.fast_encode(x, self.slot_map, gates, self.E * self.capacity)
+        else:
+            out = ops.fast_decode(x, self.idx2d, self.loc2d, gates, self.capacity)
         return out if out.dtype == self.original_dtype else out.to(self.original_dtype)
 
     def encode(self, data):

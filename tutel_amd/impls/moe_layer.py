@@ -315,7 +315,14 @@ class MOELayer(torch.nn.Module):
                 else:
                     y = y.view(self.num_global_experts, -1, y.size(2))
 
-        y = fast_decode(y.contiguous() if y.dtype == logits_dtype else y.to(logits_dtype), crit, self.is_postscore)
+        # decode: the kernel multiplies/accumulates in fp32 and rounds ONCE to its output dtype.  With an
+        # fp32 gate and low-precision experts the reference casts the buckets to fp32, combines in fp32 and
+        # rounds the result to the input dtype (moe_layer.py:359-361) -- the same single rounding -- so when
+        # the layer's output dtype equals the bucket dtype the fp32 round trip is skipped (bit-identical).
+        if y.dtype == logits_dtype or (logits_dtype == torch.float32 and y.dtype == original_dtype):
+            y = fast_decode(y if y.is_contiguous() else y.contiguous(), crit, self.is_postscore)
+        else:
+            y = fast_decode(y.to(logits_dtype), crit, self.is_postscore)
         y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
         self.l_aux = y.l_aux = l_aux
         return self.result_func(y) if self.result_func is not None else y
