@@ -119,10 +119,14 @@ int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *slot_map, con
  * fp32 temp, summed left to right, then cast (:132):
  *   out[t,:] = sum_j g_j[t] * buf[idx_j[t]*C + loc_j[t], :]   over j with loc < C && idx >= 0
  * products and sums in fp32 in the reference's order (no FMA contraction), one rounding.
- * gates NULL = all ones (is_postscore=False). Also serves GatingEncoder.backward (:31-38). */
+ * gates NULL = all ones (is_postscore=False). Also serves GatingEncoder.backward (:31-38).
+ * chunk_rows = 0: buf is the plain [E, C, M] bucket array (row e*C + l).
+ * chunk_rows = c > 0 (c divides C): buf is CHUNK-MAJOR [C/c, E, c, M] -- the layout in which the
+ *   overlapped all-to-all (overlap.py: capacity split into a2a_ffn_overlap_degree chunks) delivers
+ *   the expert outputs, so no torch.cat copy is needed: row ((l/c)*num_experts + e)*c + l%c. */
 int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *idx, const int32_t *loc,
                           const void *gates, int gate_dtype, int T, int M, int k, int capacity,
-                          void *out, tutel_stream_t stream);
+                          int num_experts, int chunk_rows, void *out, tutel_stream_t stream);
 
 /* Gate gradient (backward only).  Replaces the `backward_gate` kernel
  * (sparse.py:71-133 | custom_kernel.cpp:313-322):

@@ -67,8 +67,10 @@ def fast_encode(x, smap, gates, n_slots):
     return out.to(x.dtype)
 
 
-def fast_decode(buf, idx, loc, gates, capacity):
+def fast_decode(buf, idx, loc, gates, capacity, num_experts=0, chunk_rows=0):
     E = buf.shape[0] // max(capacity, 1)
+    if chunk_rows > 0:  # chunk-major [C/c, E, c, M] -> plain [E, C, M]
+        buf = buf.view(capacity // chunk_rows, E, chunk_rows, -1).permute(1, 0, 2, 3).reshape(E * capacity, -1)
     crit = _crit(idx, loc, gates, capacity, E)
     return O.fast_decode(buf.view(E, capacity, -1), crit, is_postscore=True)
 

@@ -212,3 +212,77 @@ def test_autocast_and_misc_paths(oracle):
     res = make_layer(M, H, E, k, 1.0, torch.float32, weights, result_func=lambda t: t * 2).eval()
     with torch.no_grad():
         assert torch.equal(res(x.cuda()), ref * 2)
+
+
+def test_decode_chunk_major_layout(oracle):
+    """fast_decode on the chunk-major bucket layout [C/c, E, c, M] of the overlapped all-to-all."""
+    from tutel_amd import ops
+    g = torch.Generator().manual_seed(8)
+    T, E, k, M = 700, 12, 2, 96
+    scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
+    crit, _ = oracle.extract_critical(scores, k, 1.0, alignment=4)
+    _, idx_o, loc_o, gates_o, C, _ = crit
+    for dtype in (torch.float32, torch.bfloat16):
+        y = torch.randn([E, C, M], generator=g).to(dtype)
+        want = oracle.fast_decode(y, crit)
+        for c in (C // 4, C // 2, C):
+            ycm = y.view(E, C // c, c, M).permute(1, 0, 2, 3).contiguous()
+            got = ops.fast_decode(ycm.view(E * C, M).cuda(), torch.stack(idx_o).cuda(), torch.stack(loc_o).cuda(),
+                                  torch.stack(gates_o).cuda(), C, num_experts=E, chunk_rows=c)
+            assert torch.equal(got.cpu().float(), want.float()), (dtype, c)
+
+
+@pytest.mark.parametrize("degree", [2, 4])
+@pytest.mark.parametrize("post", [True, False])
+def test_overlapped_path_equals_plain_path(oracle, monkeypatch, degree, post):
+    """a2a_ffn_overlap_degree > 1 must not change the result (what the reference asserts in
+    tests/test_tutel.py:161-176).  The copy-free overlapped routine (chunk-major buckets, comm
+    stream + events) is forced to run on one rank so its stream discipline is exercised here."""
+    from tutel_amd.impls import moe_layer as ml
+    T, M, H, E, k = 1024, 256, 256, 8, 2
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=torch.bfloat16, seed=6)
+    layer = make_layer(M, H, E, k, 1.0, torch.bfloat16, weights, is_postscore=post, gate={"fp32_gate": True}).eval()
+    with torch.no_grad():
+        plain = layer(x.cuda(), a2a_ffn_overlap_degree=1)
+        monkeypatch.setattr(ml, "_FORCE_OVERLAP", True)
+        for _ in range(3):  # repeated: allocator reuse across streams must stay safe
+            over = layer(x.cuda(), a2a_ffn_overlap_degree=degree)
+            torch.cuda.synchronize()
+            assert torch.equal(plain, over)
+    assert layer.protected_shape[1] % degree == 0
+
+
+def test_overlapped_path_through_rccl_single_rank():
+    """Same, with the exchange issued as a real RCCL all_to_all_single in a 1-rank process group
+    (fresh process: the group must not leak into other tests)."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import torch.distributed as dist
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from tutel import moe
+from tutel_amd.impls import moe_layer as ml, overlap
+torch.manual_seed(0)
+torch.set_default_dtype(torch.bfloat16)
+layer = moe.moe_layer(gate_type={"type": "top", "k": 2, "fp32_gate": True},
+                      experts={"type": "ffn", "num_experts_per_device": 8, "hidden_size_per_expert": 256,
+                               "activation_fn": lambda t: torch.nn.functional.relu(t)}, model_dim=256).cuda().eval()
+torch.set_default_dtype(torch.float32)
+x = torch.randn(1024, 256).bfloat16().cuda()
+with torch.no_grad():
+    plain = layer(x, a2a_ffn_overlap_degree=1)
+    ml._FORCE_OVERLAP = True
+    overlap._FORCE_RCCL = True
+    for _ in range(3):
+        over = layer(x, a2a_ffn_overlap_degree=2)
+        torch.cuda.synchronize()
+        assert torch.equal(plain, over)
+dist.destroy_process_group()
+print("RCCL_OVERLAP_OK")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert "RCCL_OVERLAP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

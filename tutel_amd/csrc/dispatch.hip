@@ -99,7 +99,8 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
                                                            const int32_t *__restrict__ loc,
                                                            const void *__restrict__ gates,
                                                            int gate_dtype, int Tn, int M, int k,
-                                                           int capacity, T *__restrict__ out) {
+                                                           int capacity, int num_experts,
+                                                           int chunk_rows, T *__restrict__ out) {
   constexpr int VN = Vec<T>::N;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
@@ -118,7 +119,10 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
       if (j < k) {
         int e = idx[(size_t)j * Tn + t], l = loc[(size_t)j * Tn + t];
         if (l < capacity && e >= 0 && l >= 0) {
-          rows[j] = buf + ((size_t)e * capacity + l) * M;
+          // bucket row: [E][C] (plain) or chunk-major [C/c][E][c] (overlapped all-to-all layout)
+          size_t r = (chunk_rows > 0) ? ((size_t)(l / chunk_rows) * num_experts + e) * chunk_rows + (l % chunk_rows)
+                                      : (size_t)e * capacity + l;
+          rows[j] = buf + r * M;
           g[j] = gates ? load_gate(gates, gate_dtype, (size_t)j * Tn + t) : 1.0f;
         }
       }
@@ -247,9 +251,10 @@ extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *sl
 
 template <typename T>
 static void launch_decode(const void *buf, const int32_t *idx, const int32_t *loc, const void *gates,
-                          int gate_dtype, int Tn, int M, int k, int capacity, void *out, hipStream_t st) {
+                          int gate_dtype, int Tn, int M, int k, int capacity, int num_experts, int chunk_rows,
+                          void *out, hipStream_t st) {
   int grid = dp_grid(Tn);
-#define DEC(KM) hipLaunchKernelGGL((decode_kernel<T, KM>), dim3(grid), dim3(DP_THREADS), 0, st, (const T *)buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, (T *)out)
+#define DEC(KM) hipLaunchKernelGGL((decode_kernel<T, KM>), dim3(grid), dim3(DP_THREADS), 0, st, (const T *)buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, num_experts, chunk_rows, (T *)out)
   if (k <= 1) DEC(1);
   else if (k <= 2) DEC(2);
   else if (k <= 4) DEC(4);
@@ -260,17 +265,20 @@ static void launch_decode(const void *buf, const int32_t *idx, const int32_t *lo
 
 extern "C" int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *idx,
                                      const int32_t *loc, const void *gates, int gate_dtype, int T,
-                                     int M, int k, int capacity, void *out, tutel_stream_t stream) {
+                                     int M, int k, int capacity, int num_experts, int chunk_rows,
+                                     void *out, tutel_stream_t stream) {
   TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_fast_decode: unsupported dtype %d", dtype);
   TUTEL_REQUIRE(gates == nullptr || dtype_ok(gate_dtype), "tutel_amd_fast_decode: unsupported gate dtype %d", gate_dtype);
   TUTEL_REQUIRE(T >= 0 && M >= 1 && k >= 1 && k <= 16 && capacity >= 0, "tutel_amd_fast_decode: bad sizes T=%d M=%d k=%d C=%d", T, M, k, capacity);
+  TUTEL_REQUIRE(chunk_rows >= 0 && (chunk_rows == 0 || (num_experts >= 1 && capacity % chunk_rows == 0)),
+                "tutel_amd_fast_decode: chunk_rows=%d must divide capacity=%d (num_experts=%d)", chunk_rows, capacity, num_experts);
   if (T == 0) return 0;
   TUTEL_REQUIRE(idx && loc && out && (buf || capacity == 0), "tutel_amd_fast_decode: null pointer");
   TUTEL_REQUIRE(((uintptr_t)buf % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_amd_fast_decode: buf/out must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TUTEL_F32) launch_decode<float>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, out, st);
-  else if (dtype == TUTEL_BF16) launch_decode<bf16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, out, st);
-  else launch_decode<f16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, out, st);
+  if (dtype == TUTEL_F32) launch_decode<float>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, out, st);
+  else if (dtype == TUTEL_BF16) launch_decode<bf16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, out, st);
+  else launch_decode<f16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, out, st);
   TUTEL_CHECK_LAUNCH("tutel_amd_fast_decode");
   return 0;
 }

@@ -26,9 +26,14 @@ from torch.nn import ModuleList
 
 from . import communicate as C
 from . import losses
-from .fast_dispatch import extract_critical, fast_decode, fast_encode, get_dispatch_count
-from .overlap import a2a_ffn_overlap_forward
+from .fast_dispatch import RoutingPlan, extract_critical, fast_decode, fast_encode, get_dispatch_count
+from .overlap import a2a_ffn_overlap_forward, a2a_ffn_overlap_fused
 from ..experts.ffn import FusedExpertsNetwork
+
+
+# test hook: run the overlapped expert-parallel path even with a single rank (exercises its
+# stream / event / allocator discipline on one GPU)
+_FORCE_OVERLAP = int(os.environ.get("TUTEL_AMD_FORCE_OVERLAP", "0")) != 0
 
 
 def _autocast_dtype(t):
@@ -276,15 +281,27 @@ class MOELayer(torch.nn.Module):
 
         self.megablocks_size = megablocks_size
         self.dispatch_count = get_dispatch_count(crit)
+        if adaptive_r is not None:
+            self.adaptive_degree = adaptive_r
+
+        # overlapped expert parallelism on the HIP path: one fused routine, no layout copies
+        if (degree > 1 and x.is_cuda and self.adaptive_degree != 0 and len(reserve_shape) == 1
+                and (self.world_size > 1 or _FORCE_OVERLAP) and self.num_global_experts >= self.world_size
+                and isinstance(self.experts, FusedExpertsNetwork) and isinstance(crit, RoutingPlan)
+                and crit[4] > 0 and crit[4] % degree == 0 and not C.SKIP_A2A and not self.use_2dh
+                and (x.dtype == logits_dtype or (logits_dtype == torch.float32 and x.dtype == original_dtype))
+                and self.experts.can_fuse(x, self)):
+            y = a2a_ffn_overlap_fused(self, x if x.is_contiguous() else x.contiguous(), crit, degree, self.is_postscore)
+            y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
+            self.l_aux = y.l_aux = l_aux
+            return self.result_func(y) if self.result_func is not None else y
+
         # encode: with is_postscore the bucket rows are verbatim copies, so the reference's
         # round trip through logits_dtype (moe_layer.py:327) is value-preserving and skipped.
         if self.is_postscore or x.dtype == logits_dtype:
             y = fast_encode(x.contiguous(), crit, self.is_postscore)
         else:
             y = fast_encode(x.to(logits_dtype), crit, self.is_postscore).to(x.dtype)
-
-        if adaptive_r is not None:
-            self.adaptive_degree = adaptive_r
 
         if self.adaptive_degree == 0:
             y = self.expert_local(y, reserve_shape)

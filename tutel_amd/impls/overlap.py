@@ -76,3 +76,83 @@ def a2a_ffn_overlap_forward(input, expert_fn, a2a_ffn_overlap_degree, use_2dh, g
     fin.record(comm)
     cur.wait_event(fin)
     return torch.cat(outs, dim=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# copy-free variant for the HIP expert path
+# ---------------------------------------------------------------------------------------------
+_FORCE_RCCL = False  # test hook: issue the collective even in a 1-rank group
+
+
+def _exchange(dst, src, group):
+    """equal-split all-to-all of dim-0 blocks (a plain copy when the group has one rank)."""
+    if C.get_world_size(group) > 1 or (_FORCE_RCCL and dist.is_initialized()):
+        dist.all_to_all_single(dst, src, group=group)
+    else:
+        dst.copy_(src)
+
+
+def a2a_ffn_overlap_fused(layer, x, crit, degree, is_postscore):
+    """Overlapped encode -> all-to-all -> expert FFN -> all-to-all -> decode with NO layout copies.
+
+    reference path (overlap.py:8-67 + communicate.py:606-622) per chunk: split view -> contiguous
+    copy -> a2a -> permute+contiguous -> FFN -> permute+contiguous -> a2a -> torch.cat.  Here:
+      * fast_encode writes the buckets CHUNK-MAJOR [degree, E, c, M] (only its slot map is
+        permuted), so chunk i is already the contiguous all-to-all message;
+      * the grouped GEMMs read the raw received buffer [W, E_loc, c, M] and write the raw send
+        buffer [W, E_loc, c, M_out] through their row addressing (rows_per_w = c);
+      * the return all-to-all lands in slice i of ONE [degree, E, c, M_out] buffer that
+        fast_decode addresses chunk-major.
+    Chunk i+1 is on the xGMI links (communication stream) while chunk i is in the GEMMs (caller's
+    stream); events hand the buffers over and every tensor that crosses streams is registered
+    with the caching allocator.  x [T, M] -> [T, M_out]."""
+    from .. import ops
+    group, experts = layer.group, layer.experts
+    W, E_loc = layer.world_size, layer.num_local_experts
+    E, Cap = crit[0], crit[4]
+    c = Cap // degree
+    T, M = x.shape
+    Mo = experts.output_dim
+    dev = x.device
+
+    smap_cm = crit.slot_map.view(E, degree, c).permute(1, 0, 2).contiguous().view(-1)
+    enc = ops.fast_encode(x, smap_cm, None if is_postscore else crit.gates2d, E * Cap).view(degree, E, c, M)
+
+    cur = torch.cuda.current_stream()
+    comm = _comm_stream(dev)
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    enc.record_stream(comm)
+
+    recv, recv_ev = [], []
+    with torch.cuda.stream(comm):
+        comm.wait_event(ready)
+        for i in range(degree):
+            buf = torch.empty([E, c, M], dtype=x.dtype, device=dev)
+            _exchange(buf, enc[i], group)
+            buf.record_stream(cur)
+            ev = torch.cuda.Event()
+            ev.record(comm)
+            recv.append(buf)
+            recv_ev.append(ev)
+
+    out_all = torch.empty([degree, E, c, Mo], dtype=x.dtype, device=dev)
+    out_all.record_stream(comm)
+    for i in range(degree):
+        cur.wait_event(recv_ev[i])
+        send = torch.empty([E, c, Mo], dtype=x.dtype, device=dev)
+        experts.forward_fused(recv[i], layer, a_layout=(c * M, E_loc * c * M, c, M), R=W * c,
+                              out=send, d_layout=(c * Mo, E_loc * c * Mo, c, Mo))
+        done = torch.cuda.Event()
+        done.record(cur)
+        send.record_stream(comm)
+        with torch.cuda.stream(comm):
+            comm.wait_event(done)
+            _exchange(out_all[i], send, group)
+    fin = torch.cuda.Event()
+    fin.record(comm)
+    cur.wait_event(fin)
+
+    layer.protected_shape = torch.Size([E_loc, W * Cap, Mo])
+    return ops.fast_decode(out_all.view(E * Cap, Mo), crit.idx2d, crit.loc2d,
+                           crit.gates2d if is_postscore else None, Cap, num_experts=E, chunk_rows=c)

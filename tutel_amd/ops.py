@@ -142,8 +142,9 @@ def fast_encode(x, smap, gates, n_slots):
     return out
 
 
-def fast_decode(buf, idx, loc, gates, capacity):
-    """buf [E*C, M] -> [T, M]; gates [k,T] or None (= ones)."""
+def fast_decode(buf, idx, loc, gates, capacity, num_experts=0, chunk_rows=0):
+    """buf [E*C, M] -> [T, M]; gates [k,T] or None (= ones).
+    chunk_rows > 0: buf is chunk-major [C/chunk_rows, E, chunk_rows, M] (overlapped all-to-all layout)."""
     _dev(buf, idx, loc, gates)
     assert buf.dim() == 2 and buf.is_contiguous()
     assert idx.dtype == torch.int32 and loc.dtype == torch.int32 and idx.is_contiguous() and loc.is_contiguous()
@@ -154,7 +155,7 @@ def fast_decode(buf, idx, loc, gates, capacity):
         assert gates.is_contiguous() and gates.shape == idx.shape
     _lib.check(_lib.lib().tutel_amd_fast_decode(_ptr(buf), _code(buf), _ptr(idx), _ptr(loc), _ptr(gates),
                                                 _code(gates) if gates is not None else 0, T, M, k,
-                                                int(capacity), _ptr(out), _stream()),
+                                                int(capacity), int(num_experts), int(chunk_rows), _ptr(out), _stream()),
                "tutel_amd_fast_decode")
     return out
 
