@@ -37,8 +37,10 @@ extern "C" {
 
 typedef void *tutel_stream_t; /* hipStream_t */
 
-/* element types of token / weight / score arrays */
-enum { TUTEL_F32 = 0, TUTEL_F16 = 1, TUTEL_BF16 = 2 };
+/* element types of token / weight / score arrays; TUTEL_F64 is accepted by tutel_amd_gate_topk only
+ * (scores / gates of an fp64 gate -- the dispatch itself runs in fp32 in the reference as well,
+ * fast_dispatch.py:94-96) */
+enum { TUTEL_F32 = 0, TUTEL_F16 = 1, TUTEL_BF16 = 2, TUTEL_F64 = 3 };
 /* fused activation of the expert GEMM epilogue (experts/ffn.py:19-24,117) */
 enum { TUTEL_ACT_NONE = 0, TUTEL_ACT_RELU = 1, TUTEL_ACT_GELU = 2, TUTEL_ACT_SILU = 3 };
 

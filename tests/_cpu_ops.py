@@ -85,3 +85,4 @@ def install(monkeypatch):
                  "fast_decode", "gate_grad"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "supported_dtype", lambda dt: dt in (torch.float32, torch.float16, torch.bfloat16))
+    monkeypatch.setattr(ops, "routing_dtype", lambda dt: dt in (torch.float32, torch.float16, torch.bfloat16, torch.float64))

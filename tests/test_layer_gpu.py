@@ -332,3 +332,28 @@ def test_helloworld_training_losses_match_reference():
         assert len(got) == len(want)
         assert [round(g, 3) for g in got] == [round(w, 3) for w in want] or \
             all(abs(g - w) <= 2e-3 for g, w in zip(got, want)), (got, want)
+
+
+def test_forward_is_hip_graph_capturable(oracle):
+    """With capacity_factor > 0 the forward has no host synchronisation, so the whole layer (HIP
+    kernels launched through the C ABI on the capturing stream + the hipBLASLt gate GEMM) can be
+    captured into a HIP graph and replayed: zero host cost per step."""
+    T, M, H, E, k = 2048, 512, 512, 16, 2
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=torch.bfloat16, seed=9)
+    layer = make_layer(M, H, E, k, 1.0, torch.bfloat16, weights).eval()
+    xs = x.cuda()
+    with torch.no_grad():
+        want = layer(xs).clone()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                layer(xs)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out = layer(xs)
+            xs.copy_(x.cuda())  # same input buffer, refreshed contents
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+    assert torch.equal(out, want)

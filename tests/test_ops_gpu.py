@@ -14,6 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+ROUTING_DTYPES = DTYPES + [torch.float64]
 
 
 def _ops():
@@ -38,7 +39,7 @@ def test_probe_tr16_permutation():
             assert int(out[l, j]) == g * 64 + (4 * j + i // 4) * 4 + (i % 4), (l, j, out[l].tolist())
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", ROUTING_DTYPES)
 @pytest.mark.parametrize("T,E,k", [(512, 16, 2), (4096, 64, 2), (300, 7, 3), (1000, 130, 4), (64, 64, 1), (5000, 256, 8),
                                    (500, 32, 6), (900, 128, 8), (9000, 64, 2), (77, 2, 2), (130, 5, 5)])
 def test_gate_topk_and_location_vs_oracle(oracle, dtype, T, E, k):
@@ -48,14 +49,14 @@ def test_gate_topk_and_location_vs_oracle(oracle, dtype, T, E, k):
     (E_, idx_o, loc_o, gates_o, cap_o, cnt_o), l_aux_o = oracle.extract_critical(scores, k, 1.0)
     idx, gates, ws, _ = ops.gate_topk(scores.cuda(), k, apply_softmax=False, normalize_gate=True)
     assert torch.equal(idx.cpu(), torch.stack(idx_o)), "top-k expert indices must be bit-exact"
-    assert torch.equal(gates.cpu().view(torch.int16 if dtype != torch.float32 else torch.int32),
-                       torch.stack(gates_o).view(torch.int16 if dtype != torch.float32 else torch.int32)), \
+    bits = {torch.float32: torch.int32, torch.float64: torch.int64}.get(dtype, torch.int16)
+    assert torch.equal(gates.cpu().view(bits), torch.stack(gates_o).view(bits)), \
         "gates must follow the reference's per-op rounding exactly"
     loc, cnt, stats, l_aux, smap = ops.compute_location(idx, E, ws=ws, capacity=cap_o, want_l_aux=True)
     assert torch.equal(loc.cpu(), torch.stack(loc_o)), "locations must be bit-exact"
     assert torch.equal(cnt.cpu(), cnt_o)
     assert int(stats.cpu()[0]) == int(cnt_o.max())
-    assert abs(float(l_aux.cpu()[0]) - float(l_aux_o.float())) <= 1e-2 * (1 if dtype != torch.float32 else 1e-3)
+    assert abs(float(l_aux.cpu()[0]) - float(l_aux_o.float())) <= 1e-2 * (1 if dtype in (torch.bfloat16, torch.float16) else 1e-3)
     # slot map = inverse of (idx, loc) on kept slots, -1 elsewhere
     want = torch.full([E * cap_o], -1, dtype=torch.int32)
     for j in range(k):
@@ -264,3 +265,50 @@ def test_headline_shape_properties(oracle):
     assert torch.equal(dec.float(), (x.float() * n_kept.unsqueeze(1)).bfloat16().float())
     # checksum of checksums: column sums of the buckets = sum_t n_kept(t) * x[t]
     torch.testing.assert_close(enc.double().sum(0), (x.double() * n_kept.double().unsqueeze(1)).sum(0), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("T,E,k,cf", [(1, 1, 1, 1.0), (5, 1, 1, 1.0), (1024, 1, 1, 1.0), (1000, 2, 2, 1.0), (63, 64, 2, 1.0),
+                                      (65, 3, 3, 0.3), (4096, 64, 2, 0.05), (257, 128, 16, 4.0)])
+def test_edge_shapes_routing_encode_decode(oracle, T, E, k, cf):
+    """Ragged / degenerate problems: one expert (the reference's golden-loss cases use E in {1,2}),
+    fewer tokens than experts, k == E, almost every token dropped (capacity 2), huge capacity."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(T * 7 + E)
+    scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
+    crit, l_o = oracle.extract_critical(scores, k, cf)
+    _, idx_o, loc_o, gates_o, C, cnt_o = crit
+    kk = len(idx_o)
+    idx, gates, ws, _ = ops.gate_topk(scores.cuda(), k)
+    assert torch.equal(idx.cpu(), torch.stack(idx_o)) and torch.equal(gates.cpu(), torch.stack(gates_o))
+    loc, cnt, stats, l_aux, smap = ops.compute_location(idx, E, ws=ws, capacity=C, want_l_aux=True)
+    assert torch.equal(loc.cpu(), torch.stack(loc_o)) and torch.equal(cnt.cpu(), cnt_o)
+    assert abs(float(l_aux) - float(l_o)) <= 1e-5 * max(1.0, abs(float(l_o)))
+    if C == 0:
+        return
+    x = torch.randn([T, 72], generator=g)
+    enc = ops.fast_encode(x.cuda(), smap, None, E * C)
+    assert torch.equal(enc.cpu().view(E, C, 72), oracle.fast_encode(x, crit))
+    dec = ops.fast_decode(enc, idx, loc, gates, C)
+    assert torch.equal(dec.cpu(), oracle.fast_decode(oracle.fast_encode(x, crit), crit))
+    assert kk == min(k, E)
+
+
+def test_masked_tokens_through_dispatcher(oracle):
+    """idx < 0 = token masked out by the caller (fast_dispatcher.update contract, fast_dispatch.py:25,59):
+    never dispatched, combines to zero."""
+    from tutel import moe
+    g = torch.Generator().manual_seed(12)
+    T, E, M, C = 300, 6, 40, 64
+    idx = torch.randint(0, E, [T], generator=g, dtype=torch.int32)
+    idx[::5] = -1
+    loc, _ = oracle.compute_locations([idx], E)
+    gate = torch.rand([T], generator=g)
+    x = torch.randn([T, M], generator=g)
+    d = moe.fast_dispatcher(E, C, M, torch.float32)
+    d.update([idx.cuda()], [loc[0].cuda()], [gate.cuda()], capacity=C)
+    enc = d.encode(x.cuda())
+    crit = (E, [idx], loc, [gate], C, None)
+    assert torch.equal(enc.cpu().view(E, C, M), oracle.fast_encode(x, crit))
+    dec = d.decode(enc)
+    want = oracle.fast_decode(oracle.fast_encode(x, crit), crit)
+    assert torch.equal(dec.cpu(), want) and bool((dec.cpu()[::5] == 0).all())

@@ -45,19 +45,30 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
 }
 
 template <typename T> struct Elem;
+// fp64: routing only (scores / gates of an fp64 gate); compute type double
+template <> struct Elem<double> {
+  using ct = double;
+  static constexpr int dtype = 3;
+  __device__ static __forceinline__ double to_f32(double x) { return x; }
+  __device__ static __forceinline__ double from_f32(double x) { return x; }
+  __device__ static __forceinline__ double eps() { return 2.220446049250313e-16; }
+};
 template <> struct Elem<float> {
+  using ct = float;
   static constexpr int dtype = TUTEL_F32;
   __device__ static __forceinline__ float to_f32(float x) { return x; }
   __device__ static __forceinline__ float from_f32(float x) { return x; }
   __device__ static __forceinline__ float eps() { return 1.1920928955078125e-07f; }
 };
 template <> struct Elem<bf16_t> {
+  using ct = float;
   static constexpr int dtype = TUTEL_BF16;
   __device__ static __forceinline__ float to_f32(bf16_t x) { return bf16_bits_to_f32(x.v); }
   __device__ static __forceinline__ bf16_t from_f32(float x) { return bf16_t{f32_to_bf16_bits(x)}; }
   __device__ static __forceinline__ float eps() { return 0.0078125f; }
 };
 template <> struct Elem<f16_t> {
+  using ct = float;
   static constexpr int dtype = TUTEL_F16;
   __device__ static __forceinline__ float to_f32(f16_t x) { return (float)x.v; }
   __device__ static __forceinline__ f16_t from_f32(float x) { return f16_t{(_Float16)x}; }
@@ -65,9 +76,13 @@ template <> struct Elem<f16_t> {
 };
 
 // round x to T and back (what a `T`-typed torch op does to an fp32 intermediate)
-template <typename T> __device__ __forceinline__ float round_to(float x) {
+template <typename T> __device__ __forceinline__ typename Elem<T>::ct round_to(typename Elem<T>::ct x) {
   return Elem<T>::to_f32(Elem<T>::from_f32(x));
 }
+__device__ __forceinline__ float ct_exp(float x) { return expf(x); }
+__device__ __forceinline__ double ct_exp(double x) { return exp(x); }
+__device__ __forceinline__ float ct_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double ct_max(double a, double b) { return fmax(a, b); }
 
 static inline int dtype_size(int dtype) { return dtype == TUTEL_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dtype) {

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
     int clear_n) {
+  using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);             // [k][E]
   float *s_col = reinterpret_cast<float *>(smem) + (size_t)k * E;  // [GT_WAVES][E]
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
   // every cross-lane step below is issued for all of them before the next step, so the
   // ~36 dependent ds_bpermute round trips per token overlap instead of adding up.
   for (int tb = t0 + wid; tb < t1; tb += GT_WAVES * GT_BATCH) {
-    float v[GT_BATCH][EPL];
+    CT v[GT_BATCH][EPL];
     bool live[GT_BATCH];
     int tt[GT_BATCH];
 #pragma unroll
@@ -93,24 +94,24 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
       }
     }
     if (apply_softmax) {
-      float m[GT_BATCH], s[GT_BATCH];
+      CT m[GT_BATCH], s[GT_BATCH];
 #pragma unroll
       for (int u = 0; u < GT_BATCH; ++u) {
         m[u] = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) m[u] = fmaxf(m[u], v[u][j]);
+        for (int j = 0; j < EPL; ++j) m[u] = ct_max(m[u], v[u][j]);
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-        for (int u = 0; u < GT_BATCH; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], o, 64));
+        for (int u = 0; u < GT_BATCH; ++u) m[u] = ct_max(m[u], __shfl_xor(m[u], o, 64));
 #pragma unroll
       for (int u = 0; u < GT_BATCH; ++u) {
         s[u] = 0.f;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
           int e = lane + 64 * j;
-          v[u][j] = (e < E) ? expf(v[u][j] - m[u]) : 0.f;
+          v[u][j] = (e < E) ? ct_exp(v[u][j] - m[u]) : 0.f;
           s[u] += v[u][j];
         }
       }
@@ -137,18 +138,18 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
         int e = lane + 64 * j;
-        if (e < E && live[u]) colacc[j] += v[u][j];  // token order u = 0..3: deterministic
+        if (e < E && live[u]) colacc[j] += (float)v[u][j];  // token order u = 0..3: deterministic
         if (v[u][j] != v[u][j]) v[u][j] = -INFINITY;  // NaN sorts last
       }
 
     // k rounds of wave arg-max, order: score desc, expert index asc.
     uint32_t taken[GT_BATCH];
-    float myg[GT_BATCH];
+    CT myg[GT_BATCH];
     int myidx[GT_BATCH];
 #pragma unroll
-    for (int u = 0; u < GT_BATCH; ++u) { taken[u] = 0; myg[u] = 0.f; myidx[u] = -1; }
+    for (int u = 0; u < GT_BATCH; ++u) { taken[u] = 0; myg[u] = 0; myidx[u] = -1; }
     for (int c = 0; c < k; ++c) {
-      float bv[GT_BATCH];
+      CT bv[GT_BATCH];
       int be[GT_BATCH];
 #pragma unroll
       for (int u = 0; u < GT_BATCH; ++u) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
       for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
         for (int u = 0; u < GT_BATCH; ++u) {
-          float ov = __shfl_xor(bv[u], o, 64);
+          CT ov = __shfl_xor(bv[u], o, 64);
           int oe = __shfl_xor(be[u], o, 64);
           if (ov > bv[u] || (ov == bv[u] && oe < be[u])) { bv[u] = ov; be[u] = oe; }
         }
@@ -178,12 +179,12 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
     // gates: raw score, optionally normalised by clamp(((0+g0)+g1)+..., eps) in dtype T.
 #pragma unroll
     for (int u = 0; u < GT_BATCH; ++u) {
-      float denom = __shfl(myg[u], 0, 64);
+      CT denom = __shfl(myg[u], 0, 64);
       for (int c = 1; c < k; ++c) denom = round_to<T>(denom + __shfl(myg[u], c, 64));
       if (lane < k && live[u]) {
-        float g = myg[u];
+        CT g = myg[u];
         if (normalize && k > 1) {
-          float d = fmaxf(denom, Elem<T>::eps());
+          CT d = ct_max(denom, (CT)Elem<T>::eps());
           if (denom != denom) d = denom;  // torch.clamp keeps NaN
           g = g / d;
         }
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
     int clear_n) {
+  using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ES = GQ_LPT * EPQ + 1;                                    // padded row of the score tile
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);                // [k][E]
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
   for (int ts = t0; ts < t1; ts += 64) {
     const int t = ts + tl;
     const bool live = t < t1;
-    float v[EPQ];
+    CT v[EPQ];
     {
       const T *row = in + (size_t)min(t, Tn - 1) * E + q * EPQ;
 #pragma unroll
@@ -259,16 +261,16 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       }
     }
     if (apply_softmax) {
-      float m = -INFINITY;
+      CT m = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < EPQ; ++j) m = fmaxf(m, v[j]);
+      for (int j = 0; j < EPQ; ++j) m = ct_max(m, v[j]);
 #pragma unroll
-      for (int o = 1; o < GQ_LPT; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      float s = 0.f;
+      for (int o = 1; o < GQ_LPT; o <<= 1) m = ct_max(m, __shfl_xor(m, o, 64));
+      CT s = 0;
 #pragma unroll
       for (int j = 0; j < EPQ; ++j) {
         int e = q * EPQ + j;
-        v[j] = (e < E) ? expf(v[j] - m) : 0.f;
+        v[j] = (e < E) ? ct_exp(v[j] - m) : CT(0);
         s += v[j];
       }
 #pragma unroll
@@ -289,14 +291,14 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
 #pragma unroll
     for (int j = 0; j < EPQ; ++j) {
       int e = q * EPQ + j;
-      if (e < E) s_sc[tl * ES + e] = live ? v[j] : 0.f;
+      if (e < E) s_sc[tl * ES + e] = live ? (float)v[j] : 0.f;
       if (v[j] != v[j]) v[j] = -INFINITY;  // NaN sorts last
     }
 
     uint32_t taken = 0;
-    float myg = 0.f, denom = 0.f;
+    CT myg = 0, denom = 0;
     for (int c = 0; c < k; ++c) {
-      float bv = -INFINITY;
+      CT bv = -INFINITY;
       int be = 0x7fffffff;
 #pragma unroll
       for (int j = 0; j < EPQ; ++j) {
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       }
 #pragma unroll
       for (int o = 1; o < GQ_LPT; o <<= 1) {
-        float ov = __shfl_xor(bv, o, 64);
+        CT ov = __shfl_xor(bv, o, 64);
         int oe = __shfl_xor(be, o, 64);
         if (ov > bv || (ov == bv && oe < be)) { bv = ov; be = oe; }
       }
@@ -319,9 +321,9 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       }
     }
     if (q < k && live) {
-      float g = myg;
+      CT g = myg;
       if (normalize && k > 1) {
-        float d = fmaxf(denom, Elem<T>::eps());
+        CT d = ct_max(denom, (CT)Elem<T>::eps());
         if (denom != denom) d = denom;  // torch.clamp keeps NaN
         g = g / d;
       }
@@ -595,7 +597,7 @@ extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax,
                                    int k, int normalize_gate, void *scores_out, int32_t *idx,
                                    void *gates, void *ws, size_t ws_bytes, int32_t *clear_map,
                                    int clear_n, tutel_stream_t stream) {
-  TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_gate_topk: unsupported dtype %d", dtype);
+  TUTEL_REQUIRE(dtype_ok(dtype) || dtype == TUTEL_F64, "tutel_amd_gate_topk: unsupported dtype %d", dtype);
   TUTEL_REQUIRE(T >= 0 && E >= 1 && E <= RT_MAX_E, "tutel_amd_gate_topk: need 1 <= E <= %d (got %d)", RT_MAX_E, E);
   TUTEL_REQUIRE(k >= 1 && k <= RT_MAX_K && k <= E, "tutel_amd_gate_topk: need 1 <= k <= min(E,%d) (got k=%d, E=%d)", RT_MAX_K, k, E);
   TUTEL_REQUIRE((size_t)k * E <= 8192, "tutel_amd_gate_topk: k*E = %d exceeds 8192", k * E);
@@ -605,6 +607,7 @@ extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax,
   TUTEL_REQUIRE(clear_n >= 0 && (clear_map != nullptr || clear_n == 0), "tutel_amd_gate_topk: bad clear_map");
   if (clear_n == 0) clear_map = nullptr;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == TUTEL_F64) return launch_gate_topk<double>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   return launch_gate_topk<f16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);

@@ -153,7 +153,7 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
     src = _logits if _logits is not None else scores
     T, E = int(src.size(0)), int(src.size(1))
     k_req, k = top_k, min(top_k, E)
-    work = src if ops.supported_dtype(src.dtype) else src.float()
+    work = src if ops.routing_dtype(src.dtype) else src.float()
     needs_grad = torch.is_grad_enabled() and src.requires_grad
 
     fused_loss = loss_fn is losses.gshard_loss and not needs_grad
@@ -209,9 +209,9 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
 
     # gates / loss: kernel values on the inference path; differentiable torch forms when training
     gate_list = None
-    if needs_grad or not ops.supported_dtype(src.dtype):
-        # training (autograd through the gates) or fp64 scores (the kernels select on the fp32
-        # image; the gate VALUES must be computed in the scores' own precision, as the reference
+    if needs_grad or not ops.routing_dtype(src.dtype):
+        # training (autograd through the gates), or an exotic scores dtype routed on its fp32 image
+        # (then the gate VALUES are still computed in the scores' own precision, as the reference
         # does before its fp32 dispatch cast, fast_dispatch.py:151,173-175,105)
         sc = scores if scores is not None else torch.softmax(_logits, dim=1)
         if not needs_grad:

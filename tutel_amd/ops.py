@@ -45,6 +45,11 @@ def supported_dtype(dtype):
     return dtype in _DT
 
 
+def routing_dtype(dtype):
+    """dtypes the top-k kernel takes natively (fp64 scores are compared and normalised in fp64)."""
+    return dtype in _DT or dtype == torch.float64
+
+
 # ---------------------------------------------------------------------------------------------
 # routing
 # ---------------------------------------------------------------------------------------------
@@ -67,7 +72,8 @@ def gate_topk(inp, k, apply_softmax=False, normalize_gate=True, want_scores=Fals
     if ws is None:
         ws = routing_workspace(T, E, k, inp.device)
     L = _lib.lib()
-    _lib.check(L.tutel_amd_gate_topk(_ptr(inp), _code(inp), int(bool(apply_softmax)), T, E, k,
+    code = _lib.F64 if inp.dtype == torch.float64 else _code(inp)
+    _lib.check(L.tutel_amd_gate_topk(_ptr(inp), code, int(bool(apply_softmax)), T, E, k,
                                      int(bool(normalize_gate)), _ptr(scores), _ptr(idx), _ptr(gates),
                                      _ptr(ws), ws.numel(), _ptr(clear), clear.numel() if clear is not None else 0,
                                      _stream()), "tutel_amd_gate_topk")
