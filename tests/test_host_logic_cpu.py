@@ -233,3 +233,62 @@ def test_expert_parallel_world2_gloo(degree, use_2dh):
         p.join(timeout=60)
     for rank, ok, info in res:
         assert ok, f"rank {rank}: {info}"
+
+
+def _sharded_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import _cpu_ops as shim
+        from oracle import moe_oracle as O
+        from tutel_amd import ops
+        for name in ("gate_topk", "compute_location", "slot_map", "cumsum_sub_one", "fast_encode", "fast_decode", "gate_grad"):
+            setattr(ops, name, getattr(shim, name))
+        ops.routing_dtype = lambda dt: True
+        from tutel import system, net
+        system.init_data_model_parallel(backend="gloo")
+        T, M, H, k = 128, 32, 16, 1
+        outs = {}
+        for ptype in ("data", "model", "adaptive:0"):
+            layer = _make_layer(M, H, -world, k, 1.0, parallel_type=ptype, seeds=(1, rank + 1, 1)).eval()
+            assert layer.num_global_experts == 1 and layer.sharded_count == world and layer.num_local_experts == 1
+            assert layer.experts.batched_fc1_w.shape == (1, H // world, M)
+            torch.manual_seed(0)
+            x = torch.randn(T, M)
+            with torch.no_grad():
+                outs[ptype] = layer(x)
+            # full expert = shards concatenated along the hidden dim, bias2 along the output dim
+            w1 = net.simple_all_gather(layer.experts.batched_fc1_w.data[0]).view(1, H, M)
+            w2 = net.simple_all_gather(layer.experts.batched_fc2_w.data[0]).view(1, H, M)
+            b1 = net.simple_all_gather(layer.experts.batched_fc1_bias.data[0]).view(1, H)
+            b2 = net.simple_all_gather(layer.experts.batched_fc2_bias.data[0]).view(1, -1)[:, :M]
+            wg = layer.gates[0].wg.weight.data
+            want, _, _, _ = O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)
+            ok = torch.allclose(outs[ptype], want, rtol=1e-5, atol=1e-5)
+            if not ok:
+                q.put((rank, False, f"{ptype}: max diff {(outs[ptype] - want).abs().max()}"))
+                return
+        ok = torch.allclose(outs["data"], outs["model"], rtol=1e-5, atol=1e-6)
+        q.put((rank, bool(ok), "data vs model"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+def test_sharded_expert_modes_world2_gloo():
+    """num_local_experts = -2: one expert's hidden dim sliced over 2 ranks; parallel_type data,
+    model and adaptive:0 must agree with each other (reference tests/test_tutel.py:154-159) and
+    with the un-sharded oracle."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, info in res:
+        assert ok, f"rank {rank}: {info}"
