@@ -60,6 +60,22 @@ template <int ACT> __device__ __forceinline__ float activate(float v) {
   return v;
 }
 
+// The lane's 8 bias 4-vectors (2 N-subtiles x 4 register groups) are fetched BEFORE the K loop,
+// branch-free with clamped addresses: in the epilogue the same loads sat inside divergent
+// `continue` branches and hipcc serialised them -- 16 x (global_load_dwordx2 ; s_waitcnt vmcnt(0))
+// per block, i.e. 16 exposed memory round trips shared by every variant of the kernel.
+#define GM_PRELOAD_BIAS()                                                                         \
+  uint2 bias_r[2][4];                                                                             \
+  {                                                                                               \
+    const uint16_t *be_ = p.bias ? reinterpret_cast<const uint16_t *>(p.bias) + (size_t)e * p.bias_stride_e : nullptr; \
+    _Pragma("unroll") for (int ni_ = 0; ni_ < 2; ++ni_)                                           \
+      _Pragma("unroll") for (int rg_ = 0; rg_ < 4; ++rg_) {                                       \
+        int n_ = n0 + wn * 64 + ni_ * 32 + rg_ * 8 + kg * 4;                                      \
+        n_ = n_ < p.N ? n_ : p.N - 4;                                                             \
+        bias_r[ni_][rg_] = be_ ? *reinterpret_cast<const uint2 *>(be_ + n_) : make_uint2(0u, 0u); \
+      }                                                                                           \
+  }
+
 struct GemmArgs {
   const void *A; long long a_stride_e, a_stride_w; int a_rpw, lda;
   const void *W; long long w_stride_e; int ldw;
@@ -163,6 +179,7 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
 
   // fragment read offsets (elements), constant over the K loop
   const int l31 = lane & 31, kg = lane >> 5;
+  GM_PRELOAD_BIAS();
   const int a_frag_off = (wm * 64 + l31) * LDK + kg * 8;                // + mi*32*LDK + kk*16
   const int wk_frag_off = (wn * 64 + l31) * LDK + kg * 8;               // k-major W
   // n-major W via ds_read_b64_tr_b16: 16-lane group g reads the 4(k) x 16(n) block at
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][rg * 4 + r];
         if (be) {
-          uint2 bb = *reinterpret_cast<const uint2 *>(be + n);
+          const uint2 bb = bias_r[ni][rg];
           uint16_t b4[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -404,6 +421,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
 
   // ---- fragment read offsets (elements)
   const int l31 = lane & 31, kg = lane >> 5;
+  GM_PRELOAD_BIAS();
   const int sw = (l31 >> 1) & 7;  // (row >> 1) & 7 with row = 32*x + l31
   int frag_k[4];                   // chunk position of (kk, kg) for this lane's row, in elements
 #pragma unroll
@@ -499,7 +517,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][rg * 4 + r];
         if (be) {
-          uint2 bb = *reinterpret_cast<const uint2 *>(be + n);
+          const uint2 bb = bias_r[ni][rg];
           uint16_t b4[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -584,7 +602,7 @@ static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
 // n-major 142 -> 130 us when the weights really come from HBM, i.e. fc1/fc2 alternating as in the
 // layer -- a warm Infinity Cache hides this, so A/B runs must alternate the two weight sets).  What did NOT pay (kept out of the tree, see git history): BK=128, single
 // LDS buffer at 3 blocks/CU, prefetch distance 2 (two register sets), a 128x256 8-wave 3-stage
-// LDS-DMA ring.  Ablation: compute alone 69 us, loads+staging alone 80-115 us -- the remaining
+// LDS-DMA ring, a single-stage LDS-DMA variant at 4 blocks/CU.  Ablation: compute alone 69 us, loads+staging alone 80-115 us -- the remaining
 // loss is phase serialisation inside a block, not DRAM (pure loads of the same pattern: 77-90 us).
 // TUTEL_AMD_GEMM_IMPL=0|1 forces register-staged | LDS-DMA for A/B runs.
 template <typename T, bool KM, int ACT>
@@ -593,9 +611,6 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   if (impl == -2) { const char *s = getenv("TUTEL_AMD_GEMM_IMPL"); impl = s ? atoi(s) : -1; }
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
-  static int pf2 = -1;
-  if (pf2 < 0) { const char *s = getenv("TUTEL_AMD_GEMM_PF2"); pf2 = s ? atoi(s) : 0; }
-  if (pf2) return launch_cfg<T, KM, ACT, 64, 2, 2, true, true, true>(a, grid, st);
   return launch_cfg<T, KM, ACT, 64, 2, 2, true, true, false>(a, grid, st);
 }
 
