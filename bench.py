@@ -64,6 +64,8 @@ class GemmTimer:
         self.ops, self.real, self.events, self.on = ops, ops.expert_gemm, {True: [], False: []}, False
         self.bytes, self.flops = {True: 0, False: 0}, {True: 0, False: 0}  # algorithmic, per launch (last seen)
         ops.expert_gemm = self
+        self.real_gather = ops.expert_gemm_gather
+        ops.expert_gemm_gather = self.gather
 
     def __call__(self, a, w, bias, w_kmajor, *args, **kw):
         if not self.on:
@@ -76,6 +78,22 @@ class GemmTimer:
         self.events[km].append((s, e))
         E_loc, N, K = (w.shape[0], w.shape[1], w.shape[2]) if km else (w.shape[0], w.shape[2], w.shape[1])
         R = kw.get("R") or a.shape[1]
+        self.bytes[km] = (w.numel() + E_loc * R * K + E_loc * R * N) * w.element_size()
+        self.flops[km] = 2 * E_loc * R * N * K
+        return out
+
+    def gather(self, x, smap, w, bias, w_kmajor, act, R, **kw):
+        """fc1 with fast_encode fused (single rank): same kernel, rows gathered from the tokens.  Algorithmic
+        bytes are counted exactly as for the plain fc1 launch (weights + E*R token rows + hidden out)."""
+        if not self.on:
+            return self.real_gather(x, smap, w, bias, w_kmajor, act, R, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = self.real_gather(x, smap, w, bias, w_kmajor, act, R, **kw)
+        e.record()
+        km = bool(w_kmajor)
+        self.events[km].append((s, e))
+        E_loc, N, K = (w.shape[0], w.shape[1], w.shape[2]) if km else (w.shape[0], w.shape[2], w.shape[1])
         self.bytes[km] = (w.numel() + E_loc * R * K + E_loc * R * N) * w.element_size()
         self.flops[km] = 2 * E_loc * R * N * K
         return out

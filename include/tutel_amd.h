@@ -167,6 +167,19 @@ int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t a_stride_w,
                           int K, int dtype, int act, const int32_t *row_counts, int row_align,
                           tutel_stream_t stream);
 
+/* fast_encode fused into the first expert GEMM (is_postscore=True, single rank): row r of expert e
+ * is gathered from the TOKEN array instead of a materialised bucket array,
+ *     A[e, r, :] = X[slot_map[e*R + r] % T, :]      (slot_map < 0: the all-zero row `zero_row`, >= K elements)
+ * which is exactly what fast_encode would have written (GatingEncoder.forward with unit gates,
+ * fast_dispatch.py:18-29): same values, minus the 2 x E*C*M bytes of writing and re-reading the
+ * buckets.  Other arguments as tutel_amd_expert_gemm (D is a plain [E_loc, R, N] array). */
+int tutel_amd_expert_gemm_gather(const void *X, int ldx, const int32_t *slot_map, int T,
+                                 const void *zero_row, const void *W, int w_kmajor,
+                                 int64_t w_stride_e, int ldw, const void *bias,
+                                 int64_t bias_stride_e, void *D, int64_t d_stride_e, int ldd,
+                                 int E_loc, int R, int N, int K, int dtype, int act,
+                                 const int32_t *row_counts, int row_align, tutel_stream_t stream);
+
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------
  * Dumps the lane->element permutation of ds_read_b64_tr_b16 (the transposing LDS read the
  * [K,N]-weight GEMM relies on): out[64*4] uint16, LDS pre-filled with lds[i] = i, lane l

@@ -312,3 +312,24 @@ def test_masked_tokens_through_dispatcher(oracle):
     dec = d.decode(enc)
     want = oracle.fast_decode(oracle.fast_encode(x, crit), crit)
     assert torch.equal(dec.cpu(), want) and bool((dec.cpu()[::5] == 0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,E,k,M,H,cf", [(512, 8, 2, 128, 192, 1.0), (4096, 64, 2, 2048, 128, 1.0), (300, 5, 2, 64, 64, 0.5)])
+def test_expert_gemm_gather_equals_encode_then_gemm(oracle, dtype, T, E, k, M, H, cf):
+    """fc1 with fast_encode fused (rows gathered from the tokens through the slot map, zero row for
+    empty slots) must equal fast_encode followed by the plain grouped GEMM, bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(T + M)
+    scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
+    crit, _ = oracle.extract_critical(scores, k, cf)
+    _, idx_o, loc_o, _, C, _ = crit
+    x = torch.randn([T, M], generator=g).to(dtype).cuda()
+    w = ((torch.rand([E, H, M], generator=g) * 2 - 1) / math.sqrt(M)).to(dtype).cuda()
+    b = torch.randn([E, H], generator=g).to(dtype).cuda()
+    smap = ops.slot_map(torch.stack(idx_o).cuda(), torch.stack(loc_o).cuda(), E, C)
+    enc = ops.fast_encode(x, smap, None, E * C).view(E, C, M)
+    want = ops.expert_gemm(enc, w, b, True, act="relu")
+    got = ops.expert_gemm_gather(x, smap, w, b, True, "relu", C)
+    assert torch.equal(got, want)
+    assert cf < 1.0 or int((smap < 0).sum()) > 0, "cf >= 1 leaves empty slots: the zero-row path must be exercised"

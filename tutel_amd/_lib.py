@@ -32,6 +32,8 @@ SIGNATURES = {
     "tutel_amd_gate_grad": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tutel_amd_expert_gemm": (_i, [_vp, _i64, _i64, _i, _i, _vp, _i, _i64, _i, _vp, _i64, _vp, _i64,
                                    _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "tutel_amd_expert_gemm_gather": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _i,
+                                          _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "tutel_amd_probe_tr16": (_i, [_vp, _vp]),
 }
 

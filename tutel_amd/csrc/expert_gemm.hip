@@ -83,6 +83,7 @@ struct GemmArgs {
   void *D; long long d_stride_e, d_stride_w; int d_rpw, ldd;
   int E_loc, R, N, K;
   const int32_t *row_counts; int row_align;
+  const int32_t *a_rows; int a_rows_mod; const void *a_zero;  // optional row gather for A (fused fast_encode)
   int ntm, ntn;
 };
 
@@ -146,6 +147,11 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
       int r = rbase + RPP * i;
       int gr = min(m0 + r, p.R - 1);
       a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + kc * 8;
+      if (p.a_rows != nullptr) {  // fused fast_encode: bucket row -> token row of x (or the zero row)
+        const int q = p.a_rows[(size_t)e * p.R + gr];
+        a_src[i] = (q >= 0 ? reinterpret_cast<const uint16_t *>(p.A) + (size_t)(q % p.a_rows_mod) * p.lda
+                           : reinterpret_cast<const uint16_t *>(p.a_zero)) + kc * 8;
+      }
       a_dst[i] = r * LDK + kc * 8;
     }
     if (W_KMAJOR) {
@@ -397,6 +403,11 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     const int gr = min(m0 + r, p.R - 1);
     a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + c * 8;
+    if (p.a_rows != nullptr) {  // fused fast_encode: bucket row -> token row of x (or the zero row)
+      const int q = p.a_rows[(size_t)e * p.R + gr];
+      a_src[i] = (q >= 0 ? reinterpret_cast<const uint16_t *>(p.A) + (size_t)(q % p.a_rows_mod) * p.lda
+                         : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;
+    }
     if (W_KMAJOR) {
       const int gn = min(n0 + r, p.N - 1);
       w_src[i] = We + (size_t)gn * p.ldw + c * 8;
@@ -625,13 +636,14 @@ static int launch_gemm_act(const GemmArgs &a, int act, int grid, hipStream_t st)
   }
 }
 
-extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t a_stride_w,
+static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_w,
                                      int a_rows_per_w, int lda, const void *W, int w_kmajor,
                                      int64_t w_stride_e, int ldw, const void *bias,
                                      int64_t bias_stride_e, void *D, int64_t d_stride_e,
                                      int64_t d_stride_w, int d_rows_per_w, int ldd, int E_loc,
                                      int R, int N, int K, int dtype, int act,
                                      const int32_t *row_counts, int row_align,
+                                     const int32_t *a_rows, int a_rows_mod, const void *a_zero,
                                      tutel_stream_t stream) {
   TUTEL_REQUIRE(dtype == TUTEL_BF16 || dtype == TUTEL_F16, "tutel_amd_expert_gemm: dtype must be bf16 or fp16 (got %d)", dtype);
   TUTEL_REQUIRE(E_loc >= 0 && R >= 0 && N >= 1 && K >= 1, "tutel_amd_expert_gemm: bad sizes E_loc=%d R=%d N=%d K=%d", E_loc, R, N, K);
@@ -654,6 +666,9 @@ extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t 
   a.D = D; a.d_stride_e = d_stride_e; a.d_stride_w = d_stride_w; a.d_rpw = d_rows_per_w; a.ldd = ldd;
   a.E_loc = E_loc; a.R = R; a.N = N; a.K = K;
   a.row_counts = row_counts; a.row_align = row_align < 1 ? 1 : row_align;
+  a.a_rows = a_rows; a.a_rows_mod = a_rows_mod; a.a_zero = a_zero;
+  TUTEL_REQUIRE(a_rows == nullptr || (a_rows_mod >= 1 && a_zero != nullptr && ((uintptr_t)a_zero % 16) == 0),
+                "tutel_amd_expert_gemm_gather: need a_rows_mod >= 1 and a 16-byte aligned zero row");
   a.ntm = (R + GM_BM - 1) / GM_BM;
   a.ntn = (N + GM_BN - 1) / GM_BN;
   long long grid_ll = (long long)E_loc * a.ntm * a.ntn;
@@ -663,4 +678,30 @@ extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t 
   if (dtype == TUTEL_BF16)
     return w_kmajor ? launch_gemm_act<bf16_t, true>(a, act, grid, st) : launch_gemm_act<bf16_t, false>(a, act, grid, st);
   return w_kmajor ? launch_gemm_act<f16_t, true>(a, act, grid, st) : launch_gemm_act<f16_t, false>(a, act, grid, st);
+}
+
+extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t a_stride_w,
+                                     int a_rows_per_w, int lda, const void *W, int w_kmajor,
+                                     int64_t w_stride_e, int ldw, const void *bias,
+                                     int64_t bias_stride_e, void *D, int64_t d_stride_e,
+                                     int64_t d_stride_w, int d_rows_per_w, int ldd, int E_loc,
+                                     int R, int N, int K, int dtype, int act,
+                                     const int32_t *row_counts, int row_align,
+                                     tutel_stream_t stream) {
+  return expert_gemm_impl(A, a_stride_e, a_stride_w, a_rows_per_w, lda, W, w_kmajor, w_stride_e, ldw, bias,
+                          bias_stride_e, D, d_stride_e, d_stride_w, d_rows_per_w, ldd, E_loc, R, N, K, dtype, act,
+                          row_counts, row_align, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int tutel_amd_expert_gemm_gather(const void *X, int ldx, const int32_t *slot_map, int T,
+                                            const void *zero_row, const void *W, int w_kmajor,
+                                            int64_t w_stride_e, int ldw, const void *bias,
+                                            int64_t bias_stride_e, void *D, int64_t d_stride_e, int ldd,
+                                            int E_loc, int R, int N, int K, int dtype, int act,
+                                            const int32_t *row_counts, int row_align,
+                                            tutel_stream_t stream) {
+  TUTEL_REQUIRE(slot_map != nullptr && T >= 1, "tutel_amd_expert_gemm_gather: need a slot map and T >= 1");
+  return expert_gemm_impl(X, 0, 0, R > 0 ? R : 1, ldx, W, w_kmajor, w_stride_e, ldw, bias, bias_stride_e, D,
+                          d_stride_e, 0, R > 0 ? R : 1, ldd, E_loc, R, N, K, dtype, act, row_counts, row_align,
+                          slot_map, T, zero_row, stream);
 }

@@ -116,15 +116,21 @@ class FusedExpertsNetwork(torch.nn.Module):
         return (ops.gemm_supported(w1.dtype, w1.size(1), w1.size(2)) and
                 ops.gemm_supported(w2.dtype, w2.size(2), w2.size(1)) and self.fused_activation() is not None)
 
-    def forward_fused(self, x, ctx, a_layout=None, R=None, out=None, d_layout=None):
+    def forward_fused(self, x, ctx, a_layout=None, R=None, out=None, d_layout=None, slot_map=None):
         """x [E_loc,R,M] (or the raw all-to-all buffer described by a_layout) -> [E_loc,R,M_out]
-        (or written into `out` in d_layout).  Two MFMA grouped-GEMM launches."""
+        (or written into `out` in d_layout).  Two MFMA grouped-GEMM launches.
+        slot_map given: x is the TOKEN array [T,M] and fc1 gathers its rows through the slot map
+        (fast_encode fused into the GEMM; R = capacity)."""
         counts, align = None, 1
         if getattr(ctx, "megablocks_size", 0) > 0:
             counts, align = ctx.dispatch_count, int(ctx.megablocks_size)
-        h = ops.expert_gemm(x, self.batched_fc1_w, self.batched_fc1_bias, True, act=self.fused_activation(),
-                            E_loc=self.batched_fc1_w.size(0), R=R, a_layout=a_layout,
-                            row_counts=counts, row_align=align)
+        if slot_map is not None:
+            h = ops.expert_gemm_gather(x, slot_map, self.batched_fc1_w, self.batched_fc1_bias, True,
+                                       self.fused_activation(), R, row_counts=counts, row_align=align)
+        else:
+            h = ops.expert_gemm(x, self.batched_fc1_w, self.batched_fc1_bias, True, act=self.fused_activation(),
+                                E_loc=self.batched_fc1_w.size(0), R=R, a_layout=a_layout,
+                                row_counts=counts, row_align=align)
         b2 = self.batched_fc2_bias
         if b2 is not None and b2.size(-1) != self.output_dim:
             b2 = b2[:, :self.output_dim].contiguous()

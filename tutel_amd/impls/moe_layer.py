@@ -34,6 +34,8 @@ from ..experts.ffn import FusedExpertsNetwork
 # test hook: run the overlapped expert-parallel path even with a single rank (exercises its
 # stream / event / allocator discipline on one GPU)
 _FORCE_OVERLAP = int(os.environ.get("TUTEL_AMD_FORCE_OVERLAP", "0")) != 0
+# A/B switch: gather fc1's rows from the tokens (fused fast_encode) on the single-rank path
+_FUSE_ENCODE = int(os.environ.get("TUTEL_AMD_FUSE_ENCODE", "1")) != 0
 
 
 def _autocast_dtype(t):
@@ -292,6 +294,21 @@ class MOELayer(torch.nn.Module):
                 and (x.dtype == logits_dtype or (logits_dtype == torch.float32 and x.dtype == original_dtype))
                 and self.experts.can_fuse(x, self)):
             y = a2a_ffn_overlap_fused(self, x if x.is_contiguous() else x.contiguous(), crit, degree, self.is_postscore)
+            y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
+            self.l_aux = y.l_aux = l_aux
+            return self.result_func(y) if self.result_func is not None else y
+
+        # single rank, is_postscore: fast_encode is a pure row copy, so fc1 gathers its rows straight
+        # from the tokens through the slot map -- the [E,C,M] bucket array is never materialised
+        if (self.world_size == 1 and self.is_postscore and x.is_cuda and len(reserve_shape) == 1
+                and isinstance(self.experts, FusedExpertsNetwork) and isinstance(crit, RoutingPlan)
+                and crit[4] > 0 and _FUSE_ENCODE
+                and (x.dtype == logits_dtype or (logits_dtype == torch.float32 and x.dtype == original_dtype))
+                and self.experts.can_fuse(x, self)):
+            y = self.experts.forward_fused(x if x.is_contiguous() else x.contiguous(), self, R=crit[4],
+                                           slot_map=crit.slot_map)
+            self.protected_shape = y.shape
+            y = fast_decode(y, crit, self.is_postscore)
             y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
             self.l_aux = y.l_aux = l_aux
             return self.result_func(y) if self.result_func is not None else y

@@ -221,6 +221,27 @@ def expert_gemm(a, w, bias, w_kmajor, act="none", E_loc=None, R=None, a_layout=N
     return out
 
 
+_zero_rows = {}
+
+
+def expert_gemm_gather(x, smap, w, bias, w_kmajor, act, R, row_counts=None, row_align=1):
+    """fc1 with fast_encode fused: D[e,r,:] = act(x[smap[e*R+r] % T] @ op(W[e]) + bias[e]), zero row where smap < 0."""
+    _dev(x, smap, w, bias, row_counts)
+    assert x.dim() == 2 and x.is_contiguous() and w.dim() == 3 and w.is_contiguous() and w.dtype == x.dtype
+    E_loc, N, K = (w.shape if w_kmajor else (w.shape[0], w.shape[2], w.shape[1]))
+    assert x.shape[1] == K and smap.dtype == torch.int32 and smap.numel() == E_loc * R
+    key = (x.device, x.dtype)
+    z = _zero_rows.get(key)
+    if z is None or z.numel() < K:
+        z = _zero_rows[key] = torch.zeros([max(K, 8192)], dtype=x.dtype, device=x.device)
+    out = torch.empty([E_loc, R, N], dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().tutel_amd_expert_gemm_gather(
+        _ptr(x), x.stride(0), _ptr(smap), x.shape[0], _ptr(z), _ptr(w), int(bool(w_kmajor)), w.stride(0), w.stride(1),
+        _ptr(bias), (bias.stride(0) if bias is not None else 0), _ptr(out), R * N, N, E_loc, R, N, K, _code(x),
+        ACT_CODES[act], _ptr(row_counts), int(row_align), _stream()), "tutel_amd_expert_gemm_gather")
+    return out
+
+
 def probe_tr16():
     out = torch.empty([256], dtype=torch.int16, device="cuda")
     _lib.check(_lib.lib().tutel_amd_probe_tr16(_ptr(out), _stream()), "tutel_amd_probe_tr16")
