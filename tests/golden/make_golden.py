@@ -209,6 +209,17 @@ def check_oracle_against_reference():
         gg = torch.empty([T])
         ck.invoke_cpu_fp32([gg, cr[1][j], cr[2][j], x, buf], [T, M, cr[4]], 2)
         expect(torch.equal(gg, O.gate_grad(x, buf, cr[1][j], cr[2][j], cr[4])), f"gate_grad j={j}")
+    # host-side loss functions of the product (pure torch) against the reference's
+    from tutel_amd.impls import losses as my_losses
+    g = torch.Generator().manual_seed(77)
+    sc = torch.softmax(torch.randn([640, 24], generator=g), dim=1)
+    ids = torch.topk(sc, 2, dim=1).indices
+    expect(torch.equal(my_losses.gshard_loss(sc, ids), ref_losses.gshard_loss(sc, ids)), "gshard_loss (torch form)")
+    logits = torch.randn([640, 24], generator=g)
+    tl = logits.gather(1, ids)
+    a = my_losses.load_importance_loss(torch.softmax(logits, 1), tl, 24, 0.7)
+    b_ = ref_losses.load_importance_loss(torch.softmax(logits, 1), tl, 24, 0.7)
+    expect(torch.allclose(a, b_, rtol=1e-6, atol=1e-7), f"load_importance_loss {float(a)} vs {float(b_)}")
     for b in bad:
         print("MISMATCH:", b)
     print("oracle-vs-reference: %d mismatches" % len(bad))
@@ -226,6 +237,22 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"layer_{name}.npz"), **out)
         print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items() if k in ("y", "idx")})
     np.savez_compressed(os.path.join(HERE, "headline_integers.npz"), **headline_integer_case())
+    # batch-prioritised routing (fast_dispatch.py:138-141,155-157): tokens ranked by -max score get buckets first
+    g = torch.Generator().manual_seed(31)
+    bpr = {}
+    for tag, (T, E, k, cf) in {"a": (1000, 16, 2, 0.5), "b": (4096, 64, 2, 1.0), "c": (300, 8, 1, 0.25)}.items():
+        while True:  # the reference orders equal importance scores by an unstable argsort: keep the fixture tie-free
+            scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
+            if scores.max(dim=1)[0].unique().numel() == T:
+                break
+        crit, _ = ref_moe.top_k_routing(scores, k, capacity_factor=cf, batch_prioritized_routing=True)
+        bpr[f"scores_{tag}"] = np_(scores)
+        bpr[f"idx_{tag}"] = np.stack([np_(i) for i in crit[1]])
+        bpr[f"loc_{tag}"] = np.stack([np_(i) for i in crit[2]])
+        bpr[f"gates_{tag}"] = np.stack([np_(i) for i in crit[3]])
+        bpr[f"meta_{tag}"] = np.array([T, E, k, crit[4]], dtype=np.int64)
+        bpr[f"cf_{tag}"] = np.array([cf])
+    np.savez_compressed(os.path.join(HERE, "bpr_routing.npz"), **bpr)
     np.savez_compressed(os.path.join(HERE, "train_losses_top2_e2.npz"), **train_losses_case(2, 2))
     np.savez_compressed(os.path.join(HERE, "train_losses_top1_e4.npz"), **train_losses_case(4, 1))
     print("done")

@@ -357,3 +357,26 @@ def test_forward_is_hip_graph_capturable(oracle):
                 g.replay()
             torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_batch_prioritized_routing_vs_reference_fixture():
+    """batch_prioritized_routing=True: locations are ranks in the order of
+    descending max-score; idx / loc / gates / capacity equal the reference's.  (The reference's
+    dispatch_count under BPR is the last token's row, not per-expert totals -- SURVEY section 7
+    quirk 8; here it stays the true totals.)"""
+    from tutel import moe
+    z = np.load(os.path.join(GOLD, "bpr_routing.npz"))
+    for tag in ("a", "b", "c"):
+        T, E, k, cap = [int(v) for v in z[f"meta_{tag}"]]
+        scores = torch.from_numpy(z[f"scores_{tag}"]).cuda()
+        crit, _ = moe.top_k_routing(scores, k, capacity_factor=float(z[f"cf_{tag}"][0]), batch_prioritized_routing=True)
+        assert crit[4] == cap
+        assert torch.equal(torch.stack(crit[1]).cpu(), torch.from_numpy(z[f"idx_{tag}"]))
+        assert torch.equal(torch.stack(crit[2]).cpu(), torch.from_numpy(z[f"loc_{tag}"])), tag
+        assert torch.equal(torch.stack(crit[3]).cpu(), torch.from_numpy(z[f"gates_{tag}"]))
+        assert int(crit[5].sum()) == k * T
+        x = torch.randn(T, 32, device="cuda")
+        y = moe.fast_decode(moe.fast_encode(x, crit), crit)
+        kept = (torch.stack(crit[2]) < cap)
+        w = (torch.stack(crit[3]) * kept).sum(0)
+        torch.testing.assert_close(y, x * w.unsqueeze(1), rtol=1e-5, atol=1e-6)
