@@ -334,7 +334,7 @@ def test_helloworld_training_losses_match_reference():
             all(abs(g - w) <= 2e-3 for g, w in zip(got, want)), (got, want)
 
 
-def test_forward_is_hip_graph_capturable(oracle):
+def test_forward_is_hip_graph_capturable_raw(oracle):
     """With capacity_factor > 0 the forward has no host synchronisation, so the whole layer (HIP
     kernels launched through the C ABI on the capturing stream + the hipBLASLt gate GEMM) can be
     captured into a HIP graph and replayed: zero host cost per step."""
@@ -380,3 +380,19 @@ def test_batch_prioritized_routing_vs_reference_fixture():
         kept = (torch.stack(crit[2]) < cap)
         w = (torch.stack(crit[3]) * kept).sum(0)
         torch.testing.assert_close(y, x * w.unsqueeze(1), rtol=1e-5, atol=1e-6)
+
+
+def test_graphed_forward_wrapper(oracle):
+    from tutel_amd.impls.graph import GraphedForward
+    T, M, H, E, k = 1024, 256, 256, 8, 2
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=torch.bfloat16, seed=10)
+    layer = make_layer(M, H, E, k, 1.0, torch.bfloat16, weights).eval()
+    xs = x.cuda()
+    with torch.no_grad():
+        want = layer(xs).clone()
+        want2 = layer(xs * 2).clone()
+    g = GraphedForward(layer, xs)
+    assert torch.equal(g(xs), want)
+    assert torch.equal(g(xs * 2), want2) and torch.equal(g(xs), want)
+    with pytest.raises(ValueError):
+        GraphedForward(layer, xs, capacity_factor=0.0)

@@ -1,0 +1,38 @@
+"""HIP-graph capture of the MoE forward (inference).
+
+With capacity_factor > 0 the forward path never synchronises with the host (the dropless mode's
+one `int(capacity)` is the only sync the API implies), and every HIP kernel is enqueued on the
+caller's current stream through the C ABI -- so the whole layer, routing to combine, can be captured
+once and replayed with zero per-step host work:
+
+    graphed = GraphedForward(layer, example_input)     # captures on a side stream
+    y = graphed(x)                                     # copies x into the static input, replays
+
+The static input/output buffers are owned by the wrapper; `y` is valid until the next call."""
+import torch
+
+
+class GraphedForward:
+    def __init__(self, layer, example, warmup=3, **forward_kwargs):
+        assert example.is_cuda, "HIP-graph capture needs a device tensor"
+        if forward_kwargs.get("capacity_factor", getattr(layer.gates[0], "capacity_factor", 1.0)) <= 0:
+            raise ValueError("dropless routing (capacity_factor <= 0) reads the capacity back to the host and cannot be captured")
+        self.layer, self.kwargs = layer, forward_kwargs
+        self.static_in = example.clone()
+        self.stream = torch.cuda.Stream(device=example.device)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                layer(self.static_in, **forward_kwargs)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.static_out = layer(self.static_in, **forward_kwargs)
+        self.l_aux = getattr(self.static_out, "l_aux", None)
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+    def __call__(self, x):
+        if x.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(x)
+        self.graph.replay()
+        return self.static_out
