@@ -180,6 +180,20 @@ int tutel_amd_expert_gemm_gather(const void *X, int ldx, const int32_t *slot_map
                                  int E_loc, int R, int N, int K, int dtype, int act,
                                  const int32_t *row_counts, int row_align, tutel_stream_t stream);
 
+/* Gated (GLU) form: D = act(A @ op(W) + bias) * G, elementwise, rounded once to `dtype`.
+ * Replaces the matmul + elementwise product of the SwiGLU expert,
+ * `y = activation_fn(y1) * y2` with y2 = x @ W_fc2 (experts/llama_ffn.py:38-40): the caller first
+ * runs tutel_amd_expert_gemm with act = silu on W_fc1 to get G = act(y1), then this entry point on
+ * W_fc2 with act = none.  G has D's layout (same strides); G == D (in place) is allowed.
+ * All other arguments as tutel_amd_expert_gemm. */
+int tutel_amd_expert_gemm_glu(const void *A, int64_t a_stride_e, int64_t a_stride_w,
+                              int a_rows_per_w, int lda, const void *W, int w_kmajor,
+                              int64_t w_stride_e, int ldw, const void *bias, int64_t bias_stride_e,
+                              const void *G, void *D, int64_t d_stride_e, int64_t d_stride_w,
+                              int d_rows_per_w, int ldd, int E_loc, int R, int N, int K, int dtype,
+                              int act, const int32_t *row_counts, int row_align,
+                              tutel_stream_t stream);
+
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------
  * Dumps the lane->element permutation of ds_read_b64_tr_b16 (the transposing LDS read the
  * [K,N]-weight GEMM relies on): out[64*4] uint16, LDS pre-filled with lds[i] = i, lane l

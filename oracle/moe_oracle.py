@@ -211,6 +211,33 @@ def expert_ffn(x, w1, b1, w2, b2, act=torch.relu, accum_fp32=False):
     return y.to(dt)
 
 
+def expert_llama_ffn(x, w1, w2, w3, act=torch.nn.functional.silu, accum_fp32=False):
+    """SwiGLU expert: x [E_loc,R,M]; w1, w2 [E_loc,M,H]; w3 [E_loc,H,M] -> [E_loc,R,M].
+    Reference: experts/llama_ffn.py:33-42.  accum_fp32 as in expert_ffn: fp32 accumulation on the
+    same inputs, act(y1) rounded once (it is stored), the gated product rounded once, output once."""
+    if not accum_fp32:
+        y1 = torch.matmul(x, w1)
+        y2 = torch.matmul(x, w2)
+        return torch.matmul(act(y1) * y2, w3)
+    dt = x.dtype
+    g = act(torch.matmul(x.float(), w1.float())).to(dt).float()
+    h = (g * torch.matmul(x.float(), w2.float())).to(dt).float()
+    return torch.matmul(h, w3.float()).to(dt)
+
+
+def cosine_gate_logits(x, proj_w, proj_b, sim, temperature, fp32_gate=False):
+    """Cosine top-k gate logits.  Reference: gates/cosine_top.py:22-34 (clamp_max = log(1/0.01)
+    evaluated in fp32, :15).  x [T,M]; proj_w [P,M]; proj_b [P]; sim [P,E]; temperature [1]."""
+    if fp32_gate:
+        x, proj_w, proj_b, sim = x.float(), proj_w.float(), proj_b.float(), sim.float()
+    else:
+        x = x.to(proj_w.dtype)
+    F = torch.nn.functional
+    logits = torch.matmul(F.normalize(F.linear(x, proj_w, proj_b), dim=1), F.normalize(sim, dim=0))
+    clamp_max = torch.log(torch.tensor(1. / 0.01)).item()
+    return logits * torch.clamp(temperature, max=clamp_max).exp()
+
+
 def gate_scores(x, wg, fp32_gate=False):
     """Reference: gates/top.py:20-22 and moe_layer.py:290.  Returns (scores, logits_dtype)."""
     w = wg.float() if fp32_gate else wg
@@ -251,17 +278,26 @@ def a2a_combine(per_rank, C):
 # ---------------------------------------------------------------------------------------------
 def moe_forward(x, wg, w1, b1, w2, b2, top_k=2, capacity_factor=1.0, fp32_gate=False,
                 normalize_gate=True, is_postscore=True, act=torch.relu, alignment=1,
-                accum_fp32=False, topk_override=None):
+                accum_fp32=False, topk_override=None, logits_fn=None, expert_fn=None):
     """Single-rank MOELayer.forward.  Reference: moe_layer.py:255-363 (dtype chain :264-270,
-    :327, :359-361).  x [..., M] -> (y [..., M_out], l_aux, crit, stages dict)."""
+    :327, :359-361).  x [..., M] -> (y [..., M_out], l_aux, crit, stages dict).
+    logits_fn(x[T,M]) -> logits replaces the linear gate (custom / cosine gates, moe_layer.py:283);
+    expert_fn(enc[E,C,M]) -> [E,C,M_out] replaces the ReLU FFN (custom / llama experts, :251)."""
     orig_shape, orig_dtype = x.shape, x.dtype
     M = orig_shape[-1]
     xr = x.reshape(-1, M).to(w1.dtype)
-    scores, logits_dtype = gate_scores(xr, wg, fp32_gate)
+    if logits_fn is not None:
+        logits = logits_fn(xr)
+        scores, logits_dtype = torch.softmax(logits, dim=1), logits.dtype
+    else:
+        scores, logits_dtype = gate_scores(xr, wg, fp32_gate)
     crit, l_aux = extract_critical(scores, top_k, capacity_factor, normalize_gate, alignment,
                                    topk_override=topk_override)
     enc = fast_encode(xr.to(logits_dtype), crit, is_postscore).to(xr.dtype)
-    ffn = expert_ffn(enc, w1, b1, w2, b2, act, accum_fp32=accum_fp32)
+    if expert_fn is not None:
+        ffn = expert_fn(enc)
+    else:
+        ffn = expert_ffn(enc, w1, b1, w2, b2, act, accum_fp32=accum_fp32)
     dec = fast_decode(ffn.to(logits_dtype), crit, is_postscore)
     y = dec.view(list(orig_shape[:-1]) + [ffn.shape[-1]]).to(orig_dtype)
     return y, l_aux, crit, {"scores": scores, "encoded": enc, "expert_out": ffn}
@@ -310,3 +346,21 @@ def make_problem(T, M, H, E, dtype=torch.float32, seed=0, out_dim=None):
     w2 = uni([E, H, out_dim], 1 / math.sqrt(H))
     b2 = uni([E, out_dim], 1 / math.sqrt(H))
     return [t.to(dtype) for t in (x, wg, w1, b1, w2, b2)]
+
+
+def make_problem_ext(T, M, H, E, P=32, dtype=torch.float32, seed=0):
+    """Inputs for the cosine gate + SwiGLU expert case (gates/cosine_top.py:12-16 and
+    experts/llama_ffn.py:27-31 initialisers, from one explicit generator):
+    x [T,M], proj_w [P,M], proj_b [P], sim [P,E], temperature [1], w1/w2 [E,M,H], w3 [E,H,M].
+    The weights use a wider spread than the reference's normal(0, 0.01) so that outputs are not
+    vanishingly small next to the comparison tolerances."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn([T, M], generator=g)
+    proj_w = (torch.rand([P, M], generator=g) * 2 - 1) / math.sqrt(M)
+    proj_b = (torch.rand([P], generator=g) * 2 - 1) / math.sqrt(M)
+    sim = torch.randn([P, E], generator=g) * 0.01
+    temperature = torch.log(torch.full([1], 1.0 / 0.5))
+    w1 = torch.randn([E, M, H], generator=g) / math.sqrt(M)
+    w2 = torch.randn([E, M, H], generator=g) / math.sqrt(M)
+    w3 = torch.randn([E, H, M], generator=g) / math.sqrt(H)
+    return [t.to(dtype) for t in (x, proj_w, proj_b, sim, temperature, w1, w2, w3)]

@@ -46,6 +46,59 @@ LAYER_CASES = [
 ]
 
 
+# cosine gate + SwiGLU expert: (name, T, M, H, E, P, k, cf, dtype, fp32_gate)
+EXT_CASES = [
+    ("f32_cosine_llama", 512, 64, 64, 16, 32, 2, 1.0, "float32", False),
+    ("bf16_cosine_llama_fp32gate", 512, 64, 64, 16, 32, 2, 1.0, "bfloat16", True),
+    ("f32_cosine_llama_k1_drop", 384, 64, 64, 8, 16, 1, 0.5, "float32", False),
+]
+
+
+def build_reference_ext_layer(T, M, H, E, P, k, cf, dtype, fp32_gate, seed):
+    x, pw, pb, sim, temp, w1, w2, w3 = O.make_problem_ext(T, M, H, E, P, dtype=dtype, seed=seed)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        layer = ref_moe.moe_layer(
+            gate_type={"type": "cosine_top", "k": k, "fp32_gate": fp32_gate, "capacity_factor": cf, "proj_dim": P},
+            experts={"type": "llama_ffn", "num_experts_per_device": E, "hidden_size_per_expert": H},
+            model_dim=M)
+    finally:
+        torch.set_default_dtype(old)
+    g = layer.gates[0]
+    with torch.no_grad():
+        g.cosine_projector.weight.copy_(pw); g.cosine_projector.bias.copy_(pb)
+        g.sim_matrix.copy_(sim); g.temperature.copy_(temp)
+        layer.experts.W_fc1.copy_(w1.reshape(-1)); layer.experts.W_fc2.copy_(w2.reshape(-1))
+        layer.experts.W_fc3.copy_(w3.reshape(-1))
+    layer.eval()
+    return layer, (x, pw, pb, sim, temp, w1, w2, w3)
+
+
+def run_ext_case(case, seed=4321):
+    name, T, M, H, E, P, k, cf, dts, fp32_gate = case
+    layer, tensors = build_reference_ext_layer(T, M, H, E, P, k, cf, DT[dts], fp32_gate, seed)
+    x = tensors[0]
+    with torch.no_grad():
+        y = layer(x)
+        logits = layer.gates[0](x)
+        crit, _ = ref_moe.top_k_routing(torch.softmax(logits, dim=1), k, capacity_factor=cf)
+    out = dict(meta=np.array([T, M, H, E, P, k, int(fp32_gate), seed], dtype=np.int64), cf=np.array([cf]),
+               dtype=np.array([dts]), in_checksum=np.array([checksum(tensors)]), logits=np_(logits),
+               idx=np.stack([np_(i) for i in crit[1]]), loc=np.stack([np_(i) for i in crit[2]]),
+               gates=np.stack([np_(g) for g in crit[3]]), capacity=np.array([crit[4]]),
+               l_aux=np.array([float(y.l_aux)]), y=np_(y))
+    return name, out, (layer, x)
+
+
+def oracle_ext_forward(case, seed=4321, accum_fp32=False):
+    name, T, M, H, E, P, k, cf, dts, fp32_gate = case
+    x, pw, pb, sim, temp, w1, w2, w3 = O.make_problem_ext(T, M, H, E, P, dtype=DT[dts], seed=seed)
+    return O.moe_forward(x, None, w1, None, None, None, top_k=k, capacity_factor=cf,
+                         logits_fn=lambda t: O.cosine_gate_logits(t, pw, pb, sim, temp, fp32_gate),
+                         expert_fn=lambda e: O.expert_llama_ffn(e, w1, w2, w3, accum_fp32=accum_fp32))
+
+
 def build_reference_layer(T, M, H, E, k, cf, dtype, fp32_gate, is_postscore, normalize_gate, seed):
     x, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=dtype, seed=seed)
     old = torch.get_default_dtype()
@@ -198,6 +251,13 @@ def check_oracle_against_reference():
             yr = layer(x)
         expect(torch.equal(yr, yo), f"layer output {name} maxdiff={(yr.double() - yo.double()).abs().max():.3e}")
         expect(abs(float(yr.l_aux) - float(lo)) == 0, f"layer l_aux {name}")
+    for case in EXT_CASES:
+        name, out, (layer, x) = run_ext_case(case)
+        yo, lo, co, st = oracle_ext_forward(case)
+        with torch.no_grad():
+            yr = layer(x)
+        expect(torch.equal(yr, yo), f"cosine+llama layer output {name} maxdiff={(yr.double() - yo.double()).abs().max():.3e}")
+        expect(float(yr.l_aux) == float(lo), f"cosine+llama l_aux {name}")
     # gate gradient kernel (backward-only row)
     from tutel.impls.jit_compiler import tutel_custom_kernel as ck  # noqa
     g = torch.Generator().manual_seed(9)
@@ -236,6 +296,10 @@ def main():
         name, out, _ = run_layer_case(case)
         np.savez_compressed(os.path.join(HERE, f"layer_{name}.npz"), **out)
         print("wrote", name, {k: getattr(v, "shape", None) for k, v in out.items() if k in ("y", "idx")})
+    for case in EXT_CASES:
+        name, out, _ = run_ext_case(case)
+        np.savez_compressed(os.path.join(HERE, f"ext_{name}.npz"), **out)
+        print("wrote ext", name)
     np.savez_compressed(os.path.join(HERE, "headline_integers.npz"), **headline_integer_case())
     # batch-prioritised routing (fast_dispatch.py:138-141,155-157): tokens ranked by -max score get buckets first
     g = torch.Generator().manual_seed(31)

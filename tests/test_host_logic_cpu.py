@@ -55,6 +55,48 @@ def test_layer_host_logic_matches_oracle(oracle, monkeypatch, k, cf, post, norm)
     assert torch.equal(layer.dispatch_count.cpu(), crit[5])
 
 
+def test_cosine_gate_and_llama_expert_host_logic(oracle, monkeypatch):
+    """`gate_type={'type': 'cosine_top'}` + `experts={'type': 'llama_ffn'}` modules
+    (parameter names/shapes of the reference, its RNG order, and the layer wiring) against the
+    reference fixtures, bit for bit on CPU."""
+    import glob
+    import numpy as np
+    from tutel import moe
+    _cpu_ops.install(monkeypatch)
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ext_f32_*.npz"))):
+        z = np.load(path)
+        T, M, H, E, P, k, fp32_gate, seed = [int(v) for v in z["meta"]]
+        x, pw, pb, sim, temp, w1, w2, w3 = oracle.make_problem_ext(T, M, H, E, P, seed=seed)
+        layer = moe.moe_layer(
+            gate_type={"type": "cosine_top", "k": k, "capacity_factor": float(z["cf"][0]), "proj_dim": P},
+            experts={"type": "llama_ffn", "num_experts_per_device": E, "hidden_size_per_expert": H}, model_dim=M).eval()
+        g = layer.gates[0]
+        assert sorted(n for n, _ in layer.named_parameters()) == sorted([
+            "gates.0.temperature", "gates.0.cosine_projector.weight", "gates.0.cosine_projector.bias",
+            "gates.0.sim_matrix", "experts.W_fc1", "experts.W_fc2", "experts.W_fc3"])
+        assert layer.experts.W_fc1.shape == (E * M * H,) and g.sim_matrix.shape == (P, E)
+        assert all(hasattr(p, "_tutel_expert") for p in layer.experts.parameters())
+        with torch.no_grad():
+            g.cosine_projector.weight.copy_(pw); g.cosine_projector.bias.copy_(pb)
+            g.sim_matrix.copy_(sim); g.temperature.copy_(temp)
+            layer.experts.W_fc1.copy_(w1.reshape(-1)); layer.experts.W_fc2.copy_(w2.reshape(-1))
+            layer.experts.W_fc3.copy_(w3.reshape(-1))
+            y = layer(x)
+        assert torch.equal(g(x), torch.from_numpy(z["logits"]))
+        assert torch.equal(y, torch.from_numpy(z["y"])) and float(y.l_aux) == float(z["l_aux"][0])
+    with pytest.raises(Exception, match="Unrecognized argument"):
+        moe.moe_layer(gate_type={"type": "cosine_top", "k": 1, "bogus": 1},
+                      experts={"type": "llama_ffn", "num_experts_per_device": 1, "hidden_size_per_expert": 8}, model_dim=8)
+    # same seeds -> same initial parameters as the reference draws them (temperature, projector, sim_matrix)
+    torch.manual_seed(5)
+    a = moe.moe_layer(gate_type={"type": "cosine_top", "k": 1, "proj_dim": 8}, seeds=(7, 8, 9),
+                      experts={"type": "llama_ffn", "num_experts_per_device": 2, "hidden_size_per_expert": 8}, model_dim=8)
+    torch.manual_seed(7)
+    t = torch.log(torch.full([1], 2.0)); lin = torch.nn.Linear(8, 8); sm = torch.randn(8, 2); torch.nn.init.normal_(sm, 0, 0.01)
+    assert torch.equal(a.gates[0].cosine_projector.weight, lin.weight) and torch.equal(a.gates[0].sim_matrix, sm)
+    assert torch.equal(a.gates[0].temperature.data, t)
+
+
 def test_low_level_api_and_tuple_contract(oracle, monkeypatch):
     """helloworld_from_scratch-style use: top_k_routing -> fast_encode -> expert -> fast_decode,
     `crit` indexable like the reference's tuple, fast_dispatcher usable with foreign idx/loc."""

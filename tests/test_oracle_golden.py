@@ -21,7 +21,7 @@ CASES = sorted(glob.glob(os.path.join(GOLD, "layer_*.npz")))
 
 
 def test_fixtures_present():
-    assert len(CASES) >= 10 and os.path.exists(os.path.join(GOLD, "headline_integers.npz"))
+    assert len(CASES) >= 10 and len(glob.glob(os.path.join(GOLD, "ext_*.npz"))) >= 3 and os.path.exists(os.path.join(GOLD, "headline_integers.npz"))
 
 
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[6:-4])
@@ -78,3 +78,29 @@ def test_oracle_edge_cases(oracle):
     per_rank = [torch.randn(4, 3, 5) for _ in range(2)]
     back = oracle.a2a_combine(oracle.a2a_dispatch(per_rank), 3)
     assert all(torch.equal(a, b) for a, b in zip(per_rank, back))
+
+
+EXT = sorted(glob.glob(os.path.join(GOLD, "ext_*.npz")))
+
+
+@pytest.mark.parametrize("path", EXT, ids=lambda p: os.path.basename(p)[4:-4])
+def test_oracle_cosine_gate_llama_expert_matches_reference_fixture(oracle, path):
+    """cosine_top gate + llama_ffn (SwiGLU) expert, reference layer output bit for bit."""
+    z = np.load(path)
+    T, M, H, E, P, k, fp32_gate, seed = [int(v) for v in z["meta"]]
+    dtype, cf = DT[str(z["dtype"][0])], float(z["cf"][0])
+    x, pw, pb, sim, temp, w1, w2, w3 = oracle.make_problem_ext(T, M, H, E, P, dtype=dtype, seed=seed)
+    chk = float(sum(t.double().abs().sum() for t in (x, pw, pb, sim, temp, w1, w2, w3)))
+    assert chk == float(z["in_checksum"][0])
+    gdt = torch.float32 if fp32_gate else dtype
+    logits = oracle.cosine_gate_logits(x, pw, pb, sim, temp, bool(fp32_gate))
+    assert torch.equal(logits, _t(z["logits"], gdt))
+    y, l_aux, crit, _ = oracle.moe_forward(
+        x, None, w1, None, None, None, top_k=k, capacity_factor=cf,
+        logits_fn=lambda t: oracle.cosine_gate_logits(t, pw, pb, sim, temp, bool(fp32_gate)),
+        expert_fn=lambda e: oracle.expert_llama_ffn(e, w1, w2, w3))
+    assert torch.equal(torch.stack(crit[1]), torch.from_numpy(z["idx"]))
+    assert torch.equal(torch.stack(crit[2]), torch.from_numpy(z["loc"]))
+    assert torch.equal(torch.stack(crit[3]), _t(z["gates"], gdt)) and crit[4] == int(z["capacity"][0])
+    assert float(l_aux) == float(z["l_aux"][0])
+    assert torch.equal(y, _t(z["y"], dtype))

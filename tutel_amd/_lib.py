@@ -34,6 +34,8 @@ SIGNATURES = {
                                    _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "tutel_amd_expert_gemm_gather": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _i,
                                           _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "tutel_amd_expert_gemm_glu": (_i, [_vp, _i64, _i64, _i, _i, _vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _i64,
+                                       _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "tutel_amd_probe_tr16": (_i, [_vp, _vp]),
 }
 

@@ -84,8 +84,71 @@ struct GemmArgs {
   int E_loc, R, N, K;
   const int32_t *row_counts; int row_align;
   const int32_t *a_rows; int a_rows_mod; const void *a_zero;  // optional row gather for A (fused fast_encode)
+  const void *mul;                                            // optional epilogue multiplier, D's layout
   int ntm, ntn;
 };
+
+// ---- epilogue shared by both kernels: lane holds, per accumulator, row m = l31, features
+// 8*rg + 4*kg + 0..3.  D = act(acc + bias) [* mul], rounded once to T; `mul` (optional) has D's
+// layout and is the gating operand of a GLU expert (llama_ffn.py:40).
+template <typename T, int ACT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, f32x16 (&acc)[2][2], uint2 (&bias_r)[2][4],
+                                              int e, int m0, int n0, int wm, int wn, int l31, int kg,
+                                              int row_limit) {
+  uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;
+  const uint16_t *Me = p.mul ? reinterpret_cast<const uint16_t *>(p.mul) + (size_t)e * p.d_stride_e : nullptr;
+  const bool has_bias = p.bias != nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wm * 64 + mi * 32 + l31;
+    if (m >= row_limit) continue;
+    const size_t roff = (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
+    uint16_t *drow = De + roff;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = n0 + wn * 64 + ni * 32 + rg * 8 + kg * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][rg * 4 + r];
+        if (has_bias) {
+          const uint2 bb = bias_r[ni][rg];
+          uint16_t b4[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            T tb;
+            __builtin_memcpy(&tb, &b4[r], 2);
+            v[r] += Elem<T>::to_f32(tb);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = activate<ACT>(v[r]);
+        if (Me) {
+          const uint2 mm = *reinterpret_cast<const uint2 *>(Me + roff + n);
+          uint16_t m4[4] = {(uint16_t)(mm.x & 0xffff), (uint16_t)(mm.x >> 16), (uint16_t)(mm.y & 0xffff), (uint16_t)(mm.y >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            T tm;
+            __builtin_memcpy(&tm, &m4[r], 2);
+            v[r] *= Elem<T>::to_f32(tm);
+          }
+        }
+        uint16_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T tv = Elem<T>::from_f32(v[r]);
+          __builtin_memcpy(&o[r], &tv, 2);
+        }
+        uint2 ov;
+        ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        *reinterpret_cast<uint2 *>(drow + n) = ov;
+      }
+    }
+  }
+}
 
 // streamed-once weight loads may bypass cache allocation (each W byte is read by exactly one CU)
 template <bool NT> __device__ __forceinline__ u32x4 ld16(const uint16_t *p) {
@@ -292,46 +355,7 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
 #undef GM_LSTORE
 #undef GM_COMPUTE
 
-  // ---- epilogue: lane holds, per accumulator, row m = l31, features 8*rg + 4*kg + 0..3
-  uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;
-  const uint16_t *be = p.bias ? reinterpret_cast<const uint16_t *>(p.bias) + (size_t)e * p.bias_stride_e : nullptr;
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = m0 + wm * 64 + mi * 32 + l31;
-    if (m >= row_limit) continue;
-    uint16_t *drow = De + (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + wn * 64 + ni * 32 + rg * 8 + kg * 4;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][rg * 4 + r];
-        if (be) {
-          const uint2 bb = bias_r[ni][rg];
-          uint16_t b4[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            T tb;
-            __builtin_memcpy(&tb, &b4[r], 2);
-            v[r] += Elem<T>::to_f32(tb);
-          }
-        }
-        uint16_t o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          T tv = Elem<T>::from_f32(activate<ACT>(v[r]));
-          __builtin_memcpy(&o[r], &tv, 2);
-        }
-        uint2 ov;
-        ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-        ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-        *reinterpret_cast<uint2 *>(drow + n) = ov;
-      }
-    }
-  }
+  gemm_epilogue<T, ACT>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -510,46 +534,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
 #undef GL_LOAD_FRAGS
 #undef GL_MMA
 
-  // ---- epilogue (identical to the register-staged kernel)
-  uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;
-  const uint16_t *be = p.bias ? reinterpret_cast<const uint16_t *>(p.bias) + (size_t)e * p.bias_stride_e : nullptr;
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = m0 + wm * 64 + mi * 32 + l31;
-    if (m >= row_limit) continue;
-    uint16_t *drow = De + (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + wn * 64 + ni * 32 + rg * 8 + kg * 4;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][rg * 4 + r];
-        if (be) {
-          const uint2 bb = bias_r[ni][rg];
-          uint16_t b4[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            T tb;
-            __builtin_memcpy(&tb, &b4[r], 2);
-            v[r] += Elem<T>::to_f32(tb);
-          }
-        }
-        uint16_t o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          T tv = Elem<T>::from_f32(activate<ACT>(v[r]));
-          __builtin_memcpy(&o[r], &tv, 2);
-        }
-        uint2 ov;
-        ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-        ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-        *reinterpret_cast<uint2 *>(drow + n) = ov;
-      }
-    }
-  }
+  gemm_epilogue<T, ACT>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
 }
 
 template <typename T, bool KM, int ACT>
@@ -644,7 +629,7 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
                                      int R, int N, int K, int dtype, int act,
                                      const int32_t *row_counts, int row_align,
                                      const int32_t *a_rows, int a_rows_mod, const void *a_zero,
-                                     tutel_stream_t stream) {
+                                     const void *mul, tutel_stream_t stream) {
   TUTEL_REQUIRE(dtype == TUTEL_BF16 || dtype == TUTEL_F16, "tutel_amd_expert_gemm: dtype must be bf16 or fp16 (got %d)", dtype);
   TUTEL_REQUIRE(E_loc >= 0 && R >= 0 && N >= 1 && K >= 1, "tutel_amd_expert_gemm: bad sizes E_loc=%d R=%d N=%d K=%d", E_loc, R, N, K);
   TUTEL_REQUIRE(K % 64 == 0, "tutel_amd_expert_gemm: K=%d must be a multiple of 64", K);
@@ -667,6 +652,8 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   a.E_loc = E_loc; a.R = R; a.N = N; a.K = K;
   a.row_counts = row_counts; a.row_align = row_align < 1 ? 1 : row_align;
   a.a_rows = a_rows; a.a_rows_mod = a_rows_mod; a.a_zero = a_zero;
+  a.mul = mul;
+  TUTEL_REQUIRE(((uintptr_t)mul % 8) == 0, "tutel_amd_expert_gemm_glu: gating operand must be 8-byte aligned");
   TUTEL_REQUIRE(a_rows == nullptr || (a_rows_mod >= 1 && a_zero != nullptr && ((uintptr_t)a_zero % 16) == 0),
                 "tutel_amd_expert_gemm_gather: need a_rows_mod >= 1 and a 16-byte aligned zero row");
   a.ntm = (R + GM_BM - 1) / GM_BM;
@@ -690,7 +677,21 @@ extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t 
                                      tutel_stream_t stream) {
   return expert_gemm_impl(A, a_stride_e, a_stride_w, a_rows_per_w, lda, W, w_kmajor, w_stride_e, ldw, bias,
                           bias_stride_e, D, d_stride_e, d_stride_w, d_rows_per_w, ldd, E_loc, R, N, K, dtype, act,
-                          row_counts, row_align, nullptr, 0, nullptr, stream);
+                          row_counts, row_align, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int tutel_amd_expert_gemm_glu(const void *A, int64_t a_stride_e, int64_t a_stride_w,
+                                         int a_rows_per_w, int lda, const void *W, int w_kmajor,
+                                         int64_t w_stride_e, int ldw, const void *bias,
+                                         int64_t bias_stride_e, const void *G, void *D, int64_t d_stride_e,
+                                         int64_t d_stride_w, int d_rows_per_w, int ldd, int E_loc,
+                                         int R, int N, int K, int dtype, int act,
+                                         const int32_t *row_counts, int row_align,
+                                         tutel_stream_t stream) {
+  TUTEL_REQUIRE(G != nullptr || E_loc == 0 || R == 0, "tutel_amd_expert_gemm_glu: null gating operand");
+  return expert_gemm_impl(A, a_stride_e, a_stride_w, a_rows_per_w, lda, W, w_kmajor, w_stride_e, ldw, bias,
+                          bias_stride_e, D, d_stride_e, d_stride_w, d_rows_per_w, ldd, E_loc, R, N, K, dtype, act,
+                          row_counts, row_align, nullptr, 0, nullptr, G, stream);
 }
 
 extern "C" int tutel_amd_expert_gemm_gather(const void *X, int ldx, const int32_t *slot_map, int T,
@@ -703,5 +704,5 @@ extern "C" int tutel_amd_expert_gemm_gather(const void *X, int ldx, const int32_
   TUTEL_REQUIRE(slot_map != nullptr && T >= 1, "tutel_amd_expert_gemm_gather: need a slot map and T >= 1");
   return expert_gemm_impl(X, 0, 0, R > 0 ? R : 1, ldx, W, w_kmajor, w_stride_e, ldw, bias, bias_stride_e, D,
                           d_stride_e, 0, R > 0 ? R : 1, ldd, E_loc, R, N, K, dtype, act, row_counts, row_align,
-                          slot_map, T, zero_row, stream);
+                          slot_map, T, zero_row, nullptr, stream);
 }

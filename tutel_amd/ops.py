@@ -186,13 +186,14 @@ def gemm_supported(dtype, N, K):
 
 
 def expert_gemm(a, w, bias, w_kmajor, act="none", E_loc=None, R=None, a_layout=None, out=None,
-                d_layout=None, row_counts=None, row_align=1):
-    """D[e,r,:] = act(A[e,r,:] @ op(W[e]) + bias[e]).
+                d_layout=None, row_counts=None, row_align=1, mul=None):
+    """D[e,r,:] = act(A[e,r,:] @ op(W[e]) + bias[e]) [* mul[e,r,:]].
 
     a: [E_loc, R, K] contiguous, or any buffer described by a_layout=(stride_e, stride_w, rows_per_w, lda)
     w: [E_loc, N, K] (w_kmajor) or [E_loc, K, N]; bias [E_loc, N] or None.
-    out/d_layout likewise (default: new contiguous [E_loc, R, N])."""
-    _dev(a, w, bias, out, row_counts)
+    out/d_layout likewise (default: new contiguous [E_loc, R, N]); mul (GLU gating operand) has
+    the output's layout and dtype."""
+    _dev(a, w, bias, out, row_counts, mul)
     assert w.dim() == 3 and w.is_contiguous()
     if w_kmajor:
         El, N, K = w.shape
@@ -211,6 +212,16 @@ def expert_gemm(a, w, bias, w_kmajor, act="none", E_loc=None, R=None, a_layout=N
     if bias is not None:
         assert bias.is_contiguous() and bias.shape[-1] == N and bias.dtype == a.dtype
     assert w.dtype == a.dtype
+    if mul is not None:
+        assert mul.dtype == a.dtype and mul.is_contiguous()
+        _lib.check(_lib.lib().tutel_amd_expert_gemm_glu(
+            _ptr(a), a_layout[0], a_layout[1], a_layout[2], a_layout[3],
+            _ptr(w), int(bool(w_kmajor)), w.stride(0), w.stride(1),
+            _ptr(bias), (bias.stride(0) if bias is not None else 0), _ptr(mul),
+            _ptr(out), d_layout[0], d_layout[1], d_layout[2], d_layout[3],
+            E_loc, R, N, K, _code(a), ACT_CODES[act],
+            _ptr(row_counts), int(row_align), _stream()), "tutel_amd_expert_gemm_glu")
+        return out
     _lib.check(_lib.lib().tutel_amd_expert_gemm(
         _ptr(a), a_layout[0], a_layout[1], a_layout[2], a_layout[3],
         _ptr(w), int(bool(w_kmajor)), w.stride(0), w.stride(1),
