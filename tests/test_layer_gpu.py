@@ -452,7 +452,7 @@ def test_llama_expert_fused_glu_gemm_vs_oracle(oracle, dtype):
     from tutel_amd.experts.llama_ffn import LlamaFFNNetwork
     E, R, M, H = 6, 200, 256, 320
     g = torch.Generator().manual_seed(3)
-    x = torch.randn([E, R, M], generator=g).to(dtype)
+    x = (torch.randn([E, R, M], generator=g) * 0.5).to(dtype)  # keeps |y| < 1: the fp16 bar is absolute
     net = LlamaFFNNetwork(M, H, E, 1).to(dtype)
     w1 = (torch.randn([E, M, H], generator=g) / M ** 0.5).to(dtype)
     w2 = (torch.randn([E, M, H], generator=g) / M ** 0.5).to(dtype)
@@ -472,3 +472,30 @@ def test_llama_expert_fused_glu_gemm_vs_oracle(oracle, dtype):
     y2 = net(x.cuda(), Ctx)
     assert y2.requires_grad
     _close(y2.detach(), oracle.expert_llama_ffn(x, w1, w2, w3), dtype, vs_lowprec_reference=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_low_precision_gate_layer_vs_oracle_on_its_own_scores(oracle, dtype):
+    """bf16 / fp16 gate (`fp32_gate=False`, the reference default): logits come from the library GEMM
+    in the gate dtype; the oracle is given the scores the routing kernel derived from them (softmax is
+    not bit-specified across exp implementations), so token -> expert assignment must agree exactly
+    and the output within the dtype's bar."""
+    from tutel_amd import ops
+    T, M, H, E, k = 1024, 512, 256, 32, 2
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=11)
+    layer = make_layer(M, H, E, k, 1.0, dtype, weights).eval()
+    with torch.no_grad():
+        xd = x.cuda()
+        logits = layer.gates[0](xd)
+        y = layer(xd)
+    assert logits.dtype == dtype
+    scores = ops.gate_topk(logits, k, apply_softmax=True, want_scores=True)[3].cpu()
+    sref = torch.softmax(logits.float(), dim=1).cpu()
+    assert float((scores.float() - sref).abs().max()) <= (2 ** -8 if dtype == torch.bfloat16 else 2 ** -11)
+    wg, w1, b1, w2, b2 = weights
+    crit, lo = oracle.extract_critical(scores, k, 1.0)
+    enc = oracle.fast_encode(x, crit)
+    yo = oracle.fast_decode(oracle.expert_ffn(enc, w1, b1, w2, b2, accum_fp32=True), crit)
+    assert torch.equal(layer.dispatch_count.cpu(), crit[5])
+    _close(y, yo, dtype)
+    assert abs(float(y.l_aux) - float(lo)) <= 1e-2
