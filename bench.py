@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide
 
 
 def build_layer(M, H, E_loc, k, rank, overlap, dtype, fp32_gate):
@@ -63,6 +64,7 @@ class GemmTimer:
         from tutel_amd import ops
         self.ops, self.real, self.events, self.on = ops, ops.expert_gemm, {True: [], False: []}, False
         self.bytes, self.flops = {True: 0, False: 0}, {True: 0, False: 0}  # algorithmic, per launch (last seen)
+        self.rows = {True: 0, False: 0}                                    # rows per expert of the last launch
         ops.expert_gemm = self
         self.real_gather = ops.expert_gemm_gather
         ops.expert_gemm_gather = self.gather
@@ -74,10 +76,11 @@ class GemmTimer:
         s.record()
         out = self.real(a, w, bias, w_kmajor, *args, **kw)
         e.record()
-        km = bool(w_kmajor)
+        km = kw.get("act", "none") != "none"  # True: fc1 (bias + ReLU fused), False: fc2
         self.events[km].append((s, e))
-        E_loc, N, K = (w.shape[0], w.shape[1], w.shape[2]) if km else (w.shape[0], w.shape[2], w.shape[1])
+        E_loc, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w_kmajor else (w.shape[0], w.shape[2], w.shape[1])
         R = kw.get("R") or a.shape[1]
+        self.rows[km] = R
         self.bytes[km] = (w.numel() + E_loc * R * K + E_loc * R * N) * w.element_size()
         self.flops[km] = 2 * E_loc * R * N * K
         return out
@@ -91,15 +94,16 @@ class GemmTimer:
         s.record()
         out = self.real_gather(x, smap, w, bias, w_kmajor, act, R, **kw)
         e.record()
-        km = bool(w_kmajor)
+        km = True  # the gathered launch is always fc1
+        self.rows[km] = R
         self.events[km].append((s, e))
-        E_loc, N, K = (w.shape[0], w.shape[1], w.shape[2]) if km else (w.shape[0], w.shape[2], w.shape[1])
+        E_loc, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w_kmajor else (w.shape[0], w.shape[2], w.shape[1])
         self.bytes[km] = (w.numel() + E_loc * R * K + E_loc * R * N) * w.element_size()
         self.flops[km] = 2 * E_loc * R * N * K
         return out
 
-    def avg_us(self, kmajor):
-        ev = self.events[kmajor]
+    def avg_us(self, fc1):
+        ev = self.events[fc1]
         return sum(s.elapsed_time(e) for s, e in ev) * 1e3 / max(1, len(ev)), len(ev)
 
 
@@ -203,6 +207,22 @@ def main():
     if os.path.exists(tpath) and world == 1 and (T, M, H, E, k) == (4096, 2048, 2048, 64, 2):
         traffic = json.load(open(tpath)).get("expert_gemm_fc1_hbm_bytes_per_launch")
 
+    fc2_obj = {"avg_launch_us": round(fc2_us, 2), "achieved_GBs": round(fc2_bytes / max(fc2_us, 1e-9) * 1e-3, 1),
+               "tflops": round(timer.flops[False] / max(fc2_us, 1e-9) * 1e-6, 1), "launches_timed": n2}
+    if timer.rows[True] >= 256:
+        # >= 256 rows per expert and launch (expert-parallel ranks): the 256 x 256-tile kernel, bound by the MFMA rate
+        tf = timer.flops[True] / fc1_us * 1e-6
+        roofline = {"bound": "mfma", "kernel": "expert_gemm_big_kernel<bf16,k-major,relu> (fc1 grouped GEMM, 256x256 tile, LDS-DMA)",
+                    "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "flops_per_launch": timer.flops[True], "rows_per_expert": timer.rows[True],
+                    "avg_launch_us": round(fc1_us, 2), "launches_timed": n1, "fc2_gemm": fc2_obj}
+    else:
+        roofline = {"bound": "hbm", "kernel": "expert_gemm_glds_kernel<bf16,k-major,relu> (fc1 grouped GEMM, LDS-DMA)",
+                    "achieved": round(fc1_bytes / fc1_us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(fc1_bytes / fc1_us * 1e-3 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": fc1_bytes, "avg_launch_us": round(fc1_us, 2), "launches_timed": n1,
+                    "fc2_gemm": fc2_obj, "mfma_tflops_fc1": round(timer.flops[True] / fc1_us * 1e-6, 1)}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * T / (elapsed / args.steps)
@@ -218,13 +238,7 @@ def main():
                        "capacity": C, "parallelism": f"ep{world}" if world > 1 else "single-gpu",
                        "a2a_ffn_overlap_degree": overlap, "fp32_gate": bool(args.fp32_gate),
                        "launch": "hip-graph replay" if (args.graph and world == 1) else "eager"},
-            "roofline": {"bound": "hbm", "kernel": "expert_gemm_glds_kernel<bf16,k-major,relu> (fc1 grouped GEMM, LDS-DMA)",
-                         "achieved": round(fc1_bytes / fc1_us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(fc1_bytes / fc1_us * 1e-3 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": fc1_bytes, "avg_launch_us": round(fc1_us, 2), "launches_timed": n1,
-                         "fc2_gemm": {"avg_launch_us": round(fc2_us, 2), "achieved_GBs": round(fc2_bytes / max(fc2_us, 1e-9) * 1e-3, 1),
-                                      "launches_timed": n2},
-                         "mfma_tflops_fc1": round(timer.flops[True] / fc1_us * 1e-6, 1)},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, M, H, E, k)

@@ -499,3 +499,32 @@ def test_low_precision_gate_layer_vs_oracle_on_its_own_scores(oracle, dtype):
     assert torch.equal(layer.dispatch_count.cpu(), crit[5])
     _close(y, yo, dtype)
     assert abs(float(y.l_aux) - float(lo)) <= 1e-2
+
+
+def test_eval_weight_prelayout_tracks_weight_updates(oracle):
+    """The eval path keeps a k-major copy of fc2's weights (experts/ffn.py KMajorCache).  It must follow
+    every in-place update of the parameter, equal the stored-layout path bit for bit, and be dropped by
+    train() / invalidate_prepacked()."""
+    T, M, H, E, k = 512, 128, 192, 4, 2
+    dtype = torch.bfloat16
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=2)
+    layer = make_layer(M, H, E, k, 1.0, dtype, weights, gate={"fp32_gate": True}).eval()
+    xd = x.cuda()
+    with torch.no_grad():
+        y1 = layer(xd)
+        assert "fc2" in layer.experts._kmajor._store
+        layer.train()          # training-mode module: stored layout, no copy
+        assert not layer.experts._kmajor._store
+        y1t = layer(xd)
+        assert torch.equal(y1, y1t), "k-major copy and stored layout give identical results"
+        layer.eval()
+        layer.experts.batched_fc2_w.mul_(2)      # in-place update bumps the version counter
+        y2 = layer(xd)
+        b2 = layer.experts.batched_fc2_bias.float().mean()
+        assert not torch.equal(y1, y2)
+        wg, w1, b1, w2, b2_ = weights
+        yo, *_ = oracle.moe_forward(x, wg, w1, b1, (w2.float() * 2).to(dtype), b2_, top_k=k, fp32_gate=True, accum_fp32=True)
+        _close(y2, yo, dtype)
+        layer.experts.batched_fc2_w.data.mul_(0.5)   # bypasses the version counter ...
+        layer.experts.invalidate_prepacked()         # ... so the documented call is needed
+        assert torch.equal(layer(xd), y1)

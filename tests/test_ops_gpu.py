@@ -176,7 +176,9 @@ def _gemm_tol(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("E,R,N,K", [(3, 100, 192, 128), (2, 128, 2048, 2048), (1, 300, 64, 64), (5, 1, 8, 64)])
+@pytest.mark.parametrize("E,R,N,K", [(3, 100, 192, 128), (2, 128, 2048, 2048), (1, 300, 64, 64), (5, 1, 8, 64),
+                                     # R >= 256 rows per expert: the 256 x 256-tile kernel (full, ragged, single k-tile)
+                                     (2, 256, 256, 128), (3, 300, 328, 192), (1, 1024, 512, 2048), (2, 257, 136, 64)])
 @pytest.mark.parametrize("kmajor", [True, False])
 @pytest.mark.parametrize("act", ["none", "relu"])
 def test_expert_gemm_vs_fp32_reference(dtype, E, R, N, K, kmajor, act):

@@ -82,6 +82,14 @@ def main():
     rec("expert_gemm1 C4 shape (8x1024x4096x4096)", timeit(lambda: ops.expert_gemm(a4, w4, None, True, act="relu"), iters=20), by4, f4)
     rec("expert_gemm2 C4 shape", timeit(lambda: ops.expert_gemm(a4, w4, None, False), iters=20), by4, f4)
     rec("torch.bmm C4 shape (yardstick)", timeit(lambda: torch.matmul(a4, w4), iters=20), by4, f4)
+    # per-rank shapes of the expert-parallel runs at the headline config (M = H = 2048): N = 2 / 4 / 8 ranks
+    for El2, R2 in ((32, 256), (16, 512), (8, 1024)):
+        a2 = torch.randn([El2, R2, M], generator=g).to(dtype).to(dev)
+        f2 = 2 * El2 * R2 * M * H
+        by2 = (El2 * H * M + 2 * El2 * R2 * M) * s
+        rec(f"expert_gemm1 EP shape ({El2}x{R2}x{H}x{M})", timeit(lambda: ops.expert_gemm(a2, w1[:El2], b1[:El2], True, act="relu"), iters=20), by2, f2)
+        rec(f"expert_gemm2 EP shape ({El2}x{R2})", timeit(lambda: ops.expert_gemm(a2, w2[:El2], b2[:El2], False), iters=20), by2, f2)
+        rec(f"torch.bmm EP shape ({El2}x{R2}) (yardstick)", timeit(lambda: torch.matmul(a2, w2[:El2]), iters=20), by2, f2)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "kernel_bench.json"), "w") as f:

@@ -64,13 +64,14 @@ template <int ACT> __device__ __forceinline__ float activate(float v) {
 // branch-free with clamped addresses: in the epilogue the same loads sat inside divergent
 // `continue` branches and hipcc serialised them -- 16 x (global_load_dwordx2 ; s_waitcnt vmcnt(0))
 // per block, i.e. 16 exposed memory round trips shared by every variant of the kernel.
-#define GM_PRELOAD_BIAS()                                                                         \
-  uint2 bias_r[2][4];                                                                             \
+#define GM_PRELOAD_BIAS() GM_PRELOAD_BIAS_N(2)
+#define GM_PRELOAD_BIAS_N(NI_)                                                                    \
+  uint2 bias_r[NI_][4];                                                                           \
   {                                                                                               \
     const uint16_t *be_ = p.bias ? reinterpret_cast<const uint16_t *>(p.bias) + (size_t)e * p.bias_stride_e : nullptr; \
-    _Pragma("unroll") for (int ni_ = 0; ni_ < 2; ++ni_)                                           \
+    _Pragma("unroll") for (int ni_ = 0; ni_ < NI_; ++ni_)                                         \
       _Pragma("unroll") for (int rg_ = 0; rg_ < 4; ++rg_) {                                       \
-        int n_ = n0 + wn * 64 + ni_ * 32 + rg_ * 8 + kg * 4;                                      \
+        int n_ = n0 + wn * (NI_ * 32) + ni_ * 32 + rg_ * 8 + kg * 4;                              \
         n_ = n_ < p.N ? n_ : p.N - 4;                                                             \
         bias_r[ni_][rg_] = be_ ? *reinterpret_cast<const uint2 *>(be_ + n_) : make_uint2(0u, 0u); \
       }                                                                                           \
@@ -91,8 +92,8 @@ struct GemmArgs {
 // ---- epilogue shared by both kernels: lane holds, per accumulator, row m = l31, features
 // 8*rg + 4*kg + 0..3.  D = act(acc + bias) [* mul], rounded once to T; `mul` (optional) has D's
 // layout and is the gating operand of a GLU expert (llama_ffn.py:40).
-template <typename T, int ACT>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, f32x16 (&acc)[2][2], uint2 (&bias_r)[2][4],
+template <typename T, int ACT, int NI = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, f32x16 (&acc)[NI][2], uint2 (&bias_r)[NI][4],
                                               int e, int m0, int n0, int wm, int wn, int l31, int kg,
                                               int row_limit) {
   uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;
@@ -105,10 +106,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, f32x16 (&acc)[2
     const size_t roff = (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
     uint16_t *drow = De + roff;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + wn * 64 + ni * 32 + rg * 8 + kg * 4;
+        const int n = n0 + wn * (NI * 32) + ni * 32 + rg * 8 + kg * 4;
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
@@ -260,7 +261,10 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
   const int nk = p.K / BK;
   // ROT: stagger the K-tile order per block so concurrently running blocks (same expert, other
   // N-tiles; other experts) are not all at the same k offset of 4 KB-strided rows at once.
-  const int rot = ROT ? (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk) : 0;
+  // K-tile rotation per PAIR of N-tiles: the 256-column kernel below shares one token tile between the
+  // pair and therefore one k order; using the same order here makes every kernel produce bit-identical
+  // sums for a given output element, whatever tile size the row count selects
+  const int rot = ROT ? (int)(((long long)((nt >> 1) + 3 * e) * nk / ((p.ntn + 1) >> 1)) % nk) : 0;
 
   // Prefetch registers: straight-line unrolled code over fixed-size arrays (no lambdas, no
   // conditionals around the loads -- hipcc otherwise demotes them to scratch / waits vmcnt(0)).
@@ -471,7 +475,10 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
   const int wt_c1 = (((c_lo + 4) ^ (q4 << 2)) << 3) + (i16 & 1) * 4;    // ni = 1
 
   const int nk = p.K / GL_BK;
-  const int rot = ROT ? (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk) : 0;
+  // K-tile rotation per PAIR of N-tiles: the 256-column kernel below shares one token tile between the
+  // pair and therefore one k order; using the same order here makes every kernel produce bit-identical
+  // sums for a given output element, whatever tile size the row count selects
+  const int rot = ROT ? (int)(((long long)((nt >> 1) + 3 * e) * nk / ((p.ntn + 1) >> 1)) % nk) : 0;
 
 #define GL_ISSUE(KT, BUF)                                                              \
   do {                                                                                 \
@@ -535,6 +542,192 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
 #undef GL_MMA
 
   gemm_epilogue<T, ACT>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
+}
+
+// -------------------------------------------------------------------------------------------
+// 256 x 256 tile variant for R >= 256 rows per expert (expert-parallel ranks, large batches).
+// There the GEMM is no longer bound by streaming the weights once from HBM but by the bytes that
+// cross L2 -> CU per flop: a 128 x 128 tile moves (128+128)*2 B per 2*128*128 flop per unit of k
+// = 64 flop/B, and at the ~36 GB/s per CU that path delivers (measured with the gate-projection
+// probes) that is ~590 TFLOP/s chip-wide -- what the 128 x 128 kernels reach (650).
+// 256 x 256 doubles the intensity.  Same LDS-DMA structure and swizzles as above:
+//   8 waves = 4 (64-row groups) x 2 (128-column groups); wave tile 64 x 128 = 2 x 4 MFMA 32x32x16
+//   tiles (128 accumulator registers); LDS stage = token tile [256][64] 32 KB + two [128n][64k]
+//   (or [64k][128n]) weight sub-tiles 2 x 16 KB; 2 stages = 128 KB, one block per CU.
+// -------------------------------------------------------------------------------------------
+#define GB_BM 256
+#define GB_BN 256
+#define GB_THREADS 512
+#define GB_LDS_BYTES ((size_t)2 * 4 * GL_STAGE * 2)
+
+template <typename T, bool W_KMAJOR, int ACT>
+__global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [2][2 * GL_STAGE]   (256 rows x 64 k)
+  uint16_t *sW = sA + 4 * GL_STAGE;                   // [2][2][GL_STAGE]    (two 128-column sub-tiles)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;     // compute roles
+  const int dg = wid >> 2, dw4 = wid & 3;    // DMA roles for the weight sub-tiles
+
+  const int nb = gridDim.x;
+  int w;
+  {
+    const int b = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = b & 7, pos = b >> 3;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int mt = w % p.ntm;
+  const int nt = (w / p.ntm) % p.ntn;
+  const int e = w / (p.ntm * p.ntn);
+  const int m0 = mt * GB_BM, n0 = nt * GB_BN;
+
+  int row_limit = p.R;
+  if (p.row_counts != nullptr) {
+    int c = p.row_counts[e];
+    c = (c + p.row_align - 1) / p.row_align * p.row_align;
+    row_limit = min(row_limit, c);
+  }
+  if (m0 >= row_limit) return;
+
+  const uint16_t *Ae = reinterpret_cast<const uint16_t *>(p.A) + (size_t)e * p.a_stride_e;
+  const uint16_t *We = reinterpret_cast<const uint16_t *>(p.W) + (size_t)e * p.w_stride_e;
+
+  // DMA sources: token tile pieces j = wid*4 + i (rows 8j..8j+7 of 256); weight sub-tile dg, pieces dw4*4 + i
+  const uint16_t *a_src[4], *w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    {
+      const int r = 8 * (wid * 4 + i) + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      const int gr = min(m0 + r, p.R - 1);
+      a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + c * 8;
+      if (p.a_rows != nullptr) {
+        const int q = p.a_rows[(size_t)e * p.R + gr];
+        a_src[i] = (q >= 0 ? reinterpret_cast<const uint16_t *>(p.A) + (size_t)(q % p.a_rows_mod) * p.lda
+                           : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;
+      }
+    }
+    if (W_KMAJOR) {
+      const int r = 8 * (dw4 * 4 + i) + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      const int gn = min(n0 + dg * GM_BN + r, p.N - 1);
+      w_src[i] = We + (size_t)gn * p.ldw + c * 8;
+    } else {
+      const int kr = 4 * (dw4 * 4 + i) + (lane >> 4);
+      const int cn = (lane & 15) ^ ((kr & 3) << 2);
+      const int gn = min(n0 + dg * GM_BN + cn * 8, p.N - 8);
+      w_src[i] = We + (size_t)kr * p.ldw + gn;
+    }
+  }
+  const size_t w_step = W_KMAJOR ? (size_t)GL_BK : (size_t)GL_BK * p.ldw;
+  const int piece_a = wid * 4 * 512, piece_w = dw4 * 4 * 512;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, kg = lane >> 5;
+  const int sw = (l31 >> 1) & 7;
+  int frag_k[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) frag_k[kk] = (((kk * 2 + kg) ^ sw) << 3);
+  const int a_row = (wm * 64 + l31) * GL_BK;  // + mi*32*64
+  const int wk_row = l31 * GL_BK;             // + ni*32*64, inside sub-tile wn
+  const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2;
+  const int c_lo = (g16 & 1) * 2 + ((i16 & 3) >> 1);
+  const int wt_row = ((g16 >> 1) * 8 + q4) * GM_BN;
+  int wt_c[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) wt_c[ni] = (((c_lo + 4 * ni) ^ (q4 << 2)) << 3) + (i16 & 1) * 4;
+
+  const int nk = p.K / GL_BK;
+  const int rot = (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk);
+
+#define GB_ISSUE(KT, BUF)                                                              \
+  do {                                                                                 \
+    int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
+    const size_t ao_ = (size_t)kr_ * GL_BK, wo_ = (size_t)kr_ * w_step;                \
+    uint16_t *da_ = sA + (BUF) * 2 * GL_STAGE + piece_a, *dw_ = sW + ((BUF) * 2 + dg) * GL_STAGE + piece_w; \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, false); \
+  } while (0)
+#define GB_LOAD_FRAGS(FA, FW, KK)                                                      \
+  do {                                                                                 \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                   \
+      FA[mi] = *reinterpret_cast<const u32x4 *>(ca + a_row + mi * 32 * GL_BK + frag_k[KK]); \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) {                                 \
+      if (W_KMAJOR) {                                                                  \
+        FW[ni] = *reinterpret_cast<const u32x4 *>(cw + wk_row + ni * 32 * GL_BK + frag_k[KK]); \
+      } else {                                                                         \
+        const uint16_t *ptr = cw + wt_row + (KK) * 16 * GM_BN + wt_c[ni];              \
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
+            (__attribute__((address_space(3))) s16x4_t *)(ptr));                       \
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                          \
+            (__attribute__((address_space(3))) s16x4_t *)(ptr + 4 * GM_BN));           \
+        u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi); \
+        u32x4 f = {lo2[0], lo2[1], hi2[0], hi2[1]};                                    \
+        FW[ni] = f;                                                                    \
+      }                                                                                \
+    }                                                                                  \
+  } while (0)
+#define GB_MMA(FA, FW)                                                                 \
+  do {                                                                                 \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
+        acc[ni][mi] = Mma<T>::run(FW[ni], FA[mi], acc[ni][mi]);                        \
+  } while (0)
+
+  GB_ISSUE(0, 0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) GB_ISSUE(kt + 1, buf ^ 1);
+    const uint16_t *ca = sA + buf * 2 * GL_STAGE, *cw = sW + (buf * 2 + wn) * GL_STAGE;
+    // two half-tiles: fragments of two k-steps (48 registers), then their 16 MFMAs; the partner wave
+    // on the SIMD runs its MFMAs while this one waits for LDS
+    u32x4 fa[2][2], fw[2][4];
+    GB_LOAD_FRAGS(fa[0], fw[0], 0);
+    GB_LOAD_FRAGS(fa[1], fw[1], 1);
+    __builtin_amdgcn_sched_barrier(0);
+    GB_MMA(fa[0], fw[0]);
+    GB_MMA(fa[1], fw[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    GB_LOAD_FRAGS(fa[0], fw[0], 2);
+    GB_LOAD_FRAGS(fa[1], fw[1], 3);
+    __builtin_amdgcn_sched_barrier(0);
+    GB_MMA(fa[0], fw[0]);
+    GB_MMA(fa[1], fw[1]);
+    __syncthreads();
+  }
+#undef GB_ISSUE
+#undef GB_LOAD_FRAGS
+#undef GB_MMA
+
+  GM_PRELOAD_BIAS_N(4);
+  gemm_epilogue<T, ACT, 4>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
+}
+
+template <typename T, bool KM, int ACT>
+static int launch_big(const GemmArgs &a, hipStream_t st) {
+  GemmArgs b = a;
+  b.ntm = (a.R + GB_BM - 1) / GB_BM;
+  b.ntn = (a.N + GB_BN - 1) / GB_BN;
+  auto kern = expert_gemm_big_kernel<T, KM, ACT>;
+  static bool optin = false;
+  if (!optin) {
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS_BYTES);
+    (void)hipGetLastError();
+    optin = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.E_loc * b.ntm * b.ntn), dim3(GB_THREADS), GB_LDS_BYTES, st, b);
+  TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
+  return 0;
 }
 
 template <typename T, bool KM, int ACT>
@@ -605,6 +798,10 @@ template <typename T, bool KM, int ACT>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   static int impl = -2;
   if (impl == -2) { const char *s = getenv("TUTEL_AMD_GEMM_IMPL"); impl = s ? atoi(s) : -1; }
+  static int big = -2;
+  if (big == -2) { const char *s = getenv("TUTEL_AMD_GEMM_BIG"); big = s ? atoi(s) : -1; }
+  // R >= 256 rows per expert: the 256 x 256 tile (twice the flop per byte crossing L2 -> CU)
+  if ((big < 0 ? a.R >= GB_BM : big == 1) && a.N >= GM_BN) return launch_big<T, KM, ACT>(a, st);
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
   return launch_cfg<T, KM, ACT, 64, 2, 2, true, true, false>(a, grid, st);

@@ -7,7 +7,9 @@ Parameters keep the reference's names and shapes (checkpoint compatible, SURVEY 
 Forward, y = act(x @ W1^T + b1) @ W2 + b2 per local expert, x [E_loc, R, M]:
   * bf16 / fp16, no autograd, recognised activation -> two launches of the MFMA grouped GEMM
     (tutel_amd_expert_gemm): bias + activation fused into the first, bias into the second,
-    W2 consumed in its stored [H, M_out] layout, dropless row counts honoured on device;
+    dropless row counts honoured on device.  W2 is stored [H, M_out] (checkpoint format); the kernel
+    takes that layout as is (training-mode modules) or, in eval mode, a k-major copy laid out once
+    (KMajorCache below);
   * anything else (fp32/fp64 experts, training, arbitrary python activation, sharded experts)
     -> ATen batched matmul (rocBLAS / hipBLASLt library GEMMs), op for op as the reference.
 """
@@ -19,6 +21,35 @@ import torch.nn.functional as F
 from .. import net, ops
 
 _PROBE = torch.tensor([-3.0, -1.0, -0.25, 0.0, 0.25, 0.5, 1.0, 2.0, 4.0])
+# eval-mode weight pre-layout: keep a [E, N, K] (k-major) copy of weights stored [E, K, N]; 0 disables
+_PREPACK = int(os.environ.get("TUTEL_AMD_PREPACK", "1")) != 0
+
+
+class KMajorCache:
+    """k-major ([E, N, K] contiguous) copies of weights the checkpoint format stores [E, K, N].
+
+    The MFMA operand layout wants 8 consecutive k per lane: a k-major tile is read from LDS with one
+    ds_read_b128 per fragment, an n-major tile needs two transposing ds_read_b64_tr_b16 -- measured
+    +3 us of 118 at the headline shape and +20 % at >= 256 rows per expert.  Inference weights are
+    static, so the fused (no-autograd, eval) path lays them out once.  A copy is rebuilt whenever the
+    parameter's storage pointer, autograd version counter (bumped by every in-place op on the
+    parameter: optimizer steps, copy_, load_state_dict), dtype, device or shape changes.  Writes
+    made through `param.data` bypass the version counter: call `invalidate()` (or
+    `module.train()`; or set TUTEL_AMD_PREPACK=0) after such a write."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, name, w):
+        key = (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
+        hit = self._store.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, w.detach().transpose(1, 2).contiguous())
+            self._store[name] = hit
+        return hit[1]
+
+    def invalidate(self):
+        self._store.clear()
 
 
 def classify_activation(fn):
@@ -64,6 +95,7 @@ class FusedExpertsNetwork(torch.nn.Module):
             activation_fn = F.relu
         self.activation_fn = activation_fn
         self._act_cache = {}
+        self._kmajor = KMajorCache()
 
         E, H = num_experts_per_device, self.hidden_size
         self.batched_fc1_w = torch.nn.Parameter(torch.empty(E, H, model_dim))
@@ -134,8 +166,27 @@ class FusedExpertsNetwork(torch.nn.Module):
         b2 = self.batched_fc2_bias
         if b2 is not None and b2.size(-1) != self.output_dim:
             b2 = b2[:, :self.output_dim].contiguous()
+        if _PREPACK and not self.training:
+            return ops.expert_gemm(h, self._kmajor.get("fc2", self.batched_fc2_w), b2, True, out=out,
+                                   d_layout=d_layout, row_counts=counts, row_align=align)
         return ops.expert_gemm(h, self.batched_fc2_w, b2, False, out=out, d_layout=d_layout,
                                row_counts=counts, row_align=align)
+
+    def invalidate_prepacked(self):
+        """Drop the eval-mode k-major weight copies (needed only after writes through `param.data`)."""
+        self._kmajor.invalidate()
+
+    def train(self, mode=True):
+        self._kmajor.invalidate()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._kmajor.invalidate()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._kmajor.invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
 
     # -- reference-equivalent ATen path -----------------------------------------------------
     def forward(self, x, ctx):

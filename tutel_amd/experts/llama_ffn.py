@@ -16,7 +16,7 @@ Forward:
 import torch
 
 from .. import net, ops
-from .ffn import classify_activation
+from .ffn import KMajorCache, classify_activation, _PREPACK
 
 
 class LlamaFFNNetwork(torch.nn.Module):
@@ -41,6 +41,7 @@ class LlamaFFNNetwork(torch.nn.Module):
         self.W_fc3, self.W_fc3_full_shape = self._create_sharded_param(num_experts_per_device, hidden_size_per_expert, model_dim)
         self.activation_fn = activation_fn
         self._act_cache = {}
+        self._kmajor = KMajorCache()
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -72,9 +73,27 @@ class LlamaFFNNetwork(torch.nn.Module):
     def forward_fused(self, x):
         w1, w2, w3 = (self.W_fc1.view(self.W_fc1_full_shape), self.W_fc2.view(self.W_fc2_full_shape),
                       self.W_fc3.view(self.W_fc3_full_shape))
-        g = ops.expert_gemm(x, w1, None, False, act=self.fused_activation())
-        h = ops.expert_gemm(x, w2, None, False, mul=g)
-        return ops.expert_gemm(h, w3, None, False)
+        km = _PREPACK and not self.training  # eval: weights laid out k-major once (see KMajorCache)
+        if km:
+            w1, w2, w3 = self._kmajor.get("fc1", w1), self._kmajor.get("fc2", w2), self._kmajor.get("fc3", w3)
+        g = ops.expert_gemm(x, w1, None, km, act=self.fused_activation())
+        h = ops.expert_gemm(x, w2, None, km, mul=g)
+        return ops.expert_gemm(h, w3, None, km)
+
+    def invalidate_prepacked(self):
+        self._kmajor.invalidate()
+
+    def train(self, mode=True):
+        self._kmajor.invalidate()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._kmajor.invalidate()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._kmajor.invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
 
     # -- reference-equivalent ATen path -----------------------------------------------------
     def forward(self, x, ctx):
