@@ -125,10 +125,16 @@ int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *slot_map, con
  * chunk_rows = 0: buf is the plain [E, C, M] bucket array (row e*C + l).
  * chunk_rows = c > 0 (c divides C): buf is CHUNK-MAJOR [C/c, E, c, M] -- the layout in which the
  *   overlapped all-to-all (overlap.py: capacity split into a2a_ffn_overlap_degree chunks) delivers
- *   the expert outputs, so no torch.cat copy is needed: row ((l/c)*num_experts + e)*c + l%c. */
+ *   the expert outputs, so no torch.cat copy is needed: row ((l/c)*num_experts + e)*c + l%c.
+ * expert_slice = s > 0 (chunk_rows must be 0; s divides num_experts / ep_world): buf is
+ *   EXPERT-SLICED [E_loc/s, W, s, C, M] with W = ep_world, E_loc = num_experts / W -- the layout of
+ *   the overlapped all-to-all that pipelines over groups of s local experts (each expert's weights
+ *   are then streamed once and its GEMM sees all W*C rows): global expert e = w*E_loc + el lives at
+ *   bucket ((el/s)*W + w)*s + el%s.  expert_slice = 0: ep_world is ignored. */
 int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *idx, const int32_t *loc,
                           const void *gates, int gate_dtype, int T, int M, int k, int capacity,
-                          int num_experts, int chunk_rows, void *out, tutel_stream_t stream);
+                          int num_experts, int chunk_rows, int expert_slice, int ep_world, void *out,
+                          tutel_stream_t stream);
 
 /* Gate gradient (backward only).  Replaces the `backward_gate` kernel
  * (sparse.py:71-133 | custom_kernel.cpp:313-322):

@@ -51,10 +51,11 @@ def test_argument_errors_are_reported_not_enqueued(L):
     assert L.tutel_amd_expert_gemm(None, 0, 0, 1, 0, None, 1, 0, 0, None, 0, None, 0, 0, 1, 0, 1, 1, 8, 100, 2, 0, None, 1, None) != 0
     assert L.tutel_amd_expert_gemm(None, 0, 0, 1, 0, None, 1, 0, 0, None, 0, None, 0, 0, 1, 0, 1, 1, 8, 64, 0, 0, None, 1, None) != 0
     with pytest.raises(_lib.TutelAmdError):
-        _lib.check(L.tutel_amd_fast_decode(None, 7, None, None, None, 0, 1, 1, 1, 1, 0, 0, None, None), "decode")
+        _lib.check(L.tutel_amd_fast_decode(None, 7, None, None, None, 0, 1, 1, 1, 1, 0, 0, 0, 1, None, None), "decode")
     # empty problems are a no-op success (nothing to launch)
-    assert L.tutel_amd_fast_decode(None, 0, None, None, None, 0, 0, 8, 2, 4, 0, 0, None, None) == 0
-    assert L.tutel_amd_fast_decode(None, 0, None, None, None, 0, 4, 8, 2, 6, 3, 4, None, None) != 0  # chunk must divide capacity
+    assert L.tutel_amd_fast_decode(None, 0, None, None, None, 0, 0, 8, 2, 4, 0, 0, 0, 1, None, None) == 0
+    assert L.tutel_amd_fast_decode(None, 0, None, None, None, 0, 4, 8, 2, 6, 3, 4, 0, 1, None, None) != 0  # chunk must divide capacity
+    assert L.tutel_amd_fast_decode(None, 0, None, None, None, 0, 4, 8, 2, 6, 8, 0, 3, 2, None, None) != 0  # slice must divide E_loc
     assert L.tutel_amd_expert_gemm(None, 0, 0, 1, 0, None, 1, 0, 0, None, 0, None, 0, 0, 1, 0, 0, 0, 8, 64, 2, 0, None, 1, None) == 0
 
 

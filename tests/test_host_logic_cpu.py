@@ -334,3 +334,58 @@ def test_sharded_expert_modes_world2_gloo():
         p.join(timeout=60)
     for rank, ok, info in res:
         assert ok, f"rank {rank}: {info}"
+
+
+@pytest.mark.parametrize("W,E_loc,Cap,degree", [(2, 4, 8, 2), (4, 2, 6, 2), (8, 8, 4, 4), (2, 3, 8, 2), (4, 1, 8, 4), (2, 6, 12, 4)])
+def test_overlap_plan_layouts_replayed_for_many_ranks(oracle, W, E_loc, Cap, degree):
+    """The copy-free overlapped pipeline only ever runs with W > 1 on a multi-GPU node.  Its buffer
+    layouts (impls/overlap.py::OverlapPlan: permuted slot map, stage messages, GEMM row addressing,
+    decode addressing) are replayed here with integer tags for every rank: each expert must see exactly
+    the rows the reference's all_to_all + pre_expert_permute gives it (oracle.a2a_dispatch), and decode
+    must find every bucket's result."""
+    from tutel_amd.impls.overlap import OverlapPlan
+    E = W * E_loc
+    plan = OverlapPlan(E, W, Cap, degree)
+    assert plan.sliced == (E_loc >= degree and E_loc % degree == 0)
+    tag = lambda r, e, l: (r * E + e) * Cap + l                                   # noqa: E731
+    buckets = [torch.tensor([[tag(r, e, l) for l in range(Cap)] for e in range(E)]) for r in range(W)]   # [E, Cap] per rank
+    want = oracle.a2a_dispatch([b.unsqueeze(-1).float() for b in buckets])        # per dest rank: [E_loc, W*Cap, 1]
+    enc = [plan.permute_slots(b.reshape(-1)).view(degree, W, plan.rows) for b in buckets]   # what fast_encode writes
+    se, sw, rpw, ld = plan.row_layout(1)
+
+    def rows_of(buf, j):  # the GEMM's view of expert j in a stage buffer
+        m = torch.arange(plan.R)
+        return buf.reshape(-1)[j * se + (m // rpw) * sw + (m % rpw) * ld]
+
+    out_all = [torch.full([degree, W * plan.rows], -1) for _ in range(W)]
+    for i in range(degree):
+        # all_to_all_single on dim-0 blocks: rank d receives block d of every source rank
+        recv = [torch.stack([enc[src][i][d] for src in range(W)]) for d in range(W)]   # [W(src), rows]
+        send = []
+        for d in range(W):
+            n_exp = plan.s
+            buf = torch.full([W * plan.rows], -1)
+            for j in range(n_exp):
+                got = rows_of(recv[d], j)
+                el = plan.expert_range(i)[0] + j if plan.sliced else j
+                exp_rows = want[d][el, :, 0].long().view(W, Cap)
+                exp_rows = exp_rows if plan.sliced else exp_rows[:, i * plan.c:(i + 1) * plan.c]
+                assert torch.equal(got, exp_rows.reshape(-1)), (i, d, j)
+                m = torch.arange(plan.R)
+                buf[j * se + (m // rpw) * sw + (m % rpw) * ld] = got            # identity "expert", written through d_layout
+            send.append(buf.view(W, plan.rows))
+        for r in range(W):
+            out_all[r][i] = torch.cat([send[d][r] for d in range(W)])           # return all_to_all into slice i
+    # decode addressing (mirror of decode_kernel's row formula)
+    kw = plan.decode_kwargs
+    for r in range(W):
+        flat = out_all[r].reshape(-1)
+        for e in range(E):
+            for l in range(Cap):
+                if kw.get("expert_slice", 0) > 0:
+                    s, el, w = kw["expert_slice"], e % E_loc, e // E_loc
+                    row = (((el // s) * W + w) * s + el % s) * Cap + l
+                else:
+                    c = kw["chunk_rows"]
+                    row = ((l // c) * E + e) * c + l % c
+                assert int(flat[row]) == tag(r, e, l)

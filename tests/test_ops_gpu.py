@@ -335,3 +335,27 @@ def test_expert_gemm_gather_equals_encode_then_gemm(oracle, dtype, T, E, k, M, H
     got = ops.expert_gemm_gather(x, smap, w, b, True, "relu", C)
     assert torch.equal(got, want)
     assert cf < 1.0 or int((smap < 0).sum()) > 0, "cf >= 1 leaves empty slots: the zero-row path must be exercised"
+
+
+@pytest.mark.parametrize("W,E_loc,s", [(1, 8, 2), (2, 4, 2), (4, 2, 1), (8, 8, 4), (2, 6, 3)])
+def test_decode_expert_sliced_layout(oracle, W, E_loc, s):
+    """fast_decode(expert_slice=s, ep_world=W) on buckets stored [E_loc/s, W, s, C, M] == plain decode of [E, C, M]
+    (bit for bit); the layout is the one OverlapPlan builds (tests/test_host_logic_cpu.py replays its index
+    algebra for W > 1 on CPU)."""
+    from tutel_amd import ops
+    from tutel_amd.impls.overlap import OverlapPlan
+    E, k, T, M = W * E_loc, 2, 777, 96
+    g = torch.Generator().manual_seed(W * 100 + E_loc)
+    scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
+    crit, _ = oracle.extract_critical(scores, k, 1.0)
+    Cap = crit[4]
+    buf = torch.randn([E, Cap, M], generator=g).to(torch.bfloat16)
+    idx, loc = torch.stack(crit[1]).cuda(), torch.stack(crit[2]).cuda()
+    gates = torch.stack(crit[3]).to(torch.bfloat16).cuda()
+    plain = ops.fast_decode(buf.view(E * Cap, M).cuda(), idx, loc, gates, Cap)
+    plan = OverlapPlan(E, W, Cap, E_loc // s)
+    assert plan.sliced and plan.s == s
+    order = plan.permute_slots(torch.arange(E * Cap))       # position p holds plain bucket row order[p]
+    sliced = buf.view(E * Cap, M)[order].contiguous().cuda()
+    got = ops.fast_decode(sliced, idx, loc, gates, Cap, **plan.decode_kwargs)
+    assert torch.equal(plain, got)

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
                                                            const void *__restrict__ gates,
                                                            int gate_dtype, int Tn, int M, int k,
                                                            int capacity, int num_experts,
-                                                           int chunk_rows, T *__restrict__ out) {
+                                                           int chunk_rows, int expert_slice,
+                                                           int ep_world, T *__restrict__ out) {
   constexpr int VN = Vec<T>::N;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
@@ -119,7 +120,12 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
       if (j < k) {
         int e = idx[(size_t)j * Tn + t], l = loc[(size_t)j * Tn + t];
         if (l < capacity && e >= 0 && l >= 0) {
-          // bucket row: [E][C] (plain) or chunk-major [C/c][E][c] (overlapped all-to-all layout)
+          // bucket row: [E][C] (plain), chunk-major [C/c][E][c], or expert-sliced [E_loc/s][W][s][C]
+          // (the two layouts of the overlapped all-to-all)
+          if (expert_slice > 0) {
+            const int e_loc = num_experts / ep_world, w = e / e_loc, el = e % e_loc;
+            e = ((el / expert_slice) * ep_world + w) * expert_slice + el % expert_slice;
+          }
           size_t r = (chunk_rows > 0) ? ((size_t)(l / chunk_rows) * num_experts + e) * chunk_rows + (l % chunk_rows)
                                       : (size_t)e * capacity + l;
           rows[j] = buf + r * M;
@@ -251,10 +257,10 @@ extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *sl
 
 template <typename T>
 static void launch_decode(const void *buf, const int32_t *idx, const int32_t *loc, const void *gates,
-                          int gate_dtype, int Tn, int M, int k, int capacity, int num_experts, int chunk_rows,
-                          void *out, hipStream_t st) {
+                          int gate_dtype, int Tn, int M, int k, int capacity, int num_experts, int chunk_rows, int expert_slice,
+                          int ep_world, void *out, hipStream_t st) {
   int grid = dp_grid(Tn);
-#define DEC(KM) hipLaunchKernelGGL((decode_kernel<T, KM>), dim3(grid), dim3(DP_THREADS), 0, st, (const T *)buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, num_experts, chunk_rows, (T *)out)
+#define DEC(KM) hipLaunchKernelGGL((decode_kernel<T, KM>), dim3(grid), dim3(DP_THREADS), 0, st, (const T *)buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, (T *)out)
   if (k <= 1) DEC(1);
   else if (k <= 2) DEC(2);
   else if (k <= 4) DEC(4);
@@ -266,19 +272,23 @@ static void launch_decode(const void *buf, const int32_t *idx, const int32_t *lo
 extern "C" int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *idx,
                                      const int32_t *loc, const void *gates, int gate_dtype, int T,
                                      int M, int k, int capacity, int num_experts, int chunk_rows,
-                                     void *out, tutel_stream_t stream) {
+                                     int expert_slice, int ep_world, void *out, tutel_stream_t stream) {
   TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_fast_decode: unsupported dtype %d", dtype);
   TUTEL_REQUIRE(gates == nullptr || dtype_ok(gate_dtype), "tutel_amd_fast_decode: unsupported gate dtype %d", gate_dtype);
   TUTEL_REQUIRE(T >= 0 && M >= 1 && k >= 1 && k <= 16 && capacity >= 0, "tutel_amd_fast_decode: bad sizes T=%d M=%d k=%d C=%d", T, M, k, capacity);
   TUTEL_REQUIRE(chunk_rows >= 0 && (chunk_rows == 0 || (num_experts >= 1 && capacity % chunk_rows == 0)),
                 "tutel_amd_fast_decode: chunk_rows=%d must divide capacity=%d (num_experts=%d)", chunk_rows, capacity, num_experts);
+  TUTEL_REQUIRE(expert_slice >= 0 && (expert_slice == 0 || (chunk_rows == 0 && ep_world >= 1 && num_experts >= 1 &&
+                                                         num_experts % ep_world == 0 && (num_experts / ep_world) % expert_slice == 0)),
+                "tutel_amd_fast_decode: expert_slice=%d must divide the %d local experts of each of %d ranks (and excludes chunk_rows)",
+                expert_slice, ep_world > 0 ? num_experts / ep_world : 0, ep_world);
   if (T == 0) return 0;
   TUTEL_REQUIRE(idx && loc && out && (buf || capacity == 0), "tutel_amd_fast_decode: null pointer");
   TUTEL_REQUIRE(((uintptr_t)buf % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_amd_fast_decode: buf/out must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TUTEL_F32) launch_decode<float>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, out, st);
-  else if (dtype == TUTEL_BF16) launch_decode<bf16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, out, st);
-  else launch_decode<f16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, out, st);
+  if (dtype == TUTEL_F32) launch_decode<float>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
+  else if (dtype == TUTEL_BF16) launch_decode<bf16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
+  else launch_decode<f16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
   TUTEL_CHECK_LAUNCH("tutel_amd_fast_decode");
   return 0;
 }

@@ -148,29 +148,34 @@ class FusedExpertsNetwork(torch.nn.Module):
         return (ops.gemm_supported(w1.dtype, w1.size(1), w1.size(2)) and
                 ops.gemm_supported(w2.dtype, w2.size(2), w2.size(1)) and self.fused_activation() is not None)
 
-    def forward_fused(self, x, ctx, a_layout=None, R=None, out=None, d_layout=None, slot_map=None):
+    def forward_fused(self, x, ctx, a_layout=None, R=None, out=None, d_layout=None, slot_map=None, expert_range=None):
         """x [E_loc,R,M] (or the raw all-to-all buffer described by a_layout) -> [E_loc,R,M_out]
         (or written into `out` in d_layout).  Two MFMA grouped-GEMM launches.
         slot_map given: x is the TOKEN array [T,M] and fc1 gathers its rows through the slot map
-        (fast_encode fused into the GEMM; R = capacity)."""
+        (fast_encode fused into the GEMM; R = capacity).
+        expert_range = (lo, hi): only local experts lo..hi-1 (x / out then hold hi-lo experts)."""
         counts, align = None, 1
         if getattr(ctx, "megablocks_size", 0) > 0:
             counts, align = ctx.dispatch_count, int(ctx.megablocks_size)
-        if slot_map is not None:
-            h = ops.expert_gemm_gather(x, slot_map, self.batched_fc1_w, self.batched_fc1_bias, True,
-                                       self.fused_activation(), R, row_counts=counts, row_align=align)
-        else:
-            h = ops.expert_gemm(x, self.batched_fc1_w, self.batched_fc1_bias, True, act=self.fused_activation(),
-                                E_loc=self.batched_fc1_w.size(0), R=R, a_layout=a_layout,
-                                row_counts=counts, row_align=align)
-        b2 = self.batched_fc2_bias
+        w1, b1, w2, b2 = self.batched_fc1_w, self.batched_fc1_bias, self.batched_fc2_w, self.batched_fc2_bias
+        w2_kmajor = _PREPACK and not self.training
+        if w2_kmajor:
+            w2 = self._kmajor.get("fc2", w2)
         if b2 is not None and b2.size(-1) != self.output_dim:
             b2 = b2[:, :self.output_dim].contiguous()
-        if _PREPACK and not self.training:
-            return ops.expert_gemm(h, self._kmajor.get("fc2", self.batched_fc2_w), b2, True, out=out,
-                                   d_layout=d_layout, row_counts=counts, row_align=align)
-        return ops.expert_gemm(h, self.batched_fc2_w, b2, False, out=out, d_layout=d_layout,
-                               row_counts=counts, row_align=align)
+        if expert_range is not None:
+            lo, hi = expert_range
+            w1, w2 = w1[lo:hi], w2[lo:hi]
+            b1 = b1[lo:hi] if b1 is not None else None
+            b2 = b2[lo:hi] if b2 is not None else None
+            assert counts is None, "megablocks row counts are not sliced"
+        if slot_map is not None:
+            h = ops.expert_gemm_gather(x, slot_map, w1, b1, True, self.fused_activation(), R,
+                                       row_counts=counts, row_align=align)
+        else:
+            h = ops.expert_gemm(x, w1, b1, True, act=self.fused_activation(), E_loc=w1.size(0), R=R,
+                                a_layout=a_layout, row_counts=counts, row_align=align)
+        return ops.expert_gemm(h, w2, b2, w2_kmajor, out=out, d_layout=d_layout, row_counts=counts, row_align=align)
 
     def invalidate_prepacked(self):
         """Drop the eval-mode k-major weight copies (needed only after writes through `param.data`)."""

@@ -92,31 +92,75 @@ def _exchange(dst, src, group):
         dst.copy_(src)
 
 
+class OverlapPlan:
+    """Buffer layouts of the copy-free overlapped pipeline (pure index arithmetic; shared by
+    a2a_ffn_overlap_fused and by tests/test_host_logic_cpu.py, which replays it for W > 1 on CPU).
+
+    sliced:  stages = groups of s = E_loc/degree local experts; buckets laid out [degree, W, s, C]
+    chunked: stages = capacity chunks of c = C/degree rows;     buckets laid out [degree, E, c]
+    In both, stage i's message is [W, s, c] rows (dim 0 = destination rank), the GEMM addresses the
+    received [W(src), s, c] rows as `s` experts x (W*c) source-rank-major rows, and decode finds
+    bucket (e, l) through `decode_kwargs`."""
+
+    def __init__(self, E, W, Cap, degree, allow_sliced=True):
+        E_loc = E // W
+        self.E, self.W, self.Cap, self.degree = E, W, Cap, degree
+        self.sliced = bool(allow_sliced and E_loc >= degree and E_loc % degree == 0)
+        if self.sliced:
+            self.s, self.c = E_loc // degree, Cap
+            self._view, self._perm = (W, degree, self.s, Cap), (1, 0, 2, 3)
+            self.decode_kwargs = dict(num_experts=E, expert_slice=self.s, ep_world=W)
+        else:
+            self.s, self.c = E_loc, Cap // degree
+            self._view, self._perm = (E, degree, self.c), (1, 0, 2)
+            self.decode_kwargs = dict(num_experts=E, chunk_rows=self.c)
+        self.rows = self.s * self.c   # bucket rows per (stage, rank) block
+        self.R = W * self.c           # GEMM rows per expert and stage
+
+    def permute_slots(self, per_slot):
+        """[E*Cap] values in plain bucket order (e*Cap + l) -> the pipeline's bucket order."""
+        return per_slot.view(*self._view).permute(*self._perm).contiguous().view(-1)
+
+    def row_layout(self, ld):
+        """(stride_e, stride_w, rows_per_w, ld) of a stage buffer with rows of `ld` elements."""
+        return (self.c * ld, self.rows * ld, self.c, ld)
+
+    def expert_range(self, i):
+        return (i * self.s, (i + 1) * self.s) if self.sliced else None
+
+
 def a2a_ffn_overlap_fused(layer, x, crit, degree, is_postscore):
     """Overlapped encode -> all-to-all -> expert FFN -> all-to-all -> decode with NO layout copies.
 
     reference path (overlap.py:8-67 + communicate.py:606-622) per chunk: split view -> contiguous
-    copy -> a2a -> permute+contiguous -> FFN -> permute+contiguous -> a2a -> torch.cat.  Here:
-      * fast_encode writes the buckets CHUNK-MAJOR [degree, E, c, M] (only its slot map is
-        permuted), so chunk i is already the contiguous all-to-all message;
-      * the grouped GEMMs read the raw received buffer [W, E_loc, c, M] and write the raw send
-        buffer [W, E_loc, c, M_out] through their row addressing (rows_per_w = c);
-      * the return all-to-all lands in slice i of ONE [degree, E, c, M_out] buffer that
-        fast_decode addresses chunk-major.
-    Chunk i+1 is on the xGMI links (communication stream) while chunk i is in the GEMMs (caller's
+    copy -> a2a -> permute+contiguous -> FFN -> permute+contiguous -> a2a -> torch.cat, with the
+    CAPACITY dimension cut into `degree` chunks.  Two pipelines here, both without copies:
+
+    expert-sliced (E_loc % degree == 0): the pipeline runs over groups of s = E_loc/degree local
+      experts.  fast_encode writes the buckets [degree, W, s, C, M] (only its slot map is permuted),
+      so stage i is the contiguous message [W, s, C, M]; its GEMMs see ALL W*C rows of s experts:
+      every expert's weights are streamed from HBM once per forward (capacity chunks stream all of
+      them `degree` times -- 2x the dominant HBM traffic at degree 2) and the row count per launch
+      stays at W*C (the 256 x 256-tile kernel's regime).  The return all-to-all lands in slice i of
+      one [degree, W, s, C, M_out] buffer that fast_decode addresses through its expert_slice mode.
+    capacity-chunked (otherwise): buckets CHUNK-MAJOR [degree, E, c, M]; the GEMMs read the raw
+      received buffer [W, E_loc, c, M] through their row addressing (rows_per_w = c); the return
+      all-to-all lands in slice i of [degree, E, c, M_out], decoded chunk-major.
+
+    Stage i+1 is on the xGMI links (communication stream) while stage i is in the GEMMs (caller's
     stream); events hand the buffers over and every tensor that crosses streams is registered
     with the caching allocator.  x [T, M] -> [T, M_out]."""
     from .. import ops
     group, experts = layer.group, layer.experts
     W, E_loc = layer.world_size, layer.num_local_experts
     E, Cap = crit[0], crit[4]
-    c = Cap // degree
     T, M = x.shape
     Mo = experts.output_dim
     dev = x.device
-
-    smap_cm = crit.slot_map.view(E, degree, c).permute(1, 0, 2).contiguous().view(-1)
-    enc = ops.fast_encode(x, smap_cm, None if is_postscore else crit.gates2d, E * Cap).view(degree, E, c, M)
+    plan = OverlapPlan(E, W, Cap, degree, allow_sliced=getattr(layer, "megablocks_size", 0) == 0)
+    rows = plan.rows
+    enc = ops.fast_encode(x, plan.permute_slots(crit.slot_map), None if is_postscore else crit.gates2d,
+                          E * Cap).view(degree, W * rows, M)
 
     cur = torch.cuda.current_stream()
     comm = _comm_stream(dev)
@@ -128,7 +172,7 @@ def a2a_ffn_overlap_fused(layer, x, crit, degree, is_postscore):
     with torch.cuda.stream(comm):
         comm.wait_event(ready)
         for i in range(degree):
-            buf = torch.empty([E, c, M], dtype=x.dtype, device=dev)
+            buf = torch.empty([W * rows, M], dtype=x.dtype, device=dev)   # [W(src), s, c, M]
             _exchange(buf, enc[i], group)
             buf.record_stream(cur)
             ev = torch.cuda.Event()
@@ -136,13 +180,13 @@ def a2a_ffn_overlap_fused(layer, x, crit, degree, is_postscore):
             recv.append(buf)
             recv_ev.append(ev)
 
-    out_all = torch.empty([degree, E, c, Mo], dtype=x.dtype, device=dev)
+    out_all = torch.empty([degree, W * rows, Mo], dtype=x.dtype, device=dev)
     out_all.record_stream(comm)
     for i in range(degree):
         cur.wait_event(recv_ev[i])
-        send = torch.empty([E, c, Mo], dtype=x.dtype, device=dev)
-        experts.forward_fused(recv[i], layer, a_layout=(c * M, E_loc * c * M, c, M), R=W * c,
-                              out=send, d_layout=(c * Mo, E_loc * c * Mo, c, Mo))
+        send = torch.empty([W * rows, Mo], dtype=x.dtype, device=dev)     # [W(dst), s, c, M_out]
+        experts.forward_fused(recv[i], layer, a_layout=plan.row_layout(M), R=plan.R, out=send,
+                              d_layout=plan.row_layout(Mo), expert_range=plan.expert_range(i))
         done = torch.cuda.Event()
         done.record(cur)
         send.record_stream(comm)
@@ -154,5 +198,5 @@ def a2a_ffn_overlap_fused(layer, x, crit, degree, is_postscore):
     cur.wait_event(fin)
 
     layer.protected_shape = torch.Size([E_loc, W * Cap, Mo])
-    return ops.fast_decode(out_all.view(E * Cap, Mo), crit.idx2d, crit.loc2d,
-                           crit.gates2d if is_postscore else None, Cap, num_experts=E, chunk_rows=c)
+    return ops.fast_decode(out_all.view(E * Cap, Mo), crit.idx2d, crit.loc2d, crit.gates2d if is_postscore else None,
+                           Cap, **plan.decode_kwargs)

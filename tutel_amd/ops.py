@@ -148,9 +148,10 @@ def fast_encode(x, smap, gates, n_slots):
     return out
 
 
-def fast_decode(buf, idx, loc, gates, capacity, num_experts=0, chunk_rows=0):
+def fast_decode(buf, idx, loc, gates, capacity, num_experts=0, chunk_rows=0, expert_slice=0, ep_world=1):
     """buf [E*C, M] -> [T, M]; gates [k,T] or None (= ones).
-    chunk_rows > 0: buf is chunk-major [C/chunk_rows, E, chunk_rows, M] (overlapped all-to-all layout)."""
+    chunk_rows > 0: buf is chunk-major [C/chunk_rows, E, chunk_rows, M]; expert_slice = s > 0: buf is
+    expert-sliced [E_loc/s, W, s, C, M] (the two layouts of the overlapped all-to-all)."""
     _dev(buf, idx, loc, gates)
     assert buf.dim() == 2 and buf.is_contiguous()
     assert idx.dtype == torch.int32 and loc.dtype == torch.int32 and idx.is_contiguous() and loc.is_contiguous()
@@ -161,7 +162,8 @@ def fast_decode(buf, idx, loc, gates, capacity, num_experts=0, chunk_rows=0):
         assert gates.is_contiguous() and gates.shape == idx.shape
     _lib.check(_lib.lib().tutel_amd_fast_decode(_ptr(buf), _code(buf), _ptr(idx), _ptr(loc), _ptr(gates),
                                                 _code(gates) if gates is not None else 0, T, M, k,
-                                                int(capacity), int(num_experts), int(chunk_rows), _ptr(out), _stream()),
+                                                int(capacity), int(num_experts), int(chunk_rows), int(expert_slice), int(ep_world),
+                                                _ptr(out), _stream()),
                "tutel_amd_fast_decode")
     return out
 
