@@ -200,6 +200,16 @@ int tutel_amd_expert_gemm_glu(const void *A, int64_t a_stride_e, int64_t a_strid
                               int act, const int32_t *row_counts, int row_align,
                               tutel_stream_t stream);
 
+/* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
+ * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG
+ * seed it once), 0 / 1 = force.  Every choice computes bit-identical results.
+ *   TUTEL_OPT_GEMM_IMPL  128-tile kernels: 0 register-staged, 1 LDS-DMA
+ *   TUTEL_OPT_GEMM_TILE  0 never / 1 always use the 256 x 256-tile kernel (automatic: >= 256 rows per
+ *                        expert and enough tiles to cover the chip) */
+#define TUTEL_OPT_GEMM_IMPL 0
+#define TUTEL_OPT_GEMM_TILE 1
+int tutel_amd_set_option(int key, int value);
+
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------
  * Dumps the lane->element permutation of ds_read_b64_tr_b16 (the transposing LDS read the
  * [K,N]-weight GEMM relies on): out[64*4] uint16, LDS pre-filled with lds[i] = i, lane l

@@ -175,13 +175,23 @@ def _gemm_tol(dtype):
     return dict(rtol=2 ** -7, atol=2e-3) if dtype == torch.bfloat16 else dict(rtol=2 ** -10, atol=3e-4)
 
 
+@pytest.fixture(params=["auto", "tile256"])
+def big_tile(request):
+    """auto: the library picks the tile (the small test shapes land on the 128-tile kernels);
+    tile256: force the 256 x 256-tile kernel wherever it applies (N >= 128)."""
+    from tutel_amd import ops, _lib
+    ops.set_option(_lib.OPT_GEMM_TILE, 1 if request.param == "tile256" else -1)
+    yield request.param
+    ops.set_option(_lib.OPT_GEMM_TILE, -1)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("E,R,N,K", [(3, 100, 192, 128), (2, 128, 2048, 2048), (1, 300, 64, 64), (5, 1, 8, 64),
                                      # R >= 256 rows per expert: the 256 x 256-tile kernel (full, ragged, single k-tile)
                                      (2, 256, 256, 128), (3, 300, 328, 192), (1, 1024, 512, 2048), (2, 257, 136, 64)])
 @pytest.mark.parametrize("kmajor", [True, False])
 @pytest.mark.parametrize("act", ["none", "relu"])
-def test_expert_gemm_vs_fp32_reference(dtype, E, R, N, K, kmajor, act):
+def test_expert_gemm_vs_fp32_reference(dtype, E, R, N, K, kmajor, act, big_tile):
     ops = _ops()
     g = torch.Generator().manual_seed(E * 1000 + R + N + K)
     a = torch.randn([E, R, K], generator=g).to(dtype)
@@ -359,3 +369,25 @@ def test_decode_expert_sliced_layout(oracle, W, E_loc, s):
     sliced = buf.view(E * Cap, M)[order].contiguous().cuda()
     got = ops.fast_decode(sliced, idx, loc, gates, Cap, **plan.decode_kwargs)
     assert torch.equal(plain, got)
+
+
+@pytest.mark.parametrize("kmajor", [True, False])
+def test_expert_gemm_kernels_are_bit_identical(kmajor):
+    """128-tile register-staged, 128-tile LDS-DMA and 256 x 256-tile kernels walk k in the same order for
+    every output element: same bits whatever the row count / option selects."""
+    from tutel_amd import ops, _lib
+    g = torch.Generator().manual_seed(17)
+    E, R, N, K = 3, 300, 640, 1024
+    a = torch.randn([E, R, K], generator=g).bfloat16().cuda()
+    w = ((torch.rand([E, N, K] if kmajor else [E, K, N], generator=g) * 2 - 1) / 32).bfloat16().cuda()
+    b = torch.randn([E, N], generator=g).bfloat16().cuda()
+    outs = []
+    try:
+        for impl, tile in ((0, 0), (1, 0), (-1, 1)):
+            ops.set_option(_lib.OPT_GEMM_IMPL, impl)
+            ops.set_option(_lib.OPT_GEMM_TILE, tile)
+            outs.append(ops.expert_gemm(a, w, b, kmajor, act="gelu"))
+    finally:
+        ops.set_option(_lib.OPT_GEMM_IMPL, -1)
+        ops.set_option(_lib.OPT_GEMM_TILE, -1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -11,6 +11,7 @@
 
 // ---- error reporting ---------------------------------------------------------------------
 void tutel_set_error(const char *fmt, ...);
+int tutel_get_option(int key);  // TUTEL_OPT_*: -1 automatic, 0 / 1 forced (api.hip)
 
 #define TUTEL_REQUIRE(cond, ...)           \
   do {                                     \

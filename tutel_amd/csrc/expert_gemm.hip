@@ -796,12 +796,12 @@ static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
 // TUTEL_AMD_GEMM_IMPL=0|1 forces register-staged | LDS-DMA for A/B runs.
 template <typename T, bool KM, int ACT>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
-  static int impl = -2;
-  if (impl == -2) { const char *s = getenv("TUTEL_AMD_GEMM_IMPL"); impl = s ? atoi(s) : -1; }
-  static int big = -2;
-  if (big == -2) { const char *s = getenv("TUTEL_AMD_GEMM_BIG"); big = s ? atoi(s) : -1; }
-  // R >= 256 rows per expert: the 256 x 256 tile (twice the flop per byte crossing L2 -> CU)
-  if ((big < 0 ? a.R >= GB_BM : big == 1) && a.N >= GM_BN) return launch_big<T, KM, ACT>(a, st);
+  const int impl = tutel_get_option(TUTEL_OPT_GEMM_IMPL), big = tutel_get_option(TUTEL_OPT_GEMM_TILE);
+  // R >= 256 rows per expert: the 256 x 256 tile (twice the flop per byte crossing L2 -> CU) -- provided its
+  // grid still covers the chip: one such block occupies a CU, so fewer than ~3/4 x 256 of them (a pipeline
+  // stage of the overlapped all-to-all is half a GEMM) leave CUs idle and the 128-tile kernels win.
+  const long long big_tiles = (long long)a.E_loc * ((a.R + GB_BM - 1) / GB_BM) * ((a.N + GB_BN - 1) / GB_BN);
+  if ((big < 0 ? (a.R >= GB_BM && big_tiles >= 192) : big == 1) && a.N >= GM_BN) return launch_big<T, KM, ACT>(a, st);
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
   return launch_cfg<T, KM, ACT, 64, 2, 2, true, true, false>(a, grid, st);

@@ -255,6 +255,11 @@ def expert_gemm_gather(x, smap, w, bias, w_kmajor, act, R, row_counts=None, row_
     return out
 
 
+def set_option(key, value):
+    """Tuning knob (_lib.OPT_*): -1 automatic, 0 / 1 forced.  For A/B runs and tests."""
+    _lib.check(_lib.lib().tutel_amd_set_option(int(key), int(value)), "tutel_amd_set_option")
+
+
 def probe_tr16():
     out = torch.empty([256], dtype=torch.int16, device="cuda")
     _lib.check(_lib.lib().tutel_amd_probe_tr16(_ptr(out), _stream()), "tutel_amd_probe_tr16")
