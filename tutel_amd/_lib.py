@@ -59,6 +59,12 @@ def lib():
     """The loaded library.  Raises TutelAmdError when it is not there -- never falls back."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: PyTorch's wheel bundles its own libamdhip64 / libhsa-runtime64 and
+        # loads them by path.  If libtutel_amd.so came first it would pull /opt/rocm's copies in, torch
+        # would then add its own, and whichever runtime initialises second finds "no ROCm-capable
+        # device".  Importing torch first makes the loader satisfy our NEEDED libamdhip64.so.7 with the
+        # copy torch already mapped, so kernels launched here run on torch's streams and allocations.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise TutelAmdError(
                 f"tutel_amd: HIP library {LIB_PATH} is missing. Build it with "
