@@ -175,12 +175,12 @@ def _gemm_tol(dtype):
     return dict(rtol=2 ** -7, atol=2e-3) if dtype == torch.bfloat16 else dict(rtol=2 ** -10, atol=3e-4)
 
 
-@pytest.fixture(params=["auto", "tile256"])
+@pytest.fixture(params=["auto", "tile256x256", "tile256x128"])
 def big_tile(request):
     """auto: the library picks the tile (the small test shapes land on the 128-tile kernels);
-    tile256: force the 256 x 256-tile kernel wherever it applies (N >= 128)."""
+    tile256x256 / tile256x128: force the 256-row kernels wherever they apply (N >= 128; 256x128: k-major)."""
     from tutel_amd import ops, _lib
-    ops.set_option(_lib.OPT_GEMM_TILE, 1 if request.param == "tile256" else -1)
+    ops.set_option(_lib.OPT_GEMM_TILE, {"auto": -1, "tile256x256": 1, "tile256x128": 2}[request.param])
     yield request.param
     ops.set_option(_lib.OPT_GEMM_TILE, -1)
 
@@ -373,7 +373,7 @@ def test_decode_expert_sliced_layout(oracle, W, E_loc, s):
 
 @pytest.mark.parametrize("kmajor", [True, False])
 def test_expert_gemm_kernels_are_bit_identical(kmajor):
-    """128-tile register-staged, 128-tile LDS-DMA and 256 x 256-tile kernels walk k in the same order for
+    """128-tile register-staged, 128-tile LDS-DMA, 256 x 256- and 256 x 128-tile kernels walk k in the same order for
     every output element: same bits whatever the row count / option selects."""
     from tutel_amd import ops, _lib
     g = torch.Generator().manual_seed(17)
@@ -383,11 +383,11 @@ def test_expert_gemm_kernels_are_bit_identical(kmajor):
     b = torch.randn([E, N], generator=g).bfloat16().cuda()
     outs = []
     try:
-        for impl, tile in ((0, 0), (1, 0), (-1, 1)):
+        for impl, tile in ((0, 0), (1, 0), (-1, 1), (-1, 2)):
             ops.set_option(_lib.OPT_GEMM_IMPL, impl)
             ops.set_option(_lib.OPT_GEMM_TILE, tile)
             outs.append(ops.expert_gemm(a, w, b, kmajor, act="gelu"))
     finally:
         ops.set_option(_lib.OPT_GEMM_IMPL, -1)
         ops.set_option(_lib.OPT_GEMM_TILE, -1)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])

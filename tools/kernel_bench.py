@@ -90,6 +90,16 @@ def main():
         rec(f"expert_gemm1 EP shape ({El2}x{R2}x{H}x{M})", timeit(lambda: ops.expert_gemm(a2, w1[:El2], b1[:El2], True, act="relu"), iters=20), by2, f2)
         rec(f"expert_gemm2 EP shape ({El2}x{R2})", timeit(lambda: ops.expert_gemm(a2, w2[:El2], b2[:El2], False), iters=20), by2, f2)
         rec(f"torch.bmm EP shape ({El2}x{R2}) (yardstick)", timeit(lambda: torch.matmul(a2, w2[:El2]), iters=20), by2, f2)
+    # one pipeline stage of the overlapped all-to-all at degree 2: half the local experts, all W*C rows
+    from tutel_amd import _lib
+    for El2, R2 in ((16, 256), (8, 512), (4, 1024)):
+        a2 = torch.randn([El2, R2, M], generator=g).to(dtype).to(dev)
+        f2 = 2 * El2 * R2 * M * H
+        by2 = (El2 * H * M + 2 * El2 * R2 * M) * s
+        for name, opt in (("auto", -1), ("128-tile", 0), ("256x128", 2), ("256x256", 1)):
+            ops.set_option(_lib.OPT_GEMM_TILE, opt)
+            rec(f"stage gemm1 ({El2}x{R2}) {name}", timeit(lambda: ops.expert_gemm(a2, w1[:El2], b1[:El2], True, act="relu"), iters=20), by2, f2)
+        ops.set_option(_lib.OPT_GEMM_TILE, -1)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "kernel_bench.json"), "w") as f:

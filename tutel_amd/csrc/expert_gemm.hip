@@ -556,20 +556,23 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
 //   (or [64k][128n]) weight sub-tiles 2 x 16 KB; 2 stages = 128 KB, one block per CU.
 // -------------------------------------------------------------------------------------------
 #define GB_BM 256
-#define GB_BN 256
 #define GB_THREADS 512
-#define GB_LDS_BYTES ((size_t)2 * 4 * GL_STAGE * 2)
 
-template <typename T, bool W_KMAJOR, int ACT>
+// NI = 32-column MFMA tiles per wave: 4 -> 256 x 256 block tile (two 128-column weight sub-tiles per
+// stage), 2 -> 256 x 128 (one sub-tile; for launches whose 256 x 256 grid would leave CUs idle).
+template <typename T, bool W_KMAJOR, int ACT, int NI>
 __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs p) {
+  constexpr int NSUB = NI / 2;              // 128-column weight sub-tiles per stage
+  constexpr int WPW = 2 * NSUB;             // weight DMA pieces per wave and stage
+  constexpr int BN = NI * 64;               // block tile columns
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [2][2 * GL_STAGE]   (256 rows x 64 k)
-  uint16_t *sW = sA + 4 * GL_STAGE;                   // [2][2][GL_STAGE]    (two 128-column sub-tiles)
+  uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [2][2 * GL_STAGE]      (256 rows x 64 k)
+  uint16_t *sW = sA + 4 * GL_STAGE;                   // [2][NSUB][GL_STAGE]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;     // compute roles
-  const int dg = wid >> 2, dw4 = wid & 3;    // DMA roles for the weight sub-tiles
+  const int wm = wid >> 1, wn = wid & 1;                 // compute roles: 64-row group, (NI*32)-column group
+  const int wsub = (wn * NI * 32) / GM_BN, wcol = (wn * NI * 32) % GM_BN;  // sub-tile and column offset of the wave's columns
 
   const int nb = gridDim.x;
   int w;
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   const int mt = w % p.ntm;
   const int nt = (w / p.ntm) % p.ntn;
   const int e = w / (p.ntm * p.ntn);
-  const int m0 = mt * GB_BM, n0 = nt * GB_BN;
+  const int m0 = mt * GB_BM, n0 = nt * BN;
 
   int row_limit = p.R;
   if (p.row_counts != nullptr) {
@@ -593,8 +596,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   const uint16_t *Ae = reinterpret_cast<const uint16_t *>(p.A) + (size_t)e * p.a_stride_e;
   const uint16_t *We = reinterpret_cast<const uint16_t *>(p.W) + (size_t)e * p.w_stride_e;
 
-  // DMA sources: token tile pieces j = wid*4 + i (rows 8j..8j+7 of 256); weight sub-tile dg, pieces dw4*4 + i
-  const uint16_t *a_src[4], *w_src[4];
+  // DMA sources: token tile pieces j = wid*4 + i (rows 8j..8j+7 of 256); weight pieces g = wid*WPW + i over the
+  // NSUB sub-tiles of 16 pieces each
+  const uint16_t *a_src[4], *w_src[WPW];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     {
@@ -608,24 +612,28 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
                            : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;
       }
     }
+  }
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int g = wid * WPW + i, dg = g >> 4, j = g & 15;
     if (W_KMAJOR) {
-      const int r = 8 * (dw4 * 4 + i) + (lane >> 3);
+      const int r = 8 * j + (lane >> 3);
       const int c = (lane & 7) ^ ((r >> 1) & 7);
       const int gn = min(n0 + dg * GM_BN + r, p.N - 1);
       w_src[i] = We + (size_t)gn * p.ldw + c * 8;
     } else {
-      const int kr = 4 * (dw4 * 4 + i) + (lane >> 4);
+      const int kr = 4 * j + (lane >> 4);
       const int cn = (lane & 15) ^ ((kr & 3) << 2);
       const int gn = min(n0 + dg * GM_BN + cn * 8, p.N - 8);
       w_src[i] = We + (size_t)kr * p.ldw + gn;
     }
   }
   const size_t w_step = W_KMAJOR ? (size_t)GL_BK : (size_t)GL_BK * p.ldw;
-  const int piece_a = wid * 4 * 512, piece_w = dw4 * 4 * 512;
+  const int piece_a = wid * 4 * 512, piece_w = wid * WPW * 512;  // weight pieces are consecutive across the sub-tiles
 
-  f32x16 acc[4][2];
+  f32x16 acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -637,30 +645,32 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) frag_k[kk] = (((kk * 2 + kg) ^ sw) << 3);
   const int a_row = (wm * 64 + l31) * GL_BK;  // + mi*32*64
-  const int wk_row = l31 * GL_BK;             // + ni*32*64, inside sub-tile wn
+  const int wk_row = (wcol + l31) * GL_BK;    // + ni*32*64, inside sub-tile wsub
   const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2;
-  const int c_lo = (g16 & 1) * 2 + ((i16 & 3) >> 1);
+  const int c_lo = wcol / 8 + (g16 & 1) * 2 + ((i16 & 3) >> 1);
   const int wt_row = ((g16 >> 1) * 8 + q4) * GM_BN;
-  int wt_c[4];
+  int wt_c[NI];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) wt_c[ni] = (((c_lo + 4 * ni) ^ (q4 << 2)) << 3) + (i16 & 1) * 4;
+  for (int ni = 0; ni < NI; ++ni) wt_c[ni] = (((c_lo + 4 * ni) ^ (q4 << 2)) << 3) + (i16 & 1) * 4;
 
   const int nk = p.K / GL_BK;
-  const int rot = (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk);
+  // the same k order as the 128-tile kernels (rotation per PAIR of 128-column tiles)
+  const int npair = NI == 4 ? p.ntn : (p.ntn + 1) >> 1, pair = NI == 4 ? nt : nt >> 1;
+  const int rot = (int)(((long long)(pair + 3 * e) * nk / npair) % nk);
 
 #define GB_ISSUE(KT, BUF)                                                              \
   do {                                                                                 \
     int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
     const size_t ao_ = (size_t)kr_ * GL_BK, wo_ = (size_t)kr_ * w_step;                \
-    uint16_t *da_ = sA + (BUF) * 2 * GL_STAGE + piece_a, *dw_ = sW + ((BUF) * 2 + dg) * GL_STAGE + piece_w; \
+    uint16_t *da_ = sA + (BUF) * 2 * GL_STAGE + piece_a, *dw_ = sW + (BUF) * NSUB * GL_STAGE + piece_w; \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, false); \
+    _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, false); \
   } while (0)
 #define GB_LOAD_FRAGS(FA, FW, KK)                                                      \
   do {                                                                                 \
     _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                   \
       FA[mi] = *reinterpret_cast<const u32x4 *>(ca + a_row + mi * 32 * GL_BK + frag_k[KK]); \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) {                                 \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                \
       if (W_KMAJOR) {                                                                  \
         FW[ni] = *reinterpret_cast<const u32x4 *>(cw + wk_row + ni * 32 * GL_BK + frag_k[KK]); \
       } else {                                                                         \
@@ -677,7 +687,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   } while (0)
 #define GB_MMA(FA, FW)                                                                 \
   do {                                                                                 \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                  \
       _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
         acc[ni][mi] = Mma<T>::run(FW[ni], FA[mi], acc[ni][mi]);                        \
   } while (0)
@@ -688,10 +698,10 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) GB_ISSUE(kt + 1, buf ^ 1);
-    const uint16_t *ca = sA + buf * 2 * GL_STAGE, *cw = sW + (buf * 2 + wn) * GL_STAGE;
+    const uint16_t *ca = sA + buf * 2 * GL_STAGE, *cw = sW + (buf * NSUB + wsub) * GL_STAGE;
     // two half-tiles: fragments of two k-steps (48 registers), then their 16 MFMAs; the partner wave
     // on the SIMD runs its MFMAs while this one waits for LDS
-    u32x4 fa[2][2], fw[2][4];
+    u32x4 fa[2][2], fw[2][NI];
     GB_LOAD_FRAGS(fa[0], fw[0], 0);
     GB_LOAD_FRAGS(fa[1], fw[1], 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -709,23 +719,24 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
 #undef GB_LOAD_FRAGS
 #undef GB_MMA
 
-  GM_PRELOAD_BIAS_N(4);
-  gemm_epilogue<T, ACT, 4>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
+  GM_PRELOAD_BIAS_N(NI);
+  gemm_epilogue<T, ACT, NI>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
 }
 
-template <typename T, bool KM, int ACT>
+template <typename T, bool KM, int ACT, int NI>
 static int launch_big(const GemmArgs &a, hipStream_t st) {
   GemmArgs b = a;
   b.ntm = (a.R + GB_BM - 1) / GB_BM;
-  b.ntn = (a.N + GB_BN - 1) / GB_BN;
-  auto kern = expert_gemm_big_kernel<T, KM, ACT>;
+  b.ntn = (a.N + NI * 64 - 1) / (NI * 64);
+  const size_t lds = (size_t)2 * (2 + NI / 2) * GL_STAGE * 2;
+  auto kern = expert_gemm_big_kernel<T, KM, ACT, NI>;
   static bool optin = false;
   if (!optin) {
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     optin = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.E_loc * b.ntm * b.ntn), dim3(GB_THREADS), GB_LDS_BYTES, st, b);
+  hipLaunchKernelGGL(kern, dim3(a.E_loc * b.ntm * b.ntn), dim3(GB_THREADS), lds, st, b);
   TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
   return 0;
 }
@@ -797,11 +808,16 @@ static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
 template <typename T, bool KM, int ACT>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   const int impl = tutel_get_option(TUTEL_OPT_GEMM_IMPL), big = tutel_get_option(TUTEL_OPT_GEMM_TILE);
-  // R >= 256 rows per expert: the 256 x 256 tile (twice the flop per byte crossing L2 -> CU) -- provided its
-  // grid still covers the chip: one such block occupies a CU, so fewer than ~3/4 x 256 of them (a pipeline
-  // stage of the overlapped all-to-all is half a GEMM) leave CUs idle and the 128-tile kernels win.
-  const long long big_tiles = (long long)a.E_loc * ((a.R + GB_BM - 1) / GB_BM) * ((a.N + GB_BN - 1) / GB_BN);
-  if ((big < 0 ? (a.R >= GB_BM && big_tiles >= 192) : big == 1) && a.N >= GM_BN) return launch_big<T, KM, ACT>(a, st);
+  // R >= 256 rows per expert: the 256-row tiles (more flop per byte crossing L2 -> CU) -- provided the grid
+  // still covers the chip: one such block occupies a CU, so with fewer than ~3/4 x 256 blocks CUs sit idle.
+  // 256 x 256 first, 256 x 128 when only that fills the chip (a pipeline stage of the overlapped
+  // all-to-all is half a GEMM), else the 128-tile kernels.  big = 1 forces 256 x 256, 2 forces 256 x 128.
+  if (a.N >= GM_BN && big != 0) {
+    const long long mt256 = (long long)a.E_loc * ((a.R + GB_BM - 1) / GB_BM);
+    const long long t256 = mt256 * ((a.N + 255) / 256), t128 = mt256 * ((a.N + 127) / 128);
+    if (big == 1 || (big < 0 && a.R >= GB_BM && t256 >= 192)) return launch_big<T, KM, ACT, 4>(a, st);
+    if (KM && (big == 2 || (big < 0 && a.R >= GB_BM && t128 >= 192))) return launch_big<T, true, ACT, 2>(a, st);
+  }
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
   return launch_cfg<T, KM, ACT, 64, 2, 2, true, true, false>(a, grid, st);
