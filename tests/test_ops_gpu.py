@@ -22,6 +22,16 @@ def _ops():
     return ops
 
 
+@pytest.fixture(params=["auto", "tile256x256", "tile256x128"])
+def big_tile(request):
+    """auto: the library picks the tile (the small test shapes land on the 128-tile kernels);
+    tile256x256 / tile256x128: force the 256-row kernels wherever they apply (N >= 128; 256x128: k-major)."""
+    from tutel_amd import ops, _lib
+    ops.set_option(_lib.OPT_GEMM_TILE, {"auto": -1, "tile256x256": 1, "tile256x128": 2}[request.param])
+    yield request.param
+    ops.set_option(_lib.OPT_GEMM_TILE, -1)
+
+
 def test_library_loads_on_gpu():
     from tutel_amd import _lib
     L = _lib.lib()
@@ -175,16 +185,6 @@ def _gemm_tol(dtype):
     return dict(rtol=2 ** -7, atol=2e-3) if dtype == torch.bfloat16 else dict(rtol=2 ** -10, atol=3e-4)
 
 
-@pytest.fixture(params=["auto", "tile256x256", "tile256x128"])
-def big_tile(request):
-    """auto: the library picks the tile (the small test shapes land on the 128-tile kernels);
-    tile256x256 / tile256x128: force the 256-row kernels wherever they apply (N >= 128; 256x128: k-major)."""
-    from tutel_amd import ops, _lib
-    ops.set_option(_lib.OPT_GEMM_TILE, {"auto": -1, "tile256x256": 1, "tile256x128": 2}[request.param])
-    yield request.param
-    ops.set_option(_lib.OPT_GEMM_TILE, -1)
-
-
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("E,R,N,K", [(3, 100, 192, 128), (2, 128, 2048, 2048), (1, 300, 64, 64), (5, 1, 8, 64),
                                      # R >= 256 rows per expert: the 256 x 256-tile kernel (full, ragged, single k-tile)
@@ -218,7 +218,7 @@ def test_expert_gemm_activations(act):
     torch.testing.assert_close(out.float(), ref.bfloat16().float(), **_gemm_tol(torch.bfloat16))
 
 
-def test_expert_gemm_ep_layout_and_row_counts(oracle):
+def test_expert_gemm_ep_layout_and_row_counts(oracle, big_tile):
     """A read straight from the all-to-all output [W,E_loc,C,K]; D written straight into the
     all-to-all input layout [W,E_loc,C,N] (communicate.py:606-622 folded into the GEMM), and the
     dropless row_counts skip (sparse_bmm_infer semantics, custom_kernel.cpp:874-889)."""
@@ -327,10 +327,11 @@ def test_masked_tokens_through_dispatcher(oracle):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("T,E,k,M,H,cf", [(512, 8, 2, 128, 192, 1.0), (4096, 64, 2, 2048, 128, 1.0), (300, 5, 2, 64, 64, 0.5)])
-def test_expert_gemm_gather_equals_encode_then_gemm(oracle, dtype, T, E, k, M, H, cf):
+@pytest.mark.parametrize("T,E,k,M,H,cf", [(512, 8, 2, 128, 192, 1.0), (4096, 64, 2, 2048, 128, 1.0), (300, 5, 2, 64, 64, 0.5),
+                                          (2048, 4, 2, 128, 320, 1.0)])   # 1024 rows per expert: the 256-row tiles when forced
+def test_expert_gemm_gather_equals_encode_then_gemm(oracle, dtype, T, E, k, M, H, cf, big_tile):
     """fc1 with fast_encode fused (rows gathered from the tokens through the slot map, zero row for
-    empty slots) must equal fast_encode followed by the plain grouped GEMM, bit for bit."""
+    empty slots) must equal fast_encode followed by the plain grouped GEMM, bit for bit -- in every kernel."""
     ops = _ops()
     g = torch.Generator().manual_seed(T + M)
     scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
