@@ -41,7 +41,11 @@ class KMajorCache:
         self._store = {}
 
     def get(self, name, w):
-        key = (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
+        try:
+            version = w._version
+        except RuntimeError:  # inference tensors (module built under torch.inference_mode()) carry no version counter
+            version = -1
+        key = (w.data_ptr(), version, w.dtype, w.device, tuple(w.shape))
         hit = self._store.get(name)
         if hit is None or hit[0] != key:
             hit = (key, w.detach().transpose(1, 2).contiguous())
