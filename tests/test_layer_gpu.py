@@ -528,3 +528,15 @@ def test_eval_weight_prelayout_tracks_weight_updates(oracle):
         layer.experts.batched_fc2_w.data.mul_(0.5)   # bypasses the version counter ...
         layer.experts.invalidate_prepacked()         # ... so the documented call is needed
         assert torch.equal(layer(xd), y1)
+
+
+def test_inference_mode_equals_no_grad(oracle):
+    T, M, H, E, k = 512, 128, 128, 8, 2
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=torch.bfloat16, seed=4)
+    layer = make_layer(M, H, E, k, 1.0, torch.bfloat16, weights).eval()
+    with torch.no_grad():
+        y0 = layer(x.cuda())
+    with torch.inference_mode():
+        y1 = layer(x.cuda())
+        crit, _ = __import__("tutel").moe.top_k_routing(torch.softmax(torch.randn(64, 8, device="cuda"), 1), 2)
+    assert torch.equal(y0, y1) and float(y0.l_aux) == float(y1.l_aux)
