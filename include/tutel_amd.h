@@ -111,9 +111,15 @@ int tutel_amd_cumsum_sub_one(const int32_t *mask, int32_t *out, int T, int E,
  * k launches of the `forward` kernel (sparse.py:21-35 | custom_kernel.cpp:293-300):
  *   out[e*C + c, :] = g * x[t, :]  for the (j,t) in slot_map, g = gates[j,t] or 1 (gates NULL,
  *   i.e. is_postscore=True); every other row = 0.  Math in fp32, one rounding to `dtype`
- *   (fast_dispatch.py:95-96,126).  x [T,M], out [n_slots,M] in `dtype`; gates [k,T] gate_dtype. */
+ *   (fast_dispatch.py:95-96,126).  x [T,M], out [n_slots,M] in `dtype`; gates [k,T] gate_dtype.
+ * Bucket order of `out` (the same three layouts tutel_amd_fast_decode reads; slot_map itself is
+ * always in plain order e*C + l): chunk_rows = expert_slice = 0 -> plain [E, C, M] (capacity,
+ * num_experts, ep_world ignored); chunk_rows = c > 0 -> chunk-major [C/c, E, c, M]; expert_slice =
+ * s > 0 -> expert-sliced [E_loc/s, W, s, C, M] (W = ep_world).  For the last two n_slots must equal
+ * num_experts * capacity. */
 int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *slot_map, const void *gates,
-                          int gate_dtype, int T, int M, int n_slots, void *out,
+                          int gate_dtype, int T, int M, int n_slots, int capacity, int num_experts,
+                          int chunk_rows, int expert_slice, int ep_world, void *out,
                           tutel_stream_t stream);
 
 /* fast_decode.  Replaces GatingDecoder.forward (fast_dispatch.py:52-66): k launches of the

@@ -42,7 +42,7 @@ def test_library_info(L):
 def test_argument_errors_are_reported_not_enqueued(L):
     from tutel_amd import _lib
     # unsupported dtype
-    assert L.tutel_amd_fast_encode(None, 99, None, None, 0, 4, 8, 4, None, None) != 0
+    assert L.tutel_amd_fast_encode(None, 99, None, None, 0, 4, 8, 4, 0, 0, 0, 0, 1, None, None) != 0
     assert b"dtype" in L.tutel_amd_last_error()
     # k > E
     assert L.tutel_amd_gate_topk(None, 0, 0, 4, 2, 3, 1, None, None, None, None, 0, None, 0, None) != 0

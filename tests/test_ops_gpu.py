@@ -370,6 +370,16 @@ def test_decode_expert_sliced_layout(oracle, W, E_loc, s):
     sliced = buf.view(E * Cap, M)[order].contiguous().cuda()
     got = ops.fast_decode(sliced, idx, loc, gates, Cap, **plan.decode_kwargs)
     assert torch.equal(plain, got)
+    # fast_encode writes the same orders itself (inverse addressing computed in the kernel): equal to encoding
+    # through an explicitly permuted slot map, for the expert-sliced and the capacity-chunked plan
+    x = torch.randn([T, M], generator=g).to(torch.bfloat16).cuda()
+    smap = ops.slot_map(idx, loc, E, Cap)
+    for pl in (plan, OverlapPlan(E, W, Cap, 2, allow_sliced=False) if Cap % 2 == 0 else plan):
+        want = ops.fast_encode(x, pl.permute_slots(smap), gates, E * Cap)
+        have = ops.fast_encode(x, smap, gates, E * Cap, capacity=Cap, **pl.decode_kwargs)
+        assert torch.equal(want, have), pl.decode_kwargs
+        back = ops.fast_decode(have, idx, loc, None, Cap, **pl.decode_kwargs)      # encode -> decode round trip in that order
+        assert torch.equal(back, ops.fast_decode(ops.fast_encode(x, smap, gates, E * Cap), idx, loc, None, Cap))
 
 
 @pytest.mark.parametrize("kmajor", [True, False])

@@ -28,7 +28,7 @@ SIGNATURES = {
     "tutel_amd_compute_location": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "tutel_amd_slot_map": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tutel_amd_cumsum_sub_one": (_i, [_vp, _vp, _i, _i, _vp]),
-    "tutel_amd_fast_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "tutel_amd_fast_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "tutel_amd_fast_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "tutel_amd_gate_grad": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tutel_amd_expert_gemm": (_i, [_vp, _i64, _i64, _i, _i, _vp, _i, _i64, _i, _vp, _i64, _vp, _i64,

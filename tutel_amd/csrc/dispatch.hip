@@ -32,7 +32,9 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
                                                            const int32_t *__restrict__ slot_map,
                                                            const void *__restrict__ gates,
                                                            int gate_dtype, int Tn, int M,
-                                                           int n_slots, T *__restrict__ out) {
+                                                           int n_slots, int capacity, int num_experts,
+                                                           int chunk_rows, int expert_slice, int ep_world,
+                                                           T *__restrict__ out) {
   constexpr int VN = Vec<T>::N;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
@@ -41,7 +43,18 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
   const bool vec_ok = (M % VN) == 0;
 
   for (int slot = wave; slot < n_slots; slot += nwaves) {
-    int q = slot_map[slot];  // wave-uniform
+    // output row `slot` in the requested bucket order -> row e*C + l of the plain slot map (the inverse of
+    // the decode kernel's addressing: chunk-major [C/c][E][c] or expert-sliced [E_loc/s][W][s][C])
+    int plain = slot;
+    if (chunk_rows > 0) {
+      const int per = num_experts * chunk_rows, ci = slot / per, rem = slot % per;
+      plain = (rem / chunk_rows) * capacity + ci * chunk_rows + rem % chunk_rows;
+    } else if (expert_slice > 0) {
+      const int blk = slot / capacity, l = slot % capacity, j = blk % expert_slice, iw = blk / expert_slice;
+      const int e = (iw % ep_world) * (num_experts / ep_world) + (iw / ep_world) * expert_slice + j;
+      plain = e * capacity + l;
+    }
+    int q = slot_map[plain];  // wave-uniform
     q = __builtin_amdgcn_readfirstlane(q);
     T *dst = out + (size_t)slot * M;
     if (q < 0) {
@@ -235,8 +248,17 @@ static inline int dp_grid(int rows) {
 
 extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *slot_map,
                                      const void *gates, int gate_dtype, int T, int M, int n_slots,
-                                     void *out, tutel_stream_t stream) {
+                                     int capacity, int num_experts, int chunk_rows, int expert_slice,
+                                     int ep_world, void *out, tutel_stream_t stream) {
   TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_fast_encode: unsupported dtype %d", dtype);
+  TUTEL_REQUIRE(chunk_rows >= 0 && expert_slice >= 0 && !(chunk_rows > 0 && expert_slice > 0), "tutel_amd_fast_encode: bad bucket order");
+  if (chunk_rows > 0 || expert_slice > 0) {
+    TUTEL_REQUIRE(num_experts >= 1 && capacity >= 1 && (long long)num_experts * capacity == n_slots,
+                  "tutel_amd_fast_encode: a bucket order needs n_slots == num_experts * capacity (got %d, %d x %d)", n_slots, num_experts, capacity);
+    TUTEL_REQUIRE(chunk_rows == 0 || capacity % chunk_rows == 0, "tutel_amd_fast_encode: chunk_rows=%d must divide capacity=%d", chunk_rows, capacity);
+    TUTEL_REQUIRE(expert_slice == 0 || (ep_world >= 1 && num_experts % ep_world == 0 && (num_experts / ep_world) % expert_slice == 0),
+                  "tutel_amd_fast_encode: expert_slice=%d must divide the local experts of each of %d ranks", expert_slice, ep_world);
+  }
   TUTEL_REQUIRE(gates == nullptr || dtype_ok(gate_dtype), "tutel_amd_fast_encode: unsupported gate dtype %d", gate_dtype);
   TUTEL_REQUIRE(T >= 0 && M >= 1 && n_slots >= 0, "tutel_amd_fast_encode: bad sizes T=%d M=%d n_slots=%d", T, M, n_slots);
   if (n_slots == 0) return 0;
@@ -246,11 +268,11 @@ extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *sl
   int grid = dp_grid(n_slots);
   int Tn = T > 0 ? T : 1;
   if (dtype == TUTEL_F32)
-    hipLaunchKernelGGL(encode_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, (float *)out);
+    hipLaunchKernelGGL(encode_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (float *)out);
   else if (dtype == TUTEL_BF16)
-    hipLaunchKernelGGL(encode_kernel<bf16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const bf16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, (bf16_t *)out);
+    hipLaunchKernelGGL(encode_kernel<bf16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const bf16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (bf16_t *)out);
   else
-    hipLaunchKernelGGL(encode_kernel<f16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const f16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, (f16_t *)out);
+    hipLaunchKernelGGL(encode_kernel<f16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const f16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (f16_t *)out);
   TUTEL_CHECK_LAUNCH("tutel_amd_fast_encode");
   return 0;
 }

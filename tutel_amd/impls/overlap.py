@@ -25,6 +25,19 @@ def _comm_stream(device):
     return _comm_streams[key]
 
 
+_event_pool = {}
+
+
+def _events(device, n):
+    """n reusable events for one forward on `device` (re-recording an event is legal; every wait of the
+    previous forward has been enqueued by then and captured the earlier record)."""
+    key = (device.type, device.index)
+    pool = _event_pool.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Event())
+    return pool
+
+
 def a2a_ffn_overlap_forward(input, expert_fn, a2a_ffn_overlap_degree, use_2dh, group):
     """input [E, C, M] -> [E, C, M_out]; expert_fn maps [E_loc, W*c, M] -> [E_loc, W*c, M_out]."""
     degree = a2a_ffn_overlap_degree
@@ -159,44 +172,51 @@ def a2a_ffn_overlap_fused(layer, x, crit, degree, is_postscore):
     dev = x.device
     plan = OverlapPlan(E, W, Cap, degree, allow_sliced=getattr(layer, "megablocks_size", 0) == 0)
     rows = plan.rows
-    enc = ops.fast_encode(x, plan.permute_slots(crit.slot_map), None if is_postscore else crit.gates2d,
-                          E * Cap).view(degree, W * rows, M)
+    # Host cost matters here: with ~20 enqueues per forward the eager path is host-bound before it is
+    # GPU-bound (measured 0.46 ms/step of Python at degree 2).  So: the bucket order is computed inside the
+    # encode kernel (no permuted slot-map tensor), every buffer is allocated up front on the caller's stream
+    # and kept referenced until the communication stream has been joined back (no record_stream
+    # bookkeeping: the allocator only ever sees these blocks freed on a stream that already waited for all
+    # their readers), events are reused, and streams are switched with the raw setter.
+    enc = ops.fast_encode(x, crit.slot_map, None if is_postscore else crit.gates2d, E * Cap, capacity=Cap,
+                          **plan.decode_kwargs).view(degree, W * rows, M)
+    recv = torch.empty([degree, W * rows, M], dtype=x.dtype, device=dev)      # stage i: [W(src), s, c, M]
+    send = torch.empty([degree, W * rows, Mo], dtype=x.dtype, device=dev)     # stage i: [W(dst), s, c, M_out]
+    out_all = torch.empty([degree, W * rows, Mo], dtype=x.dtype, device=dev)
 
     cur = torch.cuda.current_stream()
     comm = _comm_stream(dev)
-    ready = torch.cuda.Event()
+    evs = _events(dev, 2 * degree + 2)
+    ready, fin = evs[0], evs[1]
     ready.record(cur)
-    enc.record_stream(comm)
 
-    recv, recv_ev = [], []
-    with torch.cuda.stream(comm):
+    torch.cuda.set_stream(comm)
+    try:
         comm.wait_event(ready)
         for i in range(degree):
-            buf = torch.empty([W * rows, M], dtype=x.dtype, device=dev)   # [W(src), s, c, M]
-            _exchange(buf, enc[i], group)
-            buf.record_stream(cur)
-            ev = torch.cuda.Event()
-            ev.record(comm)
-            recv.append(buf)
-            recv_ev.append(ev)
+            _exchange(recv[i], enc[i], group)
+            evs[2 + i].record(comm)
+    finally:
+        torch.cuda.set_stream(cur)
 
-    out_all = torch.empty([degree, W * rows, Mo], dtype=x.dtype, device=dev)
-    out_all.record_stream(comm)
+    a_layout, d_layout = plan.row_layout(M), plan.row_layout(Mo)
     for i in range(degree):
-        cur.wait_event(recv_ev[i])
-        send = torch.empty([W * rows, Mo], dtype=x.dtype, device=dev)     # [W(dst), s, c, M_out]
-        experts.forward_fused(recv[i], layer, a_layout=plan.row_layout(M), R=plan.R, out=send,
-                              d_layout=plan.row_layout(Mo), expert_range=plan.expert_range(i))
-        done = torch.cuda.Event()
+        cur.wait_event(evs[2 + i])
+        experts.forward_fused(recv[i], layer, a_layout=a_layout, R=plan.R, out=send[i], d_layout=d_layout,
+                              expert_range=plan.expert_range(i))
+        done = evs[2 + degree + i]
         done.record(cur)
-        send.record_stream(comm)
-        with torch.cuda.stream(comm):
+        torch.cuda.set_stream(comm)
+        try:
             comm.wait_event(done)
-            _exchange(out_all[i], send, group)
-    fin = torch.cuda.Event()
+            _exchange(out_all[i], send[i], group)
+        finally:
+            torch.cuda.set_stream(cur)
     fin.record(comm)
     cur.wait_event(fin)
 
     layer.protected_shape = torch.Size([E_loc, W * Cap, Mo])
-    return ops.fast_decode(out_all.view(E * Cap, Mo), crit.idx2d, crit.loc2d, crit.gates2d if is_postscore else None,
-                           Cap, **plan.decode_kwargs)
+    y = ops.fast_decode(out_all.view(E * Cap, Mo), crit.idx2d, crit.loc2d, crit.gates2d if is_postscore else None,
+                        Cap, **plan.decode_kwargs)
+    del enc, recv, send  # released only now: `cur` has waited for every read the communication stream made
+    return y

@@ -133,8 +133,9 @@ def cumsum_sub_one(mask):
 # ---------------------------------------------------------------------------------------------
 # dispatch / combine
 # ---------------------------------------------------------------------------------------------
-def fast_encode(x, smap, gates, n_slots):
-    """x [T,M] -> [n_slots, M]; gates [k,T] or None (is_postscore)."""
+def fast_encode(x, smap, gates, n_slots, capacity=0, num_experts=0, chunk_rows=0, expert_slice=0, ep_world=1):
+    """x [T,M] -> [n_slots, M]; gates [k,T] or None (is_postscore).  smap is always in plain bucket order;
+    chunk_rows / expert_slice select the order of the OUTPUT rows (see fast_decode)."""
     _dev(x, smap, gates)
     assert x.dim() == 2 and x.is_contiguous() and smap.dtype == torch.int32 and smap.numel() == n_slots
     T, M = x.shape
@@ -143,7 +144,8 @@ def fast_encode(x, smap, gates, n_slots):
         assert gates.is_contiguous()
     _lib.check(_lib.lib().tutel_amd_fast_encode(_ptr(x), _code(x), _ptr(smap), _ptr(gates),
                                                 _code(gates) if gates is not None else 0, T, M,
-                                                int(n_slots), _ptr(out), _stream()),
+                                                int(n_slots), int(capacity), int(num_experts), int(chunk_rows),
+                                                int(expert_slice), int(ep_world), _ptr(out), _stream()),
                "tutel_amd_fast_encode")
     return out
 
