@@ -163,17 +163,32 @@ def simple_all_reduce(input, group=None, op=dist.ReduceOp.SUM, inplace=False):
     return out
 
 
+def exchange_equal_split(out, input, group=None):
+    """all_to_all_single with equal dim-0 splits on the CURRENT stream.  Device tensors on an RCCL
+    ("nccl") group go straight to the library.  A gloo group has no device all-to-all: the message is
+    staged through host memory (stream-synchronous), which keeps every expert-parallel code path runnable
+    when several ranks share ONE GPU or the job was brought up with a CPU rendezvous -- that is how the
+    multi-rank GPU tests exercise the W > 1 kernels' addressing on a single-GPU box."""
+    if input.is_cuda and dist.get_backend(group) == "gloo":
+        host_in = input.cpu()
+        host_out = torch.empty_like(host_in)
+        dist.all_to_all_single(host_out, host_in, group=group)
+        out.copy_(host_out)
+        return
+    dist.all_to_all_single(out, input, group=group)
+
+
 def simple_all_to_all(input, group=None, background=False):
     """Equal-split exchange of dim-0 chunks: chunk r of my tensor goes to rank r."""
     input = input.contiguous()
     if get_world_size(group) == 1 or SKIP_A2A:
         return input if not background else (input, lambda *a: None)
     out = torch.empty_like(input)
-    if background:
+    if background and not (input.is_cuda and dist.get_backend(group) == "gloo"):
         work = dist.all_to_all_single(out, input, group=group, async_op=True)
         return out, work.wait
-    dist.all_to_all_single(out, input, group=group)
-    return out
+    exchange_equal_split(out, input, group)
+    return (out, lambda *a: None) if background else out
 
 
 def simple_split(input, group=None):

@@ -66,7 +66,7 @@ def a2a_ffn_overlap_forward(input, expert_fn, a2a_ffn_overlap_degree, use_2dh, g
         for i, x in enumerate(chunks):
             x.record_stream(comm)
             buf = torch.empty_like(x)
-            dist.all_to_all_single(buf, x, group=group)
+            C.exchange_equal_split(buf, x, group)
             buf.record_stream(cur)
             recv[i], recv_ev[i] = buf, torch.cuda.Event()
             recv_ev[i].record(comm)
@@ -82,7 +82,7 @@ def a2a_ffn_overlap_forward(input, expert_fn, a2a_ffn_overlap_degree, use_2dh, g
             comm.wait_event(done)
             y.record_stream(comm)
             back = torch.empty_like(y)
-            dist.all_to_all_single(back, y, group=group)
+            C.exchange_equal_split(back, y, group)
             back.record_stream(cur)
             outs[i] = back
     fin = torch.cuda.Event()
@@ -100,7 +100,7 @@ _FORCE_RCCL = False  # test hook: issue the collective even in a 1-rank group
 def _exchange(dst, src, group):
     """equal-split all-to-all of dim-0 blocks (a plain copy when the group has one rank)."""
     if C.get_world_size(group) > 1 or (_FORCE_RCCL and dist.is_initialized()):
-        dist.all_to_all_single(dst, src, group=group)
+        C.exchange_equal_split(dst, src, group)
     else:
         dst.copy_(src)
 
