@@ -1,4 +1,4 @@
-"""Expert parallelism with world_size 2 ON ONE GPU: two processes share cuda:0, rendezvous over gloo, and the
+"""Expert parallelism with world_size 2 and 4 ON ONE GPU: the rank processes share cuda:0, rendezvous over gloo, and the
 all-to-all is staged through host memory (communicate.exchange_equal_split).  Everything else is the
 production multi-GPU code path: the grouped GEMMs addressing the raw exchange buffers (rows_per_w, rank
 strides), the copy-free overlapped pipeline in both its expert-sliced and capacity-chunked form, the
@@ -78,12 +78,12 @@ def _worker(rank, world, port, degree, E_loc, q):
         q.put((rank, False, traceback.format_exc(), []))
 
 
-@pytest.mark.parametrize("degree,E_loc", [(1, 2), (2, 4), (2, 3), (4, 4)])
-def test_expert_parallel_two_ranks_one_gpu(degree, E_loc):
+@pytest.mark.parametrize("world,degree,E_loc", [(2, 1, 2), (2, 2, 4), (2, 2, 3), (2, 4, 4), (4, 2, 2), (4, 1, 1)])
+def test_expert_parallel_ranks_sharing_one_gpu(world, degree, E_loc):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, degree, E_loc, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, degree, E_loc, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
