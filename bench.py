@@ -143,11 +143,20 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # Test hook (not a measurement mode): TUTEL_AMD_BENCH_SHARE_GPU=1 runs every rank on cuda:0 with a gloo
+    # rendezvous and a host-staged all-to-all, so the N > 1 code path of this script can be exercised on a
+    # single-GPU box.  The driver's multi-GPU runs use one GPU per rank over RCCL.
+    share = os.environ.get("TUTEL_AMD_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from tutel_amd import _lib
     _lib.lib()  # fail loudly if the HIP library is missing
@@ -185,7 +194,7 @@ def main():
         timer.on = False
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     assert torch.isfinite(y.float()).all()
@@ -212,7 +221,7 @@ def main():
     if timer.rows[True] >= 256:
         # >= 256 rows per expert and launch (expert-parallel ranks): the 256 x 256-tile kernel, bound by the MFMA rate
         tf = timer.flops[True] / fc1_us * 1e-6
-        roofline = {"bound": "mfma", "kernel": "expert_gemm_big_kernel<bf16,k-major,relu> (fc1 grouped GEMM, 256x256 tile, LDS-DMA)",
+        roofline = {"bound": "mfma", "kernel": "expert_gemm_big_kernel<bf16,k-major,relu> (fc1 grouped GEMM, 256-row tile: 256x256 or 256x128 by grid size, LDS-DMA)",
                     "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                     "traffic": None, "flops_per_launch": timer.flops[True], "rows_per_expert": timer.rows[True],
                     "avg_launch_us": round(fc1_us, 2), "launches_timed": n1, "fc2_gemm": fc2_obj}
@@ -230,7 +239,7 @@ def main():
             "metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic" if not share else "synthetic; TEST HOOK: all ranks share one GPU, host-staged all-to-all -- not a measurement",
             "config": {"workload": "BASELINE.json configs[1]: tutel.moe.moe_layer forward (eval), per GPU 4096 tokens "
                                    "(batch 16 x 256) x model_dim 2048, hidden 2048, 64 global experts, top-2, "
                                    "capacity_factor 1.0, ReLU, bf16, random-init weights",
