@@ -93,3 +93,23 @@ def test_expert_parallel_ranks_sharing_one_gpu(world, degree, E_loc):
         assert ok, f"rank {rank}: {info}"
         if degree > 1:
             assert plans == [E_loc % degree == 0], (plans, "expected the expert-sliced pipeline iff degree divides E_loc")
+
+
+def test_bench_script_multi_rank_code_path():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the
+    single-GPU test hook: the N > 1 branch of the script (sharded experts, overlap degree 2, max-over-ranks
+    timing, regime-aware roofline object) must produce one valid JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TUTEL_AMD_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["parallelism"] == "ep2" and d["value"] > 0
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1 and "cpu_baseline" not in d
