@@ -402,3 +402,37 @@ def test_expert_gemm_kernels_are_bit_identical(kmajor):
         ops.set_option(_lib.OPT_GEMM_IMPL, -1)
         ops.set_option(_lib.OPT_GEMM_TILE, -1)
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_routing_randomized_shapes_vs_oracle(oracle):
+    """A seeded sweep of 60 random (T, E, k, capacity_factor, dtype, normalize) problems: top-k, locations,
+    dispatch_count, capacity and the encode -> decode round trip against the oracle, bit for bit on every
+    integer; tie rows (low-precision scores) are compared through the oracle's own tie rule, which the
+    kernel implements (lowest expert index)."""
+    import random
+    ops = _ops()
+    from tutel import moe
+    rnd = random.Random(20260924)
+    for case in range(60):
+        E = rnd.choice([1, 2, 3, 7, 8, 16, 33, 64, 100, 128, 129, 256, 500])
+        T = rnd.choice([1, 5, 63, 64, 65, 300, 1000, 4096, 8192, 10000])
+        k = min(E, rnd.choice([1, 2, 2, 3, 4, 8]))
+        cf = rnd.choice([1.0, 1.0, 0.5, 2.0, 1.25, 0.0, -0.5])
+        dtype = rnd.choice([torch.float32, torch.float32, torch.bfloat16, torch.float16])
+        norm = rnd.random() < 0.7
+        g = torch.Generator().manual_seed(case)
+        scores = torch.softmax(torch.randn([T, E], generator=g) * rnd.choice([0.5, 1.0, 3.0]), dim=1).to(dtype)
+        crit_o, l_o = oracle.extract_critical(scores, k, cf, normalize_gate=norm)
+        crit, l_aux = moe.top_k_routing(scores.cuda(), k, capacity_factor=cf, normalize_gate=norm)
+        tag = f"case {case}: T={T} E={E} k={k} cf={cf} {dtype} norm={norm}"
+        assert torch.equal(torch.stack(crit[1]).cpu(), torch.stack(crit_o[1])), "idx " + tag
+        assert torch.equal(torch.stack(crit[2]).cpu(), torch.stack(crit_o[2])), "loc " + tag
+        assert crit[4] == crit_o[4] and torch.equal(crit[5].cpu(), crit_o[5]), "capacity/count " + tag
+        assert torch.equal(torch.stack(crit[3]).cpu().float(), torch.stack(crit_o[3]).float()), "gates " + tag
+        assert abs(float(l_aux) - float(l_o)) <= (1e-5 if dtype == torch.float32 else 2e-2) * max(1.0, abs(float(l_o))), "l_aux " + tag
+        if crit[4] > 0 and T * 40 * E * crit[4] < (1 << 31):
+            x = torch.randn([T, 40], generator=g).to(dtype if dtype != torch.float32 else torch.float32)
+            enc = moe.fast_encode(x.cuda(), crit)
+            assert torch.equal(enc.cpu(), oracle.fast_encode(x, crit_o)), "encode " + tag
+            dec = moe.fast_decode(enc, crit)
+            assert torch.equal(dec.cpu(), oracle.fast_decode(oracle.fast_encode(x, crit_o), crit_o)), "decode " + tag
