@@ -43,12 +43,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide
 
 
-def build_layer(M, H, E_loc, k, rank, overlap, dtype, fp32_gate):
+def build_layer(M, H, E_loc, k, rank, overlap, dtype, fp32_gate, capacity_factor=1.0):
     from tutel import moe
     torch.set_default_dtype(dtype)
     try:
         layer = moe.moe_layer(
-            gate_type={"type": "top", "k": k, "fp32_gate": fp32_gate, "capacity_factor": 1.0},
+            gate_type={"type": "top", "k": k, "fp32_gate": fp32_gate, "capacity_factor": capacity_factor},
             experts={"type": "ffn", "num_experts_per_device": E_loc, "hidden_size_per_expert": H,
                      "activation_fn": lambda t: torch.nn.functional.relu(t)},
             model_dim=M, seeds=(1, rank + 1, 1), a2a_ffn_overlap_degree=overlap)
@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--top", type=int, default=2)
     ap.add_argument("--a2a_ffn_overlap_degree", type=int, default=None)
     ap.add_argument("--fp32_gate", action="store_true")
+    ap.add_argument("--capacity_factor", type=float, default=1.0,
+                    help="BASELINE configs[2]: 0 = dropless (capacity read back from the device each step)")
+    ap.add_argument("--megablocks_size", type=int, default=0, help="configs[2]: row granularity of the dropless expert GEMMs")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured HIP graph (N=1 only)")
     args = ap.parse_args()
@@ -166,11 +169,15 @@ def main():
     overlap = args.a2a_ffn_overlap_degree or (2 if world > 1 else 1)
     dtype = torch.bfloat16
 
-    layer = build_layer(M, H, E_loc, k, rank, overlap, dtype, args.fp32_gate).to(dev).eval()
+    # like helloworld.py:77,93-94: the capacity factor belongs to the gate, megablocks_size to the forward call
+    layer = build_layer(M, H, E_loc, k, rank, overlap, dtype, args.fp32_gate, args.capacity_factor).to(dev).eval()
     torch.manual_seed(0)  # same tokens on every rank, like helloworld.py:112-113
     x = torch.randn([16, T // 16, M], dtype=torch.float32).to(dtype).to(dev)
     timer = GemmTimer()
-    step = layer
+    fwd_kw = {}
+    if args.megablocks_size:
+        fwd_kw = dict(megablocks_size=args.megablocks_size)
+    step = (lambda t: layer(t, **fwd_kw)) if fwd_kw else layer
     if args.graph and world == 1:
         from tutel_amd.impls.graph import GraphedForward
         step = GraphedForward(layer, x)  # same kernels, enqueued by one hipGraphLaunch per step
@@ -199,13 +206,12 @@ def main():
         elapsed = float(tt)
     assert torch.isfinite(y.float()).all()
 
-    C = k * ((T + E - 1) // E)
-    C = (C + overlap - 1) // overlap * overlap
+    C = int(layer.protected_shape[1]) // world  # capacity the layer actually used (dropless: max expert load)
     if not timer.events[True]:  # graph mode: time the two GEMM launches in a short eager pass after the timed region
         timer.on = True
         with torch.no_grad():
             for _ in range(20):
-                layer(x)
+                step(x)
         torch.cuda.synchronize()
         timer.on = False
     fc1_us, n1 = timer.avg_us(True)
@@ -246,6 +252,7 @@ def main():
                        "tokens_per_gpu": T, "model_dim": M, "hidden_size": H, "global_experts": E, "top_k": k,
                        "capacity": C, "parallelism": f"ep{world}" if world > 1 else "single-gpu",
                        "a2a_ffn_overlap_degree": overlap, "fp32_gate": bool(args.fp32_gate),
+                       "capacity_factor": args.capacity_factor, "megablocks_size": args.megablocks_size,
                        "launch": "hip-graph replay" if (args.graph and world == 1) else "eager"},
             "roofline": roofline,
         }

@@ -808,15 +808,17 @@ static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
 template <typename T, bool KM, int ACT>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   const int impl = tutel_get_option(TUTEL_OPT_GEMM_IMPL), big = tutel_get_option(TUTEL_OPT_GEMM_TILE);
-  // R >= 256 rows per expert: the 256-row tiles (more flop per byte crossing L2 -> CU) -- provided the grid
+  // R > 128 rows per expert: the 256-row tiles (more flop per byte crossing L2 -> CU) -- provided the grid
   // still covers the chip: one such block occupies a CU, so with fewer than ~3/4 x 256 blocks CUs sit idle.
   // 256 x 256 first, 256 x 128 when only that fills the chip (a pipeline stage of the overlapped
   // all-to-all is half a GEMM), else the 128-tile kernels.  big = 1 forces 256 x 256, 2 forces 256 x 128.
   if (a.N >= GM_BN && big != 0) {
     const long long mt256 = (long long)a.E_loc * ((a.R + GB_BM - 1) / GB_BM);
     const long long t256 = mt256 * ((a.N + 255) / 256), t128 = mt256 * ((a.N + 127) / 128);
-    if (big == 1 || (big < 0 && a.R >= GB_BM && t256 >= 192)) return launch_big<T, KM, ACT, 4>(a, st);
-    if (KM && (big == 2 || (big < 0 && a.R >= GB_BM && t128 >= 192))) return launch_big<T, true, ACT, 2>(a, st);
+    // more than one 128-row tile per expert (R > 128) already pays: the 128-tile kernels would stream every
+    // weight tile once per M-tile (dropless capacity 157 at the headline shape: fc1 214 us vs 118 at R = 128)
+    if (big == 1 || (big < 0 && a.R > GM_BM && t256 >= 192)) return launch_big<T, KM, ACT, 4>(a, st);
+    if (KM && (big == 2 || (big < 0 && a.R > GM_BM && t128 >= 192))) return launch_big<T, true, ACT, 2>(a, st);
   }
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
