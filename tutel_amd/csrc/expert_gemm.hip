@@ -630,6 +630,11 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   }
   const size_t w_step = W_KMAJOR ? (size_t)GL_BK : (size_t)GL_BK * p.ldw;
   const int piece_a = wid * 4 * 512, piece_w = wid * WPW * 512;  // weight pieces are consecutive across the sub-tiles
+  // one M-tile per expert: every weight byte is fetched by exactly one block -> no-allocate loads pay on the
+  // 256 x 256 tile with the chip covered (32 x 256 rows: 720 -> 758 TFLOP/s, dropless 64 x 157: 171 -> 156 us).
+  // With several M-tiles the blocks re-read each other's weight tiles from L2 and the hint costs 6-15 %; it also
+  // costs on the 256 x 128 tile and on half-empty grids (measured), so it is limited to the case that gains.
+  const bool w_once = NI == 4 && p.ntm == 1 && gridDim.x >= 256;
 
   f32x16 acc[NI][2];
 #pragma unroll
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
     const size_t ao_ = (size_t)kr_ * GL_BK, wo_ = (size_t)kr_ * w_step;                \
     uint16_t *da_ = sA + (BUF) * 2 * GL_STAGE + piece_a, *dw_ = sW + (BUF) * NSUB * GL_STAGE + piece_w; \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
-    _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, false); \
+    _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, w_once); \
   } while (0)
 #define GB_LOAD_FRAGS(FA, FW, KK)                                                      \
   do {                                                                                 \
