@@ -169,13 +169,28 @@ def exchange_equal_split(out, input, group=None):
     staged through host memory (stream-synchronous), which keeps every expert-parallel code path runnable
     when several ranks share ONE GPU or the job was brought up with a CPU rendezvous -- that is how the
     multi-rank GPU tests exercise the W > 1 kernels' addressing on a single-GPU box."""
-    if input.is_cuda and dist.get_backend(group) == "gloo":
+    backend = _backend_of(group)
+    if input.is_cuda and backend == "gloo":
         host_in = input.cpu()
         host_out = torch.empty_like(host_in)
         dist.all_to_all_single(host_out, host_in, group=group)
         out.copy_(host_out)
         return
+    if backend == "nccl" and _DIRECT_PG:
+        # straight to the process group: dist.all_to_all_single re-validates its arguments and goes through the
+        # c10d logging wrapper on every call (~10 us of the ~25 us a call costs the host); four calls per forward
+        # on a path that is host-bound
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        pg.alltoall_base(out, input, [], []).wait()
+        return
     dist.all_to_all_single(out, input, group=group)
+
+
+_DIRECT_PG = hasattr(dist, "ProcessGroup") and hasattr(dist.ProcessGroup, "alltoall_base")
+
+
+def _backend_of(group):
+    return dist.get_backend(group)
 
 
 def simple_all_to_all(input, group=None, background=False):
@@ -184,7 +199,7 @@ def simple_all_to_all(input, group=None, background=False):
     if get_world_size(group) == 1 or SKIP_A2A:
         return input if not background else (input, lambda *a: None)
     out = torch.empty_like(input)
-    if background and not (input.is_cuda and dist.get_backend(group) == "gloo"):
+    if background and not (input.is_cuda and _backend_of(group) == "gloo"):
         work = dist.all_to_all_single(out, input, group=group, async_op=True)
         return out, work.wait
     exchange_equal_split(out, input, group)
