@@ -293,6 +293,7 @@ print("RCCL_OVERLAP_OK")
     "--eval --dtype=bfloat16 --batch_size=16 --num_tokens=256 --num_local_experts=64 --top=2 --capacity_factor=0 --megablocks_size=4 --num_steps=12",  # configs[2]
     "--dtype=float32 --batch_size=4 --num_tokens=512 --hidden_size=128 --num_local_experts=2 --top=1 --num_steps=5",                # configs[0] flags, on the GPU (training)
     "--eval --dtype=float16 --batch_size=8 --num_tokens=512 --model_dim=1024 --hidden_size=1024 --num_local_experts=16 --fp32_gate --a2a_ffn_overlap_degree=2 --num_steps=12",
+    "--eval --dtype=bfloat16 --batch_size=8 --num_tokens=256 --model_dim=512 --hidden_size=1024 --num_local_experts=8 --expert_type=llama_ffn --use_tensorcore --num_steps=12",
 ])
 def test_helloworld_driver(flags):
     """The reference's benchmark/driver script surface (examples/helloworld.py flags)."""
@@ -310,6 +311,25 @@ def test_helloworld_driver(flags):
         assert len(set(losses)) == 1, "eval steps are deterministic"
     else:
         assert losses[-1] < losses[0], "SGD on the MoE layer must reduce the loss"
+
+
+def test_helloworld_checkpoint_flag(tmp_path):
+    """--checkpoint_path (helloworld.py:103-108,159-160): the first run trains from scratch and saves, the second
+    loads the saved state and therefore starts where the first one ended."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    ck = str(tmp_path / "ckpt-{rank}-of-{size}.pt")
+    flags = f"--dtype=float32 --batch_size=4 --num_tokens=128 --model_dim=128 --hidden_size=64 --num_local_experts=2 --top=1 --num_steps=10 --checkpoint_path={ck}"
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-m", "tutel_amd.examples.helloworld"] + flags.split(), cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        runs.append([float(l.split("loss = ")[1].split(",")[0]) for l in r.stdout.splitlines() if l.startswith("STEP-")])
+    assert os.path.exists(ck.format(rank=0, size=1))
+    assert runs[1][0] < runs[0][0] and abs(runs[1][0] - runs[0][-1]) < abs(runs[0][0] - runs[0][-1])
 
 
 def test_helloworld_training_losses_match_reference():

@@ -9,6 +9,7 @@ step_time / tflops per step and the average of the last 10 steps.
            -m tutel_amd.examples.helloworld --eval --num_local_experts=8 --a2a_ffn_overlap_degree=2
 """
 import argparse
+import os
 
 import torch
 import torch.nn.functional as F
@@ -38,6 +39,9 @@ def main():
     ap.add_argument("--eval", default=False, action="store_true")
     ap.add_argument("--capacity_factor", type=float, default=1.0)
     ap.add_argument("--megablocks_size", type=int, default=0)
+    ap.add_argument("--checkpoint_path", type=str, default="")
+    ap.add_argument("--use_tensorcore", default=False, action="store_true")  # accepted for CLI compatibility: no TF32 on gfx950
+    ap.add_argument("--expert_type", type=str, default="ffn")
     args = ap.parse_args()
 
     env = system.init_data_model_parallel(backend="nccl" if args.device == "cuda" else "gloo")
@@ -47,12 +51,19 @@ def main():
 
     layer = tutel_moe.moe_layer(
         gate_type={"type": "top", "k": args.top, "fp32_gate": args.fp32_gate, "capacity_factor": args.capacity_factor},
-        experts={"type": "ffn", "num_experts_per_device": args.num_local_experts, "hidden_size_per_expert": args.hidden_size,
-                 "activation_fn": lambda x: F.relu(x)},
+        experts={"type": args.expert_type, "num_experts_per_device": args.num_local_experts,
+                 "hidden_size_per_expert": args.hidden_size, "activation_fn": lambda x: F.relu(x)},
         model_dim=args.model_dim, scan_expert_func=lambda n, p: setattr(p, "skip_allreduce", True),
         seeds=(1, rank + 1, 1), a2a_ffn_overlap_degree=args.a2a_ffn_overlap_degree,
         parallel_type=args.parallel_type, use_2dh=args.use_2dh).to(device)
     dprint(layer)
+    checkpoint_path = ""
+    if args.checkpoint_path:  # per-rank files, pattern with {rank} / {size} (helloworld.py:103-108)
+        checkpoint_path = system.apply_rank_size_from_pattern(args.checkpoint_path, rank=rank, size=world)
+        if os.path.exists(checkpoint_path):
+            layer.load_state_dict(torch.load(checkpoint_path))
+        else:
+            print("Checkpoint not loaded: file `%s` is not found. Will train the model from start." % checkpoint_path)
 
     def model(inp):
         out = layer(inp, megablocks_size=args.megablocks_size) if args.megablocks_size > 0 else layer(inp)
@@ -90,6 +101,8 @@ def main():
         if i + 10 >= args.num_steps:
             avg += t1 - t0
     dprint("\n[Summary] Average synchronized step_time = %s sec." % (avg / 10))
+    if checkpoint_path:
+        torch.save(layer.state_dict(), checkpoint_path)
 
 
 if __name__ == "__main__":
