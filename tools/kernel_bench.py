@@ -90,6 +90,15 @@ def main():
         rec(f"expert_gemm1 EP shape ({El2}x{R2}x{H}x{M})", timeit(lambda: ops.expert_gemm(a2, w1[:El2], b1[:El2], True, act="relu"), iters=20), by2, f2)
         rec(f"expert_gemm2 EP shape ({El2}x{R2})", timeit(lambda: ops.expert_gemm(a2, w2[:El2], b2[:El2], False), iters=20), by2, f2)
         rec(f"torch.bmm EP shape ({El2}x{R2}) (yardstick)", timeit(lambda: torch.matmul(a2, w2[:El2]), iters=20), by2, f2)
+    # SwiGLU expert (experts/llama_ffn.py): three launches, silu and the gating product fused into the first two
+    from tutel_amd.experts.llama_ffn import LlamaFFNNetwork
+    net = LlamaFFNNetwork(M, H, E, 1).to(dtype).to(dev).eval()
+
+    class Ctx:
+        group = None
+    with torch.no_grad():
+        us = timeit(lambda: net(enc.view(E, C, M), Ctx), iters=30)
+    rec("llama_ffn SwiGLU expert (3 grouped GEMMs, E=64 x 128 rows)", us, (3 * E * H * M + 2 * E * C * M + 3 * E * C * H) * s, 3 * 2 * E * C * M * H)
     # one pipeline stage of the overlapped all-to-all at degree 2: half the local experts, all W*C rows
     from tutel_amd import _lib
     for El2, R2 in ((16, 256), (8, 512), (4, 1024)):
