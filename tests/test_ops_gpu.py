@@ -22,12 +22,12 @@ def _ops():
     return ops
 
 
-@pytest.fixture(params=["auto", "tile256x256", "tile256x128"])
+@pytest.fixture(params=["auto", "tile256x256", "tile256x128", "tile256x128ring3"])
 def big_tile(request):
     """auto: the library picks the tile (the small test shapes land on the 128-tile kernels);
     tile256x256 / tile256x128: force the 256-row kernels wherever they apply (N >= 128; 256x128: k-major)."""
     from tutel_amd import ops, _lib
-    ops.set_option(_lib.OPT_GEMM_TILE, {"auto": -1, "tile256x256": 1, "tile256x128": 2}[request.param])
+    ops.set_option(_lib.OPT_GEMM_TILE, {"auto": -1, "tile256x256": 1, "tile256x128": 2, "tile256x128ring3": 3}[request.param])
     yield request.param
     ops.set_option(_lib.OPT_GEMM_TILE, -1)
 
@@ -394,7 +394,7 @@ def test_expert_gemm_kernels_are_bit_identical(kmajor):
     b = torch.randn([E, N], generator=g).bfloat16().cuda()
     outs = []
     try:
-        for impl, tile in ((0, 0), (1, 0), (-1, 1), (-1, 2)):
+        for impl, tile in ((0, 0), (1, 0), (-1, 1), (-1, 2), (-1, 3)):
             ops.set_option(_lib.OPT_GEMM_IMPL, impl)
             ops.set_option(_lib.OPT_GEMM_TILE, tile)
             outs.append(ops.expert_gemm(a, w, b, kmajor, act="gelu"))

@@ -18,7 +18,7 @@ def main():
         a = torch.randn([El, R, M], generator=g).bfloat16().cuda()
         res = {}
         for rep in range(3):
-            for name, opt in (("128", 0), ("256x128", 2), ("256x256", 1)):
+            for name, opt in (("128", 0), ("256x128", 2), ("256x128 ring3", 3), ("256x256", 1)):
                 ops.set_option(_lib.OPT_GEMM_TILE, opt)
                 for _ in range(20):
                     ops.expert_gemm(a, w1[:El], b1[:El], True, act="relu")

@@ -560,14 +560,14 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
 
 // NI = 32-column MFMA tiles per wave: 4 -> 256 x 256 block tile (two 128-column weight sub-tiles per
 // stage), 2 -> 256 x 128 (one sub-tile; for launches whose 256 x 256 grid would leave CUs idle).
-template <typename T, bool W_KMAJOR, int ACT, int NI>
+template <typename T, bool W_KMAJOR, int ACT, int NI, int NS>
 __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs p) {
   constexpr int NSUB = NI / 2;              // 128-column weight sub-tiles per stage
   constexpr int WPW = 2 * NSUB;             // weight DMA pieces per wave and stage
   constexpr int BN = NI * 64;               // block tile columns
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [2][2 * GL_STAGE]      (256 rows x 64 k)
-  uint16_t *sW = sA + 4 * GL_STAGE;                   // [2][NSUB][GL_STAGE]
+  uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [NS][2 * GL_STAGE]      (256 rows x 64 k)
+  uint16_t *sW = sA + NS * 2 * GL_STAGE;              // [NS][NSUB][GL_STAGE]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -697,29 +697,60 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
         acc[ni][mi] = Mma<T>::run(FW[ni], FA[mi], acc[ni][mi]);                        \
   } while (0)
 
-  GB_ISSUE(0, 0);
-  __syncthreads();
+#define GB_TILE(BUF)                                                                   \
+  do {                                                                                 \
+    const uint16_t *ca = sA + (BUF) * 2 * GL_STAGE, *cw = sW + ((BUF) * NSUB + wsub) * GL_STAGE; \
+    /* two half-tiles: fragments of two k-steps, then their MFMAs; the partner wave on the SIMD runs its MFMAs \
+       while this one waits for LDS */                                                 \
+    u32x4 fa[2][2], fw[2][NI];                                                         \
+    GB_LOAD_FRAGS(fa[0], fw[0], 0);                                                    \
+    GB_LOAD_FRAGS(fa[1], fw[1], 1);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    GB_MMA(fa[0], fw[0]);                                                              \
+    GB_MMA(fa[1], fw[1]);                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    GB_LOAD_FRAGS(fa[0], fw[0], 2);                                                    \
+    GB_LOAD_FRAGS(fa[1], fw[1], 3);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    GB_MMA(fa[0], fw[0]);                                                              \
+    GB_MMA(fa[1], fw[1]);                                                              \
+  } while (0)
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) GB_ISSUE(kt + 1, buf ^ 1);
-    const uint16_t *ca = sA + buf * 2 * GL_STAGE, *cw = sW + (buf * NSUB + wsub) * GL_STAGE;
-    // two half-tiles: fragments of two k-steps (48 registers), then their 16 MFMAs; the partner wave
-    // on the SIMD runs its MFMAs while this one waits for LDS
-    u32x4 fa[2][2], fw[2][NI];
-    GB_LOAD_FRAGS(fa[0], fw[0], 0);
-    GB_LOAD_FRAGS(fa[1], fw[1], 1);
-    __builtin_amdgcn_sched_barrier(0);
-    GB_MMA(fa[0], fw[0]);
-    GB_MMA(fa[1], fw[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    GB_LOAD_FRAGS(fa[0], fw[0], 2);
-    GB_LOAD_FRAGS(fa[1], fw[1], 3);
-    __builtin_amdgcn_sched_barrier(0);
-    GB_MMA(fa[0], fw[0]);
-    GB_MMA(fa[1], fw[1]);
+  if (NS == 2) {
+    GB_ISSUE(0, 0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) GB_ISSUE(kt + 1, buf ^ 1);
+      GB_TILE(buf);
+      __syncthreads();  // all waves done with stage `buf`; next tile's DMA has landed (vmcnt(0))
+    }
+  } else {
+    // NS-slot ring (the 256 x 128 tile leaves room for three 48 KB slots): NS - 1 tiles in flight while one is
+    // consumed.  A __syncthreads would drain every DMA, so the wait is a hand-counted vmcnt (each tile = 4 + WPW
+    // DMA ops per wave, landing in order) and a bare s_barrier, which also says every wave is done reading the
+    // slot the next issue overwrites.
+    constexpr int OPS = 4 + WPW;
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+      if (t < nk) GB_ISSUE(t, t);
+    int kt = 0, slot = 0;
+    for (; kt + NS - 1 < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * (NS - 2)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const int nslot = slot == 0 ? NS - 1 : slot - 1;  // (kt + NS - 1) % NS
+      GB_ISSUE(kt + NS - 1, nslot);
+      GB_TILE(slot);
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    for (; kt < nk; ++kt) {  // drain
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      GB_TILE(slot);
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    }
   }
+#undef GB_TILE
 #undef GB_ISSUE
 #undef GB_LOAD_FRAGS
 #undef GB_MMA
@@ -728,13 +759,13 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   gemm_epilogue<T, ACT, NI>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
 }
 
-template <typename T, bool KM, int ACT, int NI>
+template <typename T, bool KM, int ACT, int NI, int NS = 2>
 static int launch_big(const GemmArgs &a, hipStream_t st) {
   GemmArgs b = a;
   b.ntm = (a.R + GB_BM - 1) / GB_BM;
   b.ntn = (a.N + NI * 64 - 1) / (NI * 64);
-  const size_t lds = (size_t)2 * (2 + NI / 2) * GL_STAGE * 2;
-  auto kern = expert_gemm_big_kernel<T, KM, ACT, NI>;
+  const size_t lds = (size_t)NS * (2 + NI / 2) * GL_STAGE * 2;
+  auto kern = expert_gemm_big_kernel<T, KM, ACT, NI, NS>;
   static bool optin = false;
   if (!optin) {
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -823,7 +854,10 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
     // more than one 128-row tile per expert (R > 128) already pays: the 128-tile kernels would stream every
     // weight tile once per M-tile (dropless capacity 157 at the headline shape: fc1 214 us vs 118 at R = 128)
     if (big == 1 || (big < 0 && a.R > GM_BM && t256 >= 192)) return launch_big<T, KM, ACT, 4>(a, st);
-    if (KM && (big == 2 || (big < 0 && a.R > GM_BM && t128 >= 192))) return launch_big<T, true, ACT, 2>(a, st);
+    // 256 x 128: a three-slot ring (3 x 48 KB of LDS) keeps two tiles in flight: +3-4 % over two slots on the
+    // stage shapes it is chosen for (tools/stage_probe.py); big = 2 forces the two-slot form for A/B runs
+    if (KM && big == 2) return launch_big<T, true, ACT, 2, 2>(a, st);
+    if (KM && (big == 3 || (big < 0 && a.R > GM_BM && t128 >= 192))) return launch_big<T, true, ACT, 2, 3>(a, st);
   }
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
