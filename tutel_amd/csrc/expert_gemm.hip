@@ -19,10 +19,16 @@
 //     MFMAs of the current one; one __syncthreads per K-tile; 2 blocks per CU;
 //   * LDS rows padded (+16 B for [.,k]-major tiles, +64 B for the [k][n] weight tile) so the
 //     ds_read_b128 fragment reads and the ds_read_b64_tr_b16 transposing reads are conflict-free;
-//   * [K,N]-major weights (batched_fc2_w) are consumed as stored: the k-contiguous fragment the
-//     MFMA wants is produced by gfx950's transposing LDS read, no transposed weight copy in HBM;
+//   * [K,N]-major weights (batched_fc2_w) can be consumed as stored: the k-contiguous fragment the
+//     MFMA wants is produced by gfx950's transposing LDS read (training-mode modules; eval-mode
+//     modules hand in a k-major copy laid out once, experts/ffn.py KMajorCache);
 //   * row addressing folds the expert-parallel [W,E_loc,C,M] <-> [E_loc,W*C,M] permutes
 //     (communicate.py:606-622) into the loads/stores.
+// Three kernels share this file: the register-staged 128 x 128 kernel described above, its LDS-DMA
+// sibling (global_load_lds, no VGPR / ds_write staging), and the 256-row-tile LDS-DMA kernel for
+// more than 128 rows per expert (256 x 256, or 256 x 128 on a three-slot ring), where the bound is
+// the L2 -> CU path rather than HBM.  launch_gemm() picks; every kernel walks k in the same order
+// for a given output element, so the choice never changes a bit of the result.
 #include <stdlib.h>
 
 #include "common.h"
@@ -840,14 +846,14 @@ static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
 // LDS buffer at 3 blocks/CU, prefetch distance 2 (two register sets), a 128x256 8-wave 3-stage
 // LDS-DMA ring, a single-stage LDS-DMA variant at 4 blocks/CU.  Ablation: compute alone 69 us, loads+staging alone 80-115 us -- the remaining
 // loss is phase serialisation inside a block, not DRAM (pure loads of the same pattern: 77-90 us).
-// TUTEL_AMD_GEMM_IMPL=0|1 forces register-staged | LDS-DMA for A/B runs.
+// tutel_amd_set_option(TUTEL_OPT_GEMM_IMPL, 0|1) forces register-staged | LDS-DMA for A/B runs.
 template <typename T, bool KM, int ACT>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   const int impl = tutel_get_option(TUTEL_OPT_GEMM_IMPL), big = tutel_get_option(TUTEL_OPT_GEMM_TILE);
   // R > 128 rows per expert: the 256-row tiles (more flop per byte crossing L2 -> CU) -- provided the grid
   // still covers the chip: one such block occupies a CU, so with fewer than ~3/4 x 256 blocks CUs sit idle.
   // 256 x 256 first, 256 x 128 when only that fills the chip (a pipeline stage of the overlapped
-  // all-to-all is half a GEMM), else the 128-tile kernels.  big = 1 forces 256 x 256, 2 forces 256 x 128.
+  // all-to-all is half a GEMM), else the 128-tile kernels.  big = 1 forces 256 x 256, 2 / 3 force 256 x 128.
   if (a.N >= GM_BN && big != 0) {
     const long long mt256 = (long long)a.E_loc * ((a.R + GB_BM - 1) / GB_BM);
     const long long t256 = mt256 * ((a.N + 255) / 256), t128 = mt256 * ((a.N + 127) / 128);
