@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--top", type=int, default=2)
     ap.add_argument("--a2a_ffn_overlap_degree", type=int, default=None)
     ap.add_argument("--fp32_gate", action="store_true")
+    ap.add_argument("--dtype", choices=["bfloat16", "float16"], default="bfloat16", help="the headline metric is bf16")
     ap.add_argument("--capacity_factor", type=float, default=1.0,
                     help="BASELINE configs[2]: 0 = dropless (capacity read back from the device each step)")
     ap.add_argument("--megablocks_size", type=int, default=0, help="configs[2]: row granularity of the dropless expert GEMMs")
@@ -167,7 +168,8 @@ def main():
     assert E % world == 0
     E_loc = E // world
     overlap = args.a2a_ffn_overlap_degree or (2 if world > 1 else 1)
-    dtype = torch.bfloat16
+    dtype = getattr(torch, args.dtype)
+    dname = "bf16" if dtype == torch.bfloat16 else "fp16"
 
     # like helloworld.py:77,93-94: the capacity factor belongs to the gate, megablocks_size to the forward call
     layer = build_layer(M, H, E_loc, k, rank, overlap, dtype, args.fp32_gate, args.capacity_factor).to(dev).eval()
@@ -227,12 +229,12 @@ def main():
     if timer.rows[True] >= 256:
         # >= 256 rows per expert and launch (expert-parallel ranks): the 256 x 256-tile kernel, bound by the MFMA rate
         tf = timer.flops[True] / fc1_us * 1e-6
-        roofline = {"bound": "mfma", "kernel": "expert_gemm_big_kernel<bf16,k-major,relu> (fc1 grouped GEMM, 256-row tile: 256x256 or 256x128 by grid size, LDS-DMA)",
+        roofline = {"bound": "mfma", "kernel": f"expert_gemm_big_kernel<{dname},k-major,relu> (fc1 grouped GEMM, 256-row tile: 256x256 or 256x128 by grid size, LDS-DMA)",
                     "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                     "traffic": None, "flops_per_launch": timer.flops[True], "rows_per_expert": timer.rows[True],
                     "avg_launch_us": round(fc1_us, 2), "launches_timed": n1, "fc2_gemm": fc2_obj}
     else:
-        roofline = {"bound": "hbm", "kernel": "expert_gemm_glds_kernel<bf16,k-major,relu> (fc1 grouped GEMM, LDS-DMA)",
+        roofline = {"bound": "hbm", "kernel": f"expert_gemm_glds_kernel<{dname},k-major,relu> (fc1 grouped GEMM, LDS-DMA)",
                     "achieved": round(fc1_bytes / fc1_us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(fc1_bytes / fc1_us * 1e-3 / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": fc1_bytes, "avg_launch_us": round(fc1_us, 2), "launches_timed": n1,
@@ -245,10 +247,10 @@ def main():
             "metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic" if not share else "synthetic; TEST HOOK: all ranks share one GPU, host-staged all-to-all -- not a measurement",
+            "dtype": dname, "data": "synthetic" if not share else "synthetic; TEST HOOK: all ranks share one GPU, host-staged all-to-all -- not a measurement",
             "config": {"workload": "BASELINE.json configs[1]: tutel.moe.moe_layer forward (eval), per GPU 4096 tokens "
                                    "(batch 16 x 256) x model_dim 2048, hidden 2048, 64 global experts, top-2, "
-                                   "capacity_factor 1.0, ReLU, bf16, random-init weights",
+                                   f"capacity_factor {args.capacity_factor}, ReLU, {dname}, random-init weights",
                        "tokens_per_gpu": T, "model_dim": M, "hidden_size": H, "global_experts": E, "top_k": k,
                        "capacity": C, "parallelism": f"ep{world}" if world > 1 else "single-gpu",
                        "a2a_ffn_overlap_degree": overlap, "fp32_gate": bool(args.fp32_gate),
