@@ -16,13 +16,16 @@ N > 1: experts are sharded E_loc = 64/N per rank (expert parallel, RCCL all_to_a
 xGMI), every rank keeps its own 4096 tokens -> per-GPU work is fixed: weak scaling,
 value = N * 4096 / t.
 
-Timing: W untimed warm-up steps; barrier + synchronize; exactly K steps; synchronize + barrier;
-MAX over ranks.  Rank 0 prints ONE JSON line.
+Timing: untimed initialisation passes (--settle: allocator / weight pre-layout / clock state), W untimed
+warm-up steps; barrier + synchronize; exactly K steps; synchronize + barrier; MAX over ranks.  Rank 0
+prints ONE JSON line.
 
-`roofline`: the dominant kernel is the fc1 grouped GEMM (expert_gemm_glds_kernel<bf16,k-major,relu>):
-HBM-bound at this shape (each expert has only 128 rows).  achieved = algorithmic bytes per launch
-(E_loc*H*M weights + E_loc*R*M tokens + E_loc*R*H hidden out, x2 bytes) / its average duration,
-measured with HIP events on the launch stream inside the timed region.
+`roofline`: the dominant kernel is the fc1 grouped GEMM.  N = 1 (128 rows per expert):
+expert_gemm_glds_kernel<bf16,k-major,relu>, HBM-bound; achieved = algorithmic bytes per launch
+(E_loc*H*M weights + E_loc*R*M tokens + E_loc*R*H hidden out, x2 bytes) / its average duration.
+More than 128 rows per expert and launch (N > 1, --tokens 65536, dropless): expert_gemm_big_kernel,
+MFMA-bound; achieved = flop per launch / its average duration.  Durations are measured with HIP events
+on the launch stream inside the timed region.
 `cpu_baseline`: the CPU oracle (a port of the reference CPU path, oracle/moe_oracle.py) timed on
 this box's host cores on a bounded sample, rank 0, N=1 only.  Checker code is used here ONLY as
 that reported baseline; it is never part of the measured GPU path.
