@@ -106,7 +106,7 @@ def test_bench_script_multi_rank_code_path():
     env = dict(os.environ, TUTEL_AMD_BENCH_SHARE_GPU="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--settle", "0"],
                          env=env, cwd=root, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
