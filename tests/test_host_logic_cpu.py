@@ -389,3 +389,44 @@ def test_overlap_plan_layouts_replayed_for_many_ranks(oracle, W, E_loc, Cap, deg
                     c = kw["chunk_rows"]
                     row = ((l // c) * E + e) * c + l % c
                 assert int(flat[row]) == tag(r, e, l)
+
+
+def _vcoll_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from tutel import system, net
+        system.init_data_model_parallel(backend="gloo")
+        # the reference's own examples (examples/nccl_all_to_all_v.py, nccl_all_gather_v.py), world size 2
+        if rank == 0:
+            inp, counts = torch.tensor([10, 10, 10, 10, 10]), torch.tensor([1, 4])
+        else:
+            inp, counts = torch.tensor([20, 20, 20]), torch.tensor([2, 1])
+        (out, out2), sizes = net.batch_all_to_all_v([inp, inp.float() * 0.5], counts)
+        want = torch.tensor([10, 20, 20]) if rank == 0 else torch.tensor([10, 10, 10, 10, 20])
+        ok = torch.equal(out, want) and torch.equal(out2, want.float() * 0.5)
+        ok = ok and torch.equal(sizes, torch.tensor([1, 2]) if rank == 0 else torch.tensor([4, 1]))
+        (g,), gs = net.batch_all_gather_v([inp])
+        ok = ok and torch.equal(g, torch.tensor([10] * 5 + [20] * 3)) and torch.equal(gs.view(-1), torch.tensor([5, 3]))
+        q.put((rank, bool(ok), f"{out.tolist()} {sizes.tolist()} {g.tolist()}"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+def test_variable_size_collectives_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vcoll_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, info in res:
+        assert ok, f"rank {rank}: {info}"
+    from tutel import net
+    outs, sizes = net.batch_all_to_all_v([torch.arange(4)], [4])   # single process: identity
+    assert torch.equal(outs[0], torch.arange(4)) and sizes.tolist() == [4]

@@ -237,12 +237,61 @@ def simple_all_gather(input, group=None):
     return out.view([-1] + list(input.shape[1:]))
 
 
+def _staged(t, group):
+    """device tensor on a gloo group -> host copy (see exchange_equal_split), else the tensor itself"""
+    return t.cpu() if t.is_cuda and dist.get_backend(group) == "gloo" else t
+
+
 def batch_all_to_all_v(datas, partition_sizes, group=None):
-    raise NotImplementedError("batch_all_to_all_v is outside the MoE forward hot path (SURVEY 2c: OUT OF SCOPE)")
+    """Variable-size all-to-all of a batch of flat tensors sharing one split (reference:
+    communicate.py:225-241 over custom_kernel.cpp:463-491, a grouped ncclSend/ncclRecv loop):
+    partition_sizes[r] elements of every tensor go to rank r.  Returns (outputs, out_sizes) where
+    out_sizes[r] = number of elements received from rank r.  Here: all_to_all_single with split lists."""
+    assert type(datas) in (tuple, list), "data type for batch_all_to_all_v() is not a list of tensors"
+    in_sizes = partition_sizes
+    if not torch.is_tensor(in_sizes):
+        in_sizes = torch.tensor(in_sizes, dtype=torch.int64, device=datas[0].device)
+    else:
+        in_sizes = in_sizes.to(torch.int64)
+    world_size = get_world_size(group)
+    assert in_sizes.numel() == world_size
+    if world_size == 1:
+        return list(datas), in_sizes
+    out_sizes = simple_all_to_all(in_sizes, group=group)
+    send, recv = [int(v) for v in in_sizes.tolist()], [int(v) for v in out_sizes.tolist()]  # the one sync the API implies
+    outputs = []
+    for data in datas:
+        flat = data.contiguous().view(-1)
+        assert flat.numel() == sum(send), "Tensor instances within batch_all_to_all_v are supposed to share same length."
+        src = _staged(flat, group)
+        out = torch.empty([sum(recv)], dtype=flat.dtype, device=src.device)
+        dist.all_to_all_single(out, src, output_split_sizes=recv, input_split_sizes=send, group=group)
+        outputs.append(out.to(flat.device))
+    return outputs, out_sizes
 
 
 def batch_all_gather_v(datas, group=None):
-    raise NotImplementedError("batch_all_gather_v is outside the MoE forward hot path (SURVEY 2c: OUT OF SCOPE)")
+    """Variable-size all-gather of a batch of flat tensors (reference: communicate.py:243-255 over
+    custom_kernel.cpp:493-518): every rank receives the concatenation, in rank order, of all ranks'
+    tensors.  Returns (outputs, output_sizes)."""
+    assert type(datas) in (tuple, list), "data type for batch_all_gather_v() is not a list of tensors"
+    datas = [data.contiguous().view(-1) for data in datas]
+    input_size = torch.tensor([int(datas[0].numel())], dtype=torch.int64, device=datas[0].device)
+    world_size = get_world_size(group)
+    if world_size == 1:
+        return list(datas), input_size
+    output_sizes = simple_all_gather(input_size, group=group)
+    recv = [int(v) for v in output_sizes.tolist()]
+    outputs = []
+    for flat in datas:
+        assert flat.numel() == int(input_size), "Tensor instances within batch_all_gather_v are supposed to share same length."
+        src = _staged(flat, group)
+        # my tensor to every rank, every rank's tensor to me: an all-to-all whose input is W copies of the tensor
+        out = torch.empty([sum(recv)], dtype=flat.dtype, device=src.device)
+        dist.all_to_all_single(out, src.repeat(world_size), output_split_sizes=recv,
+                               input_split_sizes=[flat.numel()] * world_size, group=group)
+        outputs.append(out.to(flat.device))
+    return outputs, output_sizes
 
 
 # ---------------------------------------------------------------------------------------------
