@@ -1,0 +1,27 @@
+"""Dev tool: the expert-parallel test of tests/test_ep_ranks_one_gpu.py with EIGHT ranks sharing one GPU
+(too slow for the suite: eight processes import torch at once)."""
+import os
+import sys
+
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import test_ep_ranks_one_gpu as T  # noqa: E402
+
+
+def main():
+    for degree, E_loc in ((2, 2), (1, 1), (2, 1)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = T._free_port()
+        procs = [ctx.Process(target=T._worker, args=(r, 8, port, degree, E_loc, q)) for r in range(8)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+        print("world 8, degree", degree, "E_loc", E_loc, "->", all(r[1] for r in res), sorted(set(r[2][:60] for r in res))[:2], flush=True)
+
+
+if __name__ == "__main__":
+    main()
