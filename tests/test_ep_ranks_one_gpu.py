@@ -95,6 +95,83 @@ def test_expert_parallel_ranks_sharing_one_gpu(world, degree, E_loc):
             assert plans == [E_loc % degree == 0], (plans, "expected the expert-sliced pipeline iff degree divides E_loc")
 
 
+def _train_worker(rank, world, port, frozen_experts, q):
+    """degree > 1, W > 1, grad enabled, layer INPUT without grad.  (a) trainable experts: the
+    overlapped path must keep the autograd graph to the expert weights (same grads as degree 1);
+    (b) frozen experts + trainable router: outputs stay gated and the router gets its gradient."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import torch.distributed as dist
+        from oracle import moe_oracle as O
+        from tutel import moe
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        T, M, H, k, E_loc = 256, 64, 64, 2, 2
+        E = E_loc * world
+        dtype = torch.float32 if not frozen_experts else torch.bfloat16
+        x = O.make_problem(T, M, H, E, dtype=dtype, seed=100 + rank)[0].cuda()
+        _, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=dtype, seed=7)
+        sl = slice(rank * E_loc, (rank + 1) * E_loc)
+        res = {}
+        for degree in (1, 2):
+            old = torch.get_default_dtype()
+            torch.set_default_dtype(dtype)
+            layer = moe.moe_layer(gate_type={"type": "top", "k": k, "fp32_gate": True}, model_dim=M,
+                                  experts={"type": "ffn", "num_experts_per_device": E_loc, "hidden_size_per_expert": H,
+                                           "activation_fn": lambda t: torch.nn.functional.relu(t)},
+                                  a2a_ffn_overlap_degree=degree)
+            torch.set_default_dtype(old)
+            with torch.no_grad():
+                layer.gates[0].wg.weight.copy_(wg.float())
+                layer.experts.batched_fc1_w.copy_(w1[sl]); layer.experts.batched_fc1_bias.copy_(b1[sl])
+                layer.experts.batched_fc2_w.copy_(w2[sl]); layer.experts.batched_fc2_bias.copy_(b2[sl])
+            layer = layer.cuda()
+            if frozen_experts:
+                layer.eval()
+                for p in layer.experts.parameters():
+                    p.requires_grad_(False)
+            assert not x.requires_grad and torch.is_grad_enabled()
+            y = layer(x)
+            (y.float().square().sum() + y.l_aux.float()).backward()
+            torch.cuda.synchronize()
+            res[degree] = (y.detach().float().cpu(),
+                           None if frozen_experts else layer.experts.batched_fc1_w.grad.float().cpu(),
+                           None if frozen_experts else layer.experts.batched_fc2_w.grad.float().cpu(),
+                           layer.gates[0].wg.weight.grad.float().cpu())
+        y1, g11, g12, gw1 = res[1]
+        y2, g21, g22, gw2 = res[2]
+        ok = torch.allclose(y1, y2, rtol=2e-2 if frozen_experts else 1e-5, atol=2e-2 if frozen_experts else 1e-5)
+        info = f"y diff {float((y1 - y2).abs().max()):.3e}"
+        ok = ok and float(gw2.abs().max()) > 0 and torch.allclose(gw1, gw2, rtol=5e-2 if frozen_experts else 1e-4, atol=5e-2 if frozen_experts else 1e-5)
+        info += f"; gate-grad max {float(gw2.abs().max()):.3e} diff {float((gw1 - gw2).abs().max()):.3e}"
+        if not frozen_experts:
+            ok = ok and float(g21.abs().max()) > 0 and float(g22.abs().max()) > 0
+            ok = ok and torch.allclose(g11, g21, rtol=1e-4, atol=1e-5) and torch.allclose(g12, g22, rtol=1e-4, atol=1e-5)
+            info += f"; fc1-grad max {float(g21.abs().max()):.3e} diff {float((g11 - g21).abs().max()):.3e}"
+        q.put((rank, bool(ok), info, []))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc(), []))
+
+
+@pytest.mark.parametrize("frozen_experts", [False, True])
+def test_overlapped_training_keeps_autograd_graph(frozen_experts):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, frozen_experts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, info, _ in res:
+        assert ok, f"rank {rank}: {info}"
+
+
 def test_bench_script_multi_rank_code_path():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the
     single-GPU test hook: the N > 1 branch of the script (sharded experts, overlap degree 2, max-over-ranks

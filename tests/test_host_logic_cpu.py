@@ -200,6 +200,29 @@ def test_activation_classifier():
     drop = torch.nn.Dropout(0.5).train()
     assert classify_activation(lambda t: drop(F.relu(t))) is None  # stochastic -> never fused
     assert classify_activation(lambda t: F.relu(t) * 1.5) is None
+    # functions that equal relu on a narrow range only must NOT be fused
+    assert classify_activation(F.relu6) is None
+    assert classify_activation(lambda t: F.hardtanh(t, 0.0, 4.0)) is None
+    assert classify_activation(lambda t: F.hardtanh(t, 0.0, 100.0)) is None
+    assert classify_activation(lambda t: t.clamp(min=0, max=30000.0)) is None
+    assert classify_activation(lambda t: F.leaky_relu(t, 1e-3)) is None
+    assert classify_activation(lambda t: F.gelu(t, approximate="tanh")) is None
+    assert classify_activation(F.relu) == "relu" and classify_activation(torch.nn.ReLU()) == "relu"
+    assert classify_activation(torch.nn.GELU()) == "gelu" and classify_activation(torch.nn.GELU(approximate="tanh")) is None
+    assert classify_activation(lambda t: F.relu(t), torch.bfloat16) == "relu"
+    assert classify_activation(lambda t: F.silu(t), torch.float16) == "silu"
+    # a function of (x, module) is opaque: never probed (side effects), never fused -- unless tagged
+    from tutel_amd.experts.ffn import FusedExpertsNetwork
+    calls = []
+
+    def with_self(t, mod):
+        calls.append(1)
+        return F.relu(t)
+    net = FusedExpertsNetwork(8, 8, 1, 1, activation_fn_with_self=with_self)
+    assert net.fused_activation() is None and not calls
+    with_self._tutel_amd_act = "relu"
+    net = FusedExpertsNetwork(8, 8, 1, 1, activation_fn_with_self=with_self)
+    assert net.fused_activation() == "relu" and not calls
 
 
 # ---- world_size 2 over gloo ---------------------------------------------------------------------

@@ -20,7 +20,6 @@ import torch.nn.functional as F
 
 from .. import net, ops
 
-_PROBE = torch.tensor([-3.0, -1.0, -0.25, 0.0, 0.25, 0.5, 1.0, 2.0, 4.0])
 # eval-mode weight pre-layout: keep a [E, N, K] (k-major) copy of weights stored [E, K, N]; 0 disables
 _PREPACK = int(os.environ.get("TUTEL_AMD_PREPACK", "1")) != 0
 
@@ -56,22 +55,67 @@ class KMajorCache:
         self._store.clear()
 
 
-def classify_activation(fn):
-    """Name of the fused epilogue equivalent to `fn`, or None.  Decided by evaluating `fn` on a
-    probe vector (twice, to reject stochastic functions such as dropout in training mode)."""
+def _probe_points():
+    """fp32 probe: dense around the origin, then every magnitude a bf16 / fp16 / fp32 hidden activation can take."""
+    lin = torch.linspace(-16.0, 16.0, 2049)
+    mag = torch.logspace(-30, 38, 545)
+    big = torch.tensor([60000.0, 65504.0, 1e5, 3.3e38])
+    return torch.cat([lin, mag, -mag, big, -big, torch.zeros(1)])
+
+
+_PROBE = _probe_points()
+_REFS = (("relu", F.relu), ("gelu", F.gelu), ("silu", F.silu), ("none", lambda t: t))
+# callables that ARE the fused epilogues (identity match, no evaluation needed)
+_KNOWN_FNS = {F.relu: "relu", torch.relu: "relu", F.gelu: "gelu", F.silu: "silu"}
+
+
+def classify_activation(fn, dtype=None):
+    """Name of the fused GEMM epilogue that computes `fn`, or None (-> ATen path, the function is called).
+
+    Recognised by identity: a string name, an explicit `_tutel_amd_act` tag, F.relu / F.gelu / F.silu
+    themselves and default-argument nn.ReLU / nn.GELU / nn.SiLU modules.  Any other callable (typically
+    the `lambda x: F.relu(x)` of the reference's examples, helloworld.py:86) is evaluated on a wide probe
+    -- 2049 points on [-16, 16] plus every decade from 1e-30 to 3.3e38 in both signs, in fp32 AND in
+    the experts' working dtype, twice (stochastic functions are rejected) -- and fused only when it
+    matches an epilogue on every point: clipped variants (relu6, hardtanh, clamp) differ there."""
     if isinstance(fn, str):
         return fn if fn in ops.ACT_CODES else None
     tag = getattr(fn, "_tutel_amd_act", None)
     if tag in ops.ACT_CODES:
         return tag
     try:
+        if fn in _KNOWN_FNS:
+            return _KNOWN_FNS[fn]
+    except TypeError:
+        pass
+    if isinstance(fn, torch.nn.Module):
+        if type(fn) is torch.nn.ReLU:
+            return "relu"
+        if type(fn) is torch.nn.SiLU:
+            return "silu"
+        if type(fn) is torch.nn.GELU and getattr(fn, "approximate", "none") == "none":
+            return "gelu"
+        if type(fn) is torch.nn.Identity:
+            return "none"
+    try:
         with torch.no_grad():
-            a, b = fn(_PROBE.clone()), fn(_PROBE.clone())
-        if not (torch.is_tensor(a) and a.shape == _PROBE.shape and torch.equal(a, b)):
-            return None
-        for name, ref in (("relu", F.relu), ("gelu", F.gelu), ("silu", F.silu), ("none", lambda t: t)):
-            if torch.allclose(a, ref(_PROBE), rtol=0, atol=1e-7):
-                return name
+            found = None
+            for dt in ([torch.float32] + ([dtype] if dtype not in (None, torch.float32) else [])):
+                lim = torch.finfo(dt).max
+                probe = _PROBE.clamp(-lim, lim).to(dt)
+                a, b = fn(probe.clone()), fn(probe.clone())
+                if not (torch.is_tensor(a) and a.shape == probe.shape and a.dtype == dt and torch.equal(a, b)):
+                    return None
+                name = None
+                for cand, ref in _REFS:
+                    r = ref(probe)
+                    if torch.allclose(a.float(), r.float(), rtol=0, atol=1e-7 if dt == torch.float32 else 0.0, equal_nan=True):
+                        name = cand
+                        break
+                if name is None or (found is not None and name != found):
+                    return None
+                found = name
+            return found
     except Exception:
         pass
     return None
@@ -92,9 +136,17 @@ class FusedExpertsNetwork(torch.nn.Module):
         self.hidden_size = hidden_size_per_expert // sharded_count
         self.output_dim = output_dim or model_dim
 
+        self._act_opaque = False
         if activation_fn_with_self is not None:
             assert activation_fn is None, "Option `activation_fn_with_self` has been specified, please keep exactly one of them."
+            tag = getattr(activation_fn_with_self, "_tutel_amd_act", None)
             activation_fn = lambda x: activation_fn_with_self(x, self)  # noqa: E731
+            if tag is not None:
+                activation_fn._tutel_amd_act = tag
+            else:
+                # a function of (x, module) may read module state or have side effects (fairseq passes
+                # dropout + layernorm here): never evaluated on a probe, never replaced by an epilogue
+                self._act_opaque = True
         if activation_fn is None:
             activation_fn = F.relu
         self.activation_fn = activation_fn
@@ -135,9 +187,11 @@ class FusedExpertsNetwork(torch.nn.Module):
 
     # -- fused path -------------------------------------------------------------------------
     def fused_activation(self):
-        key = self.training
+        if self._act_opaque:
+            return None
+        key = (self.training, self.batched_fc1_w.dtype)
         if key not in self._act_cache:
-            self._act_cache[key] = classify_activation(self.activation_fn)
+            self._act_cache[key] = classify_activation(self.activation_fn, key[1])
         return self._act_cache[key]
 
     def can_fuse(self, x, ctx):

@@ -158,11 +158,14 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
 
     fused_loss = loss_fn is losses.gshard_loss and not needs_grad
 
+    # samples per expert from the GLOBAL maximum token count when ranks hold different numbers of tokens
+    # (fast_dispatch.py:181-186): every rank must derive the same capacity in every branch below
+    n = T
+    if inequivalent_tokens:
+        n = int(simple_all_reduce(torch.tensor(T, device=src.device), group=group, op=torch.distributed.ReduceOp.MAX))
+    spe = (n + E - 1) // E
     if capacity_factor > 0:
-        n = T
-        if inequivalent_tokens:
-            n = int(simple_all_reduce(torch.tensor(T, device=src.device), group=group, op=torch.distributed.ReduceOp.MAX))
-        capacity = k * int(capacity_factor * ((n + E - 1) // E))
+        capacity = k * int(capacity_factor * spe)
         rem = capacity % alignment
         capacity += (alignment - rem) if rem > 0 else 0
     else:
@@ -194,7 +197,6 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
             l_aux_dtype=src.dtype if ops.supported_dtype(src.dtype) else torch.float32, cleared_slot_map=pre)
 
     if capacity_factor <= 0:
-        spe = (T + E - 1) // E
         cap = stats[0]
         capacity = int(simple_all_reduce(cap, group=group, op=torch.distributed.ReduceOp.MAX))  # the one host sync the API implies
         if capacity_factor < 0:
@@ -232,7 +234,6 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
         l_aux = loss_fn(sc, idx2d.t().long())
 
     if get_world_rank(group) == 0 and logging.getLogger().isEnabledFor(logging.INFO):
-        spe = (T + E - 1) // E
         logging.info("Capacity = %d, real-time capacity-factor for top-%d = %s", capacity, k_req, capacity / max(1, k * spe))
 
     return RoutingPlan(E, idx2d, loc2d, gates2d if gate_list is None else None, capacity, cnt, smap, gate_list), l_aux

@@ -291,6 +291,7 @@ class MOELayer(torch.nn.Module):
                 and (self.world_size > 1 or _FORCE_OVERLAP) and self.num_global_experts >= self.world_size
                 and isinstance(self.experts, FusedExpertsNetwork) and isinstance(crit, RoutingPlan)
                 and crit[4] > 0 and crit[4] % degree == 0 and not C.SKIP_A2A and not self.use_2dh
+                and crit.gates2d is not None  # trainable router: gates live in crit[3] with autograd -> generic path
                 and (x.dtype == logits_dtype or (logits_dtype == torch.float32 and x.dtype == original_dtype))
                 and self.experts.can_fuse(x, self)):
             y = a2a_ffn_overlap_fused(self, x if x.is_contiguous() else x.contiguous(), crit, degree, self.is_postscore)
@@ -334,8 +335,13 @@ class MOELayer(torch.nn.Module):
             fused = (isinstance(self.experts, FusedExpertsNetwork) and self.world_size > 1 and len(reserve_shape) == 1
                      and self.num_global_experts >= self.world_size and not C.SKIP_A2A and self.experts.can_fuse(y, self))
             if degree > 1 and y.is_cuda:
+                # the stream pipeline carries no autograd graph: only when neither the buckets nor any
+                # expert parameter can require grad (a no-grad INPUT says nothing about the experts)
+                needs_autograd = torch.is_grad_enabled() and (
+                    y.requires_grad or any(p.requires_grad for p in self.experts.parameters()))
                 y = a2a_ffn_overlap_forward(y, expert_fn=lambda t: self.expert_local(t, reserve_shape),
-                                            a2a_ffn_overlap_degree=degree, use_2dh=self.use_2dh, group=self.group)
+                                            a2a_ffn_overlap_degree=degree, use_2dh=self.use_2dh, group=self.group,
+                                            needs_autograd=needs_autograd)
             elif fused:
                 y = self._experts_on_raw_a2a(y, reserve_shape)
             else:

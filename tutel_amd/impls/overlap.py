@@ -38,15 +38,23 @@ def _events(device, n):
     return pool
 
 
-def a2a_ffn_overlap_forward(input, expert_fn, a2a_ffn_overlap_degree, use_2dh, group):
-    """input [E, C, M] -> [E, C, M_out]; expert_fn maps [E_loc, W*c, M] -> [E_loc, W*c, M_out]."""
+def a2a_ffn_overlap_forward(input, expert_fn, a2a_ffn_overlap_degree, use_2dh, group, needs_autograd=None):
+    """input [E, C, M] -> [E, C, M_out]; expert_fn maps [E_loc, W*c, M] -> [E_loc, W*c, M_out].
+
+    needs_autograd: the caller's statement that something in the chain (the buckets OR the expert
+    parameters behind expert_fn) can require grad.  The stream pipeline below exchanges through raw
+    collectives into fresh buffers -- no autograd graph -- so it is taken only when nothing can; the
+    default (None) is the safe reading `torch.is_grad_enabled()`.  (The reference wraps every step of
+    its overlap path in autograd Functions, communicate.py:288-397.)"""
     degree = a2a_ffn_overlap_degree
     assert degree <= MAX_NUM_SPLIT, "Excepting a2a_ffn_overlap_degree (%d) <= AllToAllStatus.max_num_split (%d)." % (degree, MAX_NUM_SPLIT)
     assert input.shape[1] % degree == 0, "Excepting input.shape[%d] (%d) be multiple of a2a_ffn_overlap_degree (%d)." % (1, input.shape[1], degree)
     W = C.get_world_size(group)
     if W == 1:
         return expert_fn(input)
-    if torch.is_grad_enabled() and input.requires_grad or not input.is_cuda:
+    if needs_autograd is None:
+        needs_autograd = torch.is_grad_enabled()
+    if (torch.is_grad_enabled() and (needs_autograd or input.requires_grad)) or not input.is_cuda:
         # training / CPU: same chunking, executed in order (autograd-safe); bitwise the same result
         outs = []
         for x in input.chunk(degree, dim=1):
