@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, degree, E_loc, q):
+def _worker(rank, world, port, degree, E_loc, q, shape=None):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
         import sys
@@ -32,7 +32,7 @@ def _worker(rank, world, port, degree, E_loc, q):
         from tutel_amd.impls import overlap as OV
         dist.init_process_group("gloo", rank=rank, world_size=world)
         torch.cuda.set_device(0)
-        T, M, H, k = 512, 128, 192, 2
+        T, M, H, k = shape or (512, 128, 192, 2)
         E = E_loc * world
         dtype = torch.bfloat16
         xs = [O.make_problem(T, M, H, E, dtype=dtype, seed=100 + r)[0] for r in range(world)]
@@ -69,9 +69,15 @@ def _worker(rank, world, port, degree, E_loc, q):
                                        [b2[r * E_loc:(r + 1) * E_loc] for r in range(world)],
                                        top_k=k, fp32_gate=True, alignment=degree, accum_fp32=True)
         err = (y.cpu().double() - want[rank].double()).abs()
-        tol = 2 ** -7 * want[rank].double().abs() + 2e-3
-        ok = bool((err <= tol).all()) and torch.equal(layer.dispatch_count.cpu(), crits[rank][5])
-        q.put((rank, ok, f"max err {float(err.max()):.3e}; pipeline sliced={plans}", plans))
+        # bf16 bar (tests/test_layer_gpu.py header): 2 ulps of the element + an absolute term.  The absolute
+        # term covers 1-ulp flips of the bf16 EXPERT outputs (fp32 sums in another order round differently for
+        # ~1e-3 of the elements), which reach y scaled by the gate even where the two choices cancel: it is
+        # one bf16 ulp at the output scale, 2e-3 at the small shapes.
+        scale = float(want[rank].double().abs().max())
+        tol = 2 ** -7 * want[rank].double().abs() + max(2e-3, 2 ** -8 * scale)
+        bad = int((err > tol).sum())
+        ok = bad == 0 and torch.equal(layer.dispatch_count.cpu(), crits[rank][5])
+        q.put((rank, ok, f"max err {float(err.max()):.3e}, {bad} elements over the bar, |y|max {scale:.3f}; pipeline sliced={plans}", plans))
         dist.destroy_process_group()
     except Exception:  # pragma: no cover
         import traceback
@@ -93,6 +99,26 @@ def test_expert_parallel_ranks_sharing_one_gpu(world, degree, E_loc):
         assert ok, f"rank {rank}: {info}"
         if degree > 1:
             assert plans == [E_loc % degree == 0], (plans, "expected the expert-sliced pipeline iff degree divides E_loc")
+
+
+def test_config3_per_rank_shape_two_ranks_one_gpu():
+    """BASELINE configs[3]'s per-rank expert problem -- 8 local experts x 1024 rows, model_dim = hidden = 4096
+    (what each of 8 ranks sees with 64 global experts and 4096 tokens per rank) -- reproduced with two ranks:
+    E = 16, T = 4096 per rank => capacity 512, R = W*C = 1024 rows per expert.  Degree 2 (the config's overlap
+    degree) through the expert-sliced pipeline, 256-row-tile GEMM kernels, vs the oracle's 2-rank simulation."""
+    world, degree, E_loc = 2, 2, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, degree, E_loc, q, (4096, 4096, 4096, 2))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, info, plans in res:
+        assert ok, f"rank {rank}: {info}"
+        assert plans == [True]
 
 
 def _train_worker(rank, world, port, frozen_experts, q):

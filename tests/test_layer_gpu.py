@@ -171,6 +171,38 @@ def test_dropless_megablocks_equals_dense(oracle):
     _close(dense, yo, dtype)
 
 
+@pytest.mark.parametrize("fp32_gate", [True, False])
+def test_dropless_headline_shape_vs_oracle(oracle, fp32_gate):
+    """BASELINE configs[2] at the headline shape: T=4096, M=H=2048, E=64, top-2, capacity_factor=0
+    (capacity = max expert load, 150-160 here: more than one 128-row tile per expert), megablocks_size
+    0 and 4: dense == megablocks bitwise, both vs the fp32-accumulating oracle at the dropless capacity."""
+    from tutel_amd import ops
+    T, M, H, E, k = 4096, 2048, 2048, 64, 2
+    dtype = torch.bfloat16
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=3)
+    layer = make_layer(M, H, E, k, 0.0, dtype, weights, gate={"fp32_gate": fp32_gate}).eval()
+    xd = x.cuda()
+    with torch.no_grad():
+        dense = layer(xd)
+        cap_dense = int(layer.protected_shape[1])
+        counts = layer.dispatch_count.cpu()
+        mega = layer(xd, megablocks_size=4)
+        cap_mega = int(layer.protected_shape[1])
+        logits = layer.gates[0](xd)
+    assert cap_dense == int(counts.max()) and cap_dense > 128
+    assert layer.megablocks_size == 4 and cap_mega == (cap_dense + 3) // 4 * 4
+    assert torch.equal(dense, mega)
+    if fp32_gate:
+        yo, lo, crit, _ = oracle.moe_forward(x, *weights, top_k=k, capacity_factor=0.0, fp32_gate=True, accum_fp32=True)
+    else:  # low-precision gate: the oracle routes on the scores the kernel derived from the library GEMM's logits
+        scores = ops.gate_topk(logits, k, apply_softmax=True, want_scores=True)[3].cpu()
+        wg, w1, b1, w2, b2 = weights
+        crit, lo = oracle.extract_critical(scores, k, 0.0)
+        yo = oracle.fast_decode(oracle.expert_ffn(oracle.fast_encode(x, crit), w1, b1, w2, b2, accum_fp32=True), crit)
+    assert crit[4] == cap_dense and torch.equal(counts, crit[5])
+    _close(dense, yo, dtype)
+
+
 @pytest.mark.parametrize("name,E_loc,k", [("train_losses_top2_e2", 2, 2), ("train_losses_top1_e4", 4, 1)])
 def test_training_replay_matches_reference_losses(oracle, name, E_loc, k):
     """fwd + bwd + SGD for a few steps (the style of the reference's golden-loss tests,
@@ -418,6 +450,23 @@ def test_graphed_forward_wrapper(oracle):
         GraphedForward(layer, xs, capacity_factor=0.0)
 
 
+def test_graph_replay_equals_eager_at_bench_config(oracle):
+    """`bench.py --graph`: the captured forward at BASELINE configs[1] (bf16 gate, as benched) returns the
+    eager forward's bits, replay after replay."""
+    from tutel_amd.impls.graph import GraphedForward
+    T, M, H, E, k = 4096, 2048, 2048, 64, 2
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=torch.bfloat16, seed=12)
+    layer = make_layer(M, H, E, k, 1.0, torch.bfloat16, weights).eval()
+    xs = x.cuda().view(16, 256, M)
+    with torch.no_grad():
+        want = layer(xs).clone()
+        want_neg = layer(-xs).clone()
+    g = GraphedForward(layer, xs)
+    for _ in range(3):
+        assert torch.equal(g(xs), want)
+        assert torch.equal(g(-xs), want_neg)
+
+
 # ---- SURVEY 8f row 3: cosine gate + SwiGLU (llama_ffn) expert ---------------------------------
 def make_ext_layer(M, H, E, P, k, cf, dtype, fp32_gate, tensors):
     from tutel import moe
@@ -494,14 +543,15 @@ def test_llama_expert_fused_glu_gemm_vs_oracle(oracle, dtype):
     _close(y2.detach(), oracle.expert_llama_ffn(x, w1, w2, w3), dtype, vs_lowprec_reference=True)
 
 
+@pytest.mark.parametrize("shape", [(1024, 512, 256, 32, 2), (4096, 2048, 2048, 64, 2)], ids=["small", "headline"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_low_precision_gate_layer_vs_oracle_on_its_own_scores(oracle, dtype):
+def test_low_precision_gate_layer_vs_oracle_on_its_own_scores(oracle, dtype, shape):
     """bf16 / fp16 gate (`fp32_gate=False`, the reference default): logits come from the library GEMM
     in the gate dtype; the oracle is given the scores the routing kernel derived from them (softmax is
     not bit-specified across exp implementations), so token -> expert assignment must agree exactly
     and the output within the dtype's bar."""
     from tutel_amd import ops
-    T, M, H, E, k = 1024, 512, 256, 32, 2
+    T, M, H, E, k = shape   # "headline" = BASELINE configs[1] exactly as bench.py runs it (fp32_gate=False)
     x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=11)
     layer = make_layer(M, H, E, k, 1.0, dtype, weights).eval()
     with torch.no_grad():
