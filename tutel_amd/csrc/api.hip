@@ -32,7 +32,7 @@ int tutel_get_option(int key) {
 
 extern "C" int tutel_amd_set_option(int key, int value) {
   TUTEL_REQUIRE(key >= 0 && key <= 1, "tutel_amd_set_option: unknown key %d", key);
-  TUTEL_REQUIRE(value >= -1 && value <= 3, "tutel_amd_set_option: value %d out of range [-1, 3]", value);
+  TUTEL_REQUIRE(value >= -1 && value <= 4, "tutel_amd_set_option: value %d out of range [-1, 4]", value);
   g_opt[key] = value;
   return 0;
 }

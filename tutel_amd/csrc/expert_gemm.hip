@@ -765,6 +765,232 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   gemm_epilogue<T, ACT, NI>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
 }
 
+// -------------------------------------------------------------------------------------------
+// 256 x 256 "ping-pong" kernel (k-major weights): the MFMA-bound regime's main kernel.
+//
+// PMC of expert_gemm_big_kernel above (profiles/r01_pmc_big_gemm.txt): MFMA busy 37 % of SIMD cycles,
+// 46 % of wave cycles parked in s_waitcnt -- every K-tile ends in a __syncthreads that drains all
+// LDS-DMA (vmcnt(0)), and both waves of a SIMD read fragments / run MFMAs at the same time.  Here:
+//   * the 8 waves form two groups (waves 0-3, 4-7: one wave of each per SIMD) that run the SAME
+//     instruction stream half a phase apart: while one group issues its 8 MFMAs of a phase (256 cycles
+//     of the SIMD's matrix pipe) the other group issues the phase's LDS-DMA, fragment reads and waits.
+//     Every s_barrier flips the roles; the matrix pipe always has exactly one wave feeding it.
+//   * a K-tile (64 deep) is 4 phases; phase q multiplies the wave's 64 token rows with its q-th 32-column
+//     strip of weights (8 x v_mfma_32x32x16).  Token fragments are read once per K-tile (phase 0) and
+//     kept in registers; each phase reads 4 weight fragments.
+//   * LDS holds two K-tiles (2 x (32 KB tokens + 32 KB weights)), recycled piecewise: the token tile
+//     is dead after phase 0, weight strip q after phase q, and each piece is re-filled for tile j+2 two
+//     phases after its last read.  DMA is never drained: every phase issues exactly 2 LDS-DMA
+//     instructions per wave and waits with a COUNTED s_waitcnt vmcnt(6) (the data a phase reads was
+//     issued >= 4 phases = 8 instructions earlier), raw s_barrier, no __syncthreads in the loop.
+// Hazards (p = phase index, one barrier interval = half a phase; group 1 runs one interval late):
+//   RAW: data read in phase p was issued in phases <= p-4; each wave's vmcnt(6) in phase p-1 retires its
+//        own pieces, and the barrier(s) between that wait and any reader's phase p order the rest.
+//   WAR: the DMA issued in phase p overwrites pieces last read in phases <= p-2; those reads were
+//        retired (lgkmcnt(0)) by both groups before the barrier that precedes phase p's issue.
+// Same k order per output element as the other kernels (rotation per 256-column tile, kk ascending):
+// results are bit-identical to theirs.
+// -------------------------------------------------------------------------------------------
+#define PP_BUF (4 * GL_STAGE)   // elements per LDS K-tile buffer: [256][64] tokens + [256][64] weights = 64 KB
+
+template <typename T, int ACT, bool W_ONCE>
+__global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t *lds = reinterpret_cast<uint16_t *>(smem);  // [2][ tokens 2*GL_STAGE | weights 2*GL_STAGE ]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;  // 64-row group, 128-column group
+
+  const int nb = gridDim.x;
+  int w;
+  {
+    const int b = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = b & 7, pos = b >> 3;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int mt = w % p.ntm;
+  const int nt = (w / p.ntm) % p.ntn;
+  const int e = w / (p.ntm * p.ntn);
+  const int m0 = mt * GB_BM, n0 = nt * 256;
+
+  int row_limit = p.R;
+  if (p.row_counts != nullptr) {
+    int c = p.row_counts[e];
+    c = (c + p.row_align - 1) / p.row_align * p.row_align;
+    row_limit = min(row_limit, c);
+  }
+  if (m0 >= row_limit) return;
+
+  const uint16_t *Ae = reinterpret_cast<const uint16_t *>(p.A) + (size_t)e * p.a_stride_e;
+  const uint16_t *We = reinterpret_cast<const uint16_t *>(p.W) + (size_t)e * p.w_stride_e;
+
+  // ---- DMA sources.  A piece = 8 LDS rows x 128 B (one wave instruction); lane -> (row lane/8, 16-byte
+  // position lane%8 holding chunk (lane%8) ^ ((row >> 1) & 7) of the row: the bank-conflict swizzle).
+  // Token tile: LDS row = tile row.  Pieces {2w, 2w+1} (first half) and {16+2w, 17+2w} (second half).
+  // Weight tile: LDS row = (strip q, column group wn, column i) -> (2q + wn)*32 + i, so that strip q of
+  // BOTH column groups is one contiguous 8 KB range; pieces {2w, 2w+1} (strips 0,1), {16+2w, 17+2w} (2,3).
+  const uint16_t *a_src[4], *w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = (i >> 1) * 16 + 2 * wid + (i & 1);
+    const int r = 8 * piece + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    {
+      const int gr = min(m0 + r, p.R - 1);
+      a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + c * 8;
+      if (p.a_rows != nullptr) {
+        const int q = p.a_rows[(size_t)e * p.R + gr];
+        a_src[i] = (q >= 0 ? reinterpret_cast<const uint16_t *>(p.A) + (size_t)(q % p.a_rows_mod) * p.lda
+                           : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;
+      }
+    }
+    {
+      const int col = ((r >> 5) & 1) * 128 + (r >> 6) * 32 + (r & 31);  // LDS row r -> column of the 256-column tile
+      const int gn = min(n0 + col, p.N - 1);
+      w_src[i] = We + (size_t)gn * p.ldw + c * 8;
+    }
+  }
+  const int piece_lo = 2 * wid * 512, piece_hi = (16 + 2 * wid) * 512;  // element offsets of the wave's pieces in a 32 KB tile
+  // W_ONCE (one M-tile per expert and the chip covered): every weight byte is fetched by exactly one block ->
+  // no-allocate loads (see expert_gemm_big_kernel); a template axis so the issue path has no branch
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, kg = lane >> 5;
+  const int sw = (l31 >> 1) & 7;
+  int frag_k[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) frag_k[kk] = (((kk * 2 + kg) ^ sw) << 3);
+  const int a_row = (wm * 64 + l31) * GL_BK;                    // + mi*32*64
+  const int w_row = 2 * GL_STAGE + (wn * 32 + l31) * GL_BK;     // + q*64*64, weights follow the token tile
+
+  const int nk = p.K / GL_BK;
+  const int rot = (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk);
+
+#define PP_KOFF(J, KO)                                     \
+  size_t KO;                                               \
+  {                                                        \
+    int kr_ = (J) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_; \
+    KO = (size_t)kr_ * GL_BK;                              \
+  }
+  // LDS-DMA issue of one half of a tile (2 instructions per wave): HALF 0 -> pieces 2w,2w+1; 1 -> 16+2w,17+2w
+#define PP_ISSUE_A(J, BUF, HALF)                                                         \
+  do {                                                                                   \
+    PP_KOFF(J, ko_);                                                                     \
+    uint16_t *d_ = lds + (BUF) * PP_BUF + ((HALF) ? piece_hi : piece_lo);                \
+    glds16(a_src[2 * (HALF)] + ko_, d_, false);                                          \
+    glds16(a_src[2 * (HALF) + 1] + ko_, d_ + 512, false);                                \
+  } while (0)
+#define PP_ISSUE_W(J, BUF, HALF)                                                         \
+  do {                                                                                   \
+    PP_KOFF(J, ko_);                                                                     \
+    uint16_t *d_ = lds + (BUF) * PP_BUF + 2 * GL_STAGE + ((HALF) ? piece_hi : piece_lo); \
+    glds16(w_src[2 * (HALF)] + ko_, d_, W_ONCE);                                         \
+    glds16(w_src[2 * (HALF) + 1] + ko_, d_ + 512, W_ONCE);                               \
+  } while (0)
+
+  u32x4 fa[4][2], fw[4];
+  // one phase: [DMA issue] [fragment reads] [counted DMA wait] barrier [8 MFMAs at raised priority] barrier
+#define PP_PHASE(Q, BUF, STEADY, ISSUE)                                                  \
+  do {                                                                                   \
+    ISSUE;                                                                               \
+    const uint16_t *cb_ = lds + (BUF) * PP_BUF;                                          \
+    if ((Q) == 0) {                                                                      \
+      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                   \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
+          fa[kk][mi] = *reinterpret_cast<const u32x4 *>(cb_ + a_row + mi * 32 * GL_BK + frag_k[kk]); \
+    }                                                                                    \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                     \
+      fw[kk] = *reinterpret_cast<const u32x4 *>(cb_ + w_row + (Q) * 64 * GL_BK + frag_k[kk]); \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                         \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+    __builtin_amdgcn_s_barrier();                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                     \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                   \
+        acc[Q][mi] = Mma<T>::run(fw[kk], fa[kk][mi], acc[Q][mi]);                        \
+    __builtin_amdgcn_s_setprio(0);                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    __builtin_amdgcn_s_barrier();                                                        \
+  } while (0)
+
+  // ---- prologue: tiles 0 (tokens + weights) and 1 (tokens) in flight; wait for tile 0 only
+  PP_ISSUE_A(0, 0, 0); PP_ISSUE_A(0, 0, 1);
+  PP_ISSUE_W(0, 0, 0); PP_ISSUE_W(0, 0, 1);
+  if (nk > 1) {
+    PP_ISSUE_A(1, 1, 0); PP_ISSUE_A(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wid >= 4) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier interval behind group 0
+
+  int j = 0;
+  // steady state: two K-tiles per iteration (static LDS buffer indices), every issue real
+  for (; j + 3 < nk; j += 2) {
+    PP_PHASE(0, 0, true, PP_ISSUE_W(j + 1, 1, 0));
+    PP_PHASE(1, 0, true, PP_ISSUE_W(j + 1, 1, 1));
+    PP_PHASE(2, 0, true, PP_ISSUE_A(j + 2, 0, 0));
+    PP_PHASE(3, 0, true, PP_ISSUE_A(j + 2, 0, 1));
+    PP_PHASE(0, 1, true, PP_ISSUE_W(j + 2, 0, 0));
+    PP_PHASE(1, 1, true, PP_ISSUE_W(j + 2, 0, 1));
+    PP_PHASE(2, 1, true, PP_ISSUE_A(j + 3, 1, 0));
+    PP_PHASE(3, 1, true, PP_ISSUE_A(j + 3, 1, 1));
+  }
+  // tail (last <= 3 tiles): issues only while tiles remain, every wait drains; one copy of the four phases with the
+  // LDS buffer chosen at run time (two static copies made hipcc hoist ~40 address registers into scratch)
+  for (; j < nk; ++j) {
+    const int cur = __builtin_amdgcn_readfirstlane(j & 1), nxt = cur ^ 1;
+    const bool more1 = j + 1 < nk, more2 = j + 2 < nk;
+    PP_PHASE(0, cur, false, if (more1) PP_ISSUE_W(j + 1, nxt, 0));
+    PP_PHASE(1, cur, false, if (more1) PP_ISSUE_W(j + 1, nxt, 1));
+    PP_PHASE(2, cur, false, if (more2) PP_ISSUE_A(j + 2, cur, 0));
+    PP_PHASE(3, cur, false, if (more2) PP_ISSUE_A(j + 2, cur, 1));
+  }
+  if (wid < 4) __builtin_amdgcn_s_barrier();  // group 0 catches up: equal barrier counts for all waves
+#undef PP_PHASE
+#undef PP_ISSUE_A
+#undef PP_ISSUE_W
+#undef PP_KOFF
+
+  GM_PRELOAD_BIAS_N(4);
+  gemm_epilogue<T, ACT, 4>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
+}
+
+template <typename T, int ACT, bool W_ONCE>
+static int launch_pp_cfg(const GemmArgs &b, hipStream_t st) {
+  const size_t lds = (size_t)2 * PP_BUF * 2;  // 128 KB
+  auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE>;
+  static bool optin = false;
+  if (!optin) {
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    optin = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(b.E_loc * b.ntm * b.ntn), dim3(GB_THREADS), lds, st, b);
+  TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
+  return 0;
+}
+
+template <typename T, int ACT>
+static int launch_pp(const GemmArgs &a, hipStream_t st) {
+  GemmArgs b = a;
+  b.ntm = (a.R + GB_BM - 1) / GB_BM;
+  b.ntn = (a.N + 255) / 256;
+  if (b.ntm == 1 && (long long)b.E_loc * b.ntn >= 256) return launch_pp_cfg<T, ACT, true>(b, st);
+  return launch_pp_cfg<T, ACT, false>(b, st);
+}
+
 template <typename T, bool KM, int ACT, int NI, int NS = 2>
 static int launch_big(const GemmArgs &a, hipStream_t st) {
   GemmArgs b = a;
@@ -859,7 +1085,8 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
     const long long t256 = mt256 * ((a.N + 255) / 256), t128 = mt256 * ((a.N + 127) / 128);
     // more than one 128-row tile per expert (R > 128) already pays: the 128-tile kernels would stream every
     // weight tile once per M-tile (dropless capacity 157 at the headline shape: fc1 214 us vs 118 at R = 128)
-    if (big == 1 || (big < 0 && a.R > GM_BM && t256 >= 192)) return launch_big<T, KM, ACT, 4>(a, st);
+    if (KM && (big == 4 || (big < 0 && a.R > GM_BM && t256 >= 192))) return launch_pp<T, ACT>(a, st);
+    if (big == 1 || big == 4 || (big < 0 && a.R > GM_BM && t256 >= 192)) return launch_big<T, KM, ACT, 4>(a, st);
     // 256 x 128: a three-slot ring (3 x 48 KB of LDS) keeps two tiles in flight: +3-4 % over two slots on the
     // stage shapes it is chosen for (tools/stage_probe.py); big = 2 forces the two-slot form for A/B runs
     if (KM && big == 2) return launch_big<T, true, ACT, 2, 2>(a, st);
