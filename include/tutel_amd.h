@@ -210,11 +210,12 @@ int tutel_amd_expert_gemm_glu(const void *A, int64_t a_stride_e, int64_t a_strid
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG
  * seed it once), 0 / 1 = force.  Every choice computes bit-identical results.
  *   TUTEL_OPT_GEMM_IMPL  128-tile kernels: 0 register-staged, 1 LDS-DMA
- *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always 256 x 256, 2 / 3 always 256 x 128 with a two- /
- *                        three-slot LDS ring (k-major weights) (automatic: > 128 rows per expert and enough
- *                        tiles to cover the chip) */
+ *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
+ *                        with a two- / three-slot LDS ring (k-major weights), 4 always the 256 x 256 ping-pong kernel
+ *                        (automatic: > 128 rows per expert and enough tiles to cover the chip) */
 #define TUTEL_OPT_GEMM_IMPL 0
 #define TUTEL_OPT_GEMM_TILE 1
+#define TUTEL_OPT_GEMM_ABL 2 /* dev only: ablation variant of the ping-pong kernel (timing experiments; results invalid) */
 int tutel_amd_set_option(int key, int value);
 
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------

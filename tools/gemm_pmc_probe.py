@@ -8,7 +8,11 @@ x = torch.randn([E, R, M], generator=g).bfloat16().cuda()
 w1 = (torch.randn([E, H, M], generator=g) / 45).bfloat16().cuda()
 w2 = (torch.randn([E, H, M], generator=g) / 45).bfloat16().cuda()
 b = torch.randn([E, H], generator=g).bfloat16().cuda()
+import os
+from tutel_amd import _lib
+if os.environ.get("GEMM_TILE"):
+    ops.set_option(_lib.OPT_GEMM_TILE, int(os.environ["GEMM_TILE"]))
 for _ in range(12):
     h = ops.expert_gemm(x, w1, b, True, act="relu")
-    y = ops.expert_gemm(h, w2, b, False)
+    y = ops.expert_gemm(x, w2, b, True)
 torch.cuda.synchronize()

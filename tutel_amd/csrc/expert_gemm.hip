@@ -91,6 +91,8 @@ struct GemmArgs {
   int E_loc, R, N, K;
   const int32_t *row_counts; int row_align;
   const int32_t *a_rows; int a_rows_mod; const void *a_zero;  // optional row gather for A (fused fast_encode)
+  int a_span_bytes;                                           // gather: bytes of the token array (a_rows_mod rows)
+  bool fits32;                                                // operands addressable with 32-bit byte offsets
   const void *mul;                                            // optional epilogue multiplier, D's layout
   int ntm, ntn;
 };
@@ -793,7 +795,15 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
 // -------------------------------------------------------------------------------------------
 #define PP_BUF (4 * GL_STAGE)   // elements per LDS K-tile buffer: [256][64] tokens + [256][64] weights = 64 KB
 
-template <typename T, int ACT, bool W_ONCE>
+// 16 bytes per lane, global -> LDS, through a buffer descriptor: address = base + voff (VGPR) + soff (SGPR)
+template <bool NT>
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint16_t *l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)l, 16, voff, soff, 0, NT ? 2 : 0);
+}
+
+// ABL: ablation bits for on-hardware timing experiments (tools/pp_probe.py abl); 0 in the product.
+//   1 no LDS-DMA in the loop   2 no fragment reads   4 no epilogue   8 no s_setprio   16 no stagger (groups in lockstep)
+template <typename T, int ACT, bool W_ONCE, int ABL = 0>
 __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t *lds = reinterpret_cast<uint16_t *>(smem);  // [2][ tokens 2*GL_STAGE | weights 2*GL_STAGE ]
@@ -829,7 +839,13 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   // Token tile: LDS row = tile row.  Pieces {2w, 2w+1} (first half) and {16+2w, 17+2w} (second half).
   // Weight tile: LDS row = (strip q, column group wn, column i) -> (2q + wn)*32 + i, so that strip q of
   // BOTH column groups is one contiguous 8 KB range; pieces {2w, 2w+1} (strips 0,1), {16+2w, 17+2w} (2,3).
-  const uint16_t *a_src[4], *w_src[4];
+  // Issued as `buffer_load_dwordx4 ... lds`: descriptor in SGPRs, a per-lane 32-bit byte offset that never
+  // changes, and the K-tile offset as the scalar offset operand -- NO vector ALU work per issue.  (With 64-bit
+  // per-lane pointers every issue needed two v_lshl_add_u64, and VALU instructions of the wave in its memory
+  // part starve behind the partner wave's MFMAs: 315 cycles per 2 issues measured with s_memtime, vs ~100
+  // with both waves in their memory part.)  Out-of-range offsets return ZEROS into LDS (probed on gfx950,
+  // tools/scratch/oob_lds.hip): that is the all-zero row of an empty bucket slot in the fused fast_encode.
+  int a_off[4], w_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int piece = (i >> 1) * 16 + 2 * wid + (i & 1);
@@ -837,19 +853,25 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     {
       const int gr = min(m0 + r, p.R - 1);
-      a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + c * 8;
+      size_t off = (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda;  // elements from Ae
       if (p.a_rows != nullptr) {
         const int q = p.a_rows[(size_t)e * p.R + gr];
-        a_src[i] = (q >= 0 ? reinterpret_cast<const uint16_t *>(p.A) + (size_t)(q % p.a_rows_mod) * p.lda
-                           : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;
+        off = q >= 0 ? (size_t)(q % p.a_rows_mod) * p.lda : (size_t)0x3ffff800u;            // elements from p.A; empty -> out of range
       }
+      a_off[i] = (int)(unsigned)(off * 2 + c * 16);
     }
     {
       const int col = ((r >> 5) & 1) * 128 + (r >> 6) * 32 + (r & 31);  // LDS row r -> column of the 256-column tile
       const int gn = min(n0 + col, p.N - 1);
-      w_src[i] = We + (size_t)gn * p.ldw + c * 8;
+      w_off[i] = (int)(unsigned)(((size_t)gn * p.ldw) * 2 + c * 16);
     }
   }
+  // descriptors: raw buffers (stride 0); the token descriptor's size is the token array when rows are gathered
+  // (so the empty-slot offset is out of range), "unbounded" otherwise
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(p.a_rows != nullptr ? reinterpret_cast<const uint16_t *>(p.A) : Ae), 0,
+      p.a_rows != nullptr ? p.a_span_bytes : -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(We), 0, -1, 0x00020000);
   const int piece_lo = 2 * wid * 512, piece_hi = (16 + 2 * wid) * 512;  // element offsets of the wave's pieces in a 32 KB tile
   // W_ONCE (one M-tile per expert and the chip covered): every weight byte is fetched by exactly one block ->
   // no-allocate loads (see expert_gemm_big_kernel); a template axis so the issue path has no branch
@@ -871,36 +893,56 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   const int w_row = 2 * GL_STAGE + (wn * 32 + l31) * GL_BK;     // + q*64*64, weights follow the token tile
 
   const int nk = p.K / GL_BK;
-  const int rot = (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk);
+  const int rot = (ABL & 32) ? 0 : (ABL & 64) ? (int)(((long long)(3 * e) * nk / 8) % nk) : (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk);
 
 #define PP_KOFF(J, KO)                                     \
-  size_t KO;                                               \
+  int KO;                                                  \
   {                                                        \
     int kr_ = (J) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_; \
-    KO = (size_t)kr_ * GL_BK;                              \
+    KO = kr_ * (GL_BK * 2); /* bytes */                    \
   }
   // LDS-DMA issue of one half of a tile (2 instructions per wave): HALF 0 -> pieces 2w,2w+1; 1 -> 16+2w,17+2w
 #define PP_ISSUE_A(J, BUF, HALF)                                                         \
   do {                                                                                   \
     PP_KOFF(J, ko_);                                                                     \
     uint16_t *d_ = lds + (BUF) * PP_BUF + ((HALF) ? piece_hi : piece_lo);                \
-    glds16(a_src[2 * (HALF)] + ko_, d_, false);                                          \
-    glds16(a_src[2 * (HALF) + 1] + ko_, d_ + 512, false);                                \
+    bdma16<false>(rs_a, a_off[2 * (HALF)], ko_, d_);                                     \
+    bdma16<false>(rs_a, a_off[2 * (HALF) + 1], ko_, d_ + 512);                           \
   } while (0)
 #define PP_ISSUE_W(J, BUF, HALF)                                                         \
   do {                                                                                   \
     PP_KOFF(J, ko_);                                                                     \
     uint16_t *d_ = lds + (BUF) * PP_BUF + 2 * GL_STAGE + ((HALF) ? piece_hi : piece_lo); \
-    glds16(w_src[2 * (HALF)] + ko_, d_, W_ONCE);                                         \
-    glds16(w_src[2 * (HALF) + 1] + ko_, d_ + 512, W_ONCE);                               \
+    bdma16<W_ONCE>(rs_w, w_off[2 * (HALF)], ko_, d_);                                    \
+    bdma16<W_ONCE>(rs_w, w_off[2 * (HALF) + 1], ko_, d_ + 512);                          \
   } while (0)
 
+#define PP_NOW(T)                                                                         \
+  unsigned long long T = 0;                                                              \
+  if (ABL & 128) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T)::"memory")
+  unsigned seg[5] = {0, 0, 0, 0, 0};
+  PP_NOW(tstart);
   u32x4 fa[4][2], fw[4];
+  if (ABL & 2) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      fw[kk] = u32x4{0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+      fa[kk][0] = fw[kk]; fa[kk][1] = fw[kk];
+    }
+  }
   // one phase: [DMA issue] [fragment reads] [counted DMA wait] barrier [8 MFMAs at raised priority] barrier
 #define PP_PHASE(Q, BUF, STEADY, ISSUE)                                                  \
   do {                                                                                   \
-    ISSUE;                                                                               \
+    PP_NOW(t0_);                                                                         \
+    if (!(ABL & 1)) { ISSUE; }                                                           \
+    PP_NOW(t1_);                                                                         \
     const uint16_t *cb_ = lds + (BUF) * PP_BUF;                                          \
+    if (ABL & 2) {                                                                       \
+      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                 \
+        asm volatile("" : "+v"(fw[kk]));                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) asm volatile("" : "+v"(fa[kk][mi])); \
+      }                                                                                  \
+    } else {                                                                             \
     if ((Q) == 0) {                                                                      \
       _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                   \
         _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
@@ -908,19 +950,28 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     }                                                                                    \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                     \
       fw[kk] = *reinterpret_cast<const u32x4 *>(cb_ + w_row + (Q) * 64 * GL_BK + frag_k[kk]); \
+    }                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                   \
-    if (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                         \
+    if ((STEADY) && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
     __builtin_amdgcn_s_barrier();                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+    PP_NOW(t2_);                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                   \
-    __builtin_amdgcn_s_setprio(1);                                                       \
+    if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);                                       \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                     \
       _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                   \
         acc[Q][mi] = Mma<T>::run(fw[kk], fa[kk][mi], acc[Q][mi]);                        \
-    __builtin_amdgcn_s_setprio(0);                                                       \
+    if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);                                       \
     __builtin_amdgcn_sched_barrier(0);                                                   \
+    PP_NOW(t3_);                                                                         \
     __builtin_amdgcn_s_barrier();                                                        \
+    PP_NOW(t4_);                                                                         \
+    if (ABL & 128) {                                                                     \
+      seg[0] += (unsigned)(t1_ - t0_); seg[1] += (unsigned)(t2_ - t1_);                  \
+      seg[2] += (unsigned)(t3_ - t2_); seg[3] += (unsigned)(t4_ - t3_);                  \
+      if ((Q) == 0) seg[4] += (unsigned)(t2_ - t1_);                                     \
+    }                                                                                    \
   } while (0)
 
   // ---- prologue: tiles 0 (tokens + weights) and 1 (tokens) in flight; wait for tile 0 only
@@ -933,7 +984,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  if (wid >= 4) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier interval behind group 0
+  if (wid >= 4 && !(ABL & 16)) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier interval behind group 0
 
   int j = 0;
   // steady state: two K-tiles per iteration (static LDS buffer indices), every issue real
@@ -957,20 +1008,49 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     PP_PHASE(2, cur, false, if (more2) PP_ISSUE_A(j + 2, cur, 0));
     PP_PHASE(3, cur, false, if (more2) PP_ISSUE_A(j + 2, cur, 1));
   }
-  if (wid < 4) __builtin_amdgcn_s_barrier();  // group 0 catches up: equal barrier counts for all waves
+  if (wid < 4 && !(ABL & 16)) __builtin_amdgcn_s_barrier();  // group 0 catches up: equal barrier counts for all waves
 #undef PP_PHASE
 #undef PP_ISSUE_A
 #undef PP_ISSUE_W
 #undef PP_KOFF
 
+  if (ABL & 128) {  // timing instrumentation: per-wave segment sums (cycles) -> debug buffer passed in p.mul
+    PP_NOW(tend);
+    if (lane == 0 && p.mul != nullptr && (blockIdx.x == 0 || blockIdx.x == 100)) {
+      unsigned *dbg = reinterpret_cast<unsigned *>(const_cast<void *>(p.mul)) + ((blockIdx.x ? 8 : 0) + wid) * 8;
+      for (int i = 0; i < 5; ++i) dbg[i] = seg[i];
+      dbg[5] = (unsigned)(tend - tstart);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[i][jj][r];
+    if (sum == 12345.678f) reinterpret_cast<uint16_t *>(p.D)[tid] = 1;
+    return;
+  }
+#undef PP_NOW
+  if (ABL & 4) {  // keep the accumulators alive, store one element per lane
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[i][jj][r];
+    if (sum == 12345.678f) reinterpret_cast<uint16_t *>(p.D)[tid] = 1;
+    return;
+  }
   GM_PRELOAD_BIAS_N(4);
   gemm_epilogue<T, ACT, 4>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
 }
 
-template <typename T, int ACT, bool W_ONCE>
+template <typename T, int ACT, bool W_ONCE, int ABL = 0>
 static int launch_pp_cfg(const GemmArgs &b, hipStream_t st) {
   const size_t lds = (size_t)2 * PP_BUF * 2;  // 128 KB
-  auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE>;
+  auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, ABL>;
   static bool optin = false;
   if (!optin) {
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -987,6 +1067,23 @@ static int launch_pp(const GemmArgs &a, hipStream_t st) {
   GemmArgs b = a;
   b.ntm = (a.R + GB_BM - 1) / GB_BM;
   b.ntn = (a.N + 255) / 256;
+  if (ACT == TUTEL_ACT_RELU && sizeof(T) == 2) {  // ablation variants (dev only): bf16/fp16 + relu
+    switch (tutel_get_option(TUTEL_OPT_GEMM_ABL)) {
+      case 1: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 1>(b, st);
+      case 2: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 2>(b, st);
+      case 3: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 3>(b, st);
+      case 4: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 4>(b, st);
+      case 7: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 7>(b, st);
+      case 8: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 8>(b, st);
+      case 16: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 16>(b, st);
+      case 32: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 32>(b, st);
+      case 64: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 64>(b, st);
+      case 36: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 36>(b, st);
+      case 128: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 128>(b, st);
+      case 144: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 144>(b, st);
+      default: break;
+    }
+  }
   if (b.ntm == 1 && (long long)b.E_loc * b.ntn >= 256) return launch_pp_cfg<T, ACT, true>(b, st);
   return launch_pp_cfg<T, ACT, false>(b, st);
 }
@@ -1085,7 +1182,7 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
     const long long t256 = mt256 * ((a.N + 255) / 256), t128 = mt256 * ((a.N + 127) / 128);
     // more than one 128-row tile per expert (R > 128) already pays: the 128-tile kernels would stream every
     // weight tile once per M-tile (dropless capacity 157 at the headline shape: fc1 214 us vs 118 at R = 128)
-    if (KM && (big == 4 || (big < 0 && a.R > GM_BM && t256 >= 192))) return launch_pp<T, ACT>(a, st);
+    if (KM && a.fits32 && (big == 4 || (big < 0 && a.R > GM_BM && t256 >= 192))) return launch_pp<T, ACT>(a, st);
     if (big == 1 || big == 4 || (big < 0 && a.R > GM_BM && t256 >= 192)) return launch_big<T, KM, ACT, 4>(a, st);
     // 256 x 128: a three-slot ring (3 x 48 KB of LDS) keeps two tiles in flight: +3-4 % over two slots on the
     // stage shapes it is chosen for (tools/stage_probe.py); big = 2 forces the two-slot form for A/B runs
@@ -1139,6 +1236,17 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   a.E_loc = E_loc; a.R = R; a.N = N; a.K = K;
   a.row_counts = row_counts; a.row_align = row_align < 1 ? 1 : row_align;
   a.a_rows = a_rows; a.a_rows_mod = a_rows_mod; a.a_zero = a_zero;
+  a.a_span_bytes = 0;
+  bool fits32 = true;  // the ping-pong kernel addresses rows with 32-bit byte offsets from the operand bases
+  if (a_rows != nullptr) {
+    const long long span = (long long)a_rows_mod * lda * 2;
+    fits32 = span < 0x7ffff000LL;
+    a.a_span_bytes = (int)span;
+  } else {
+    fits32 = ((long long)((R - 1) / a_rows_per_w) * a_stride_w + (long long)a_rows_per_w * lda + K) * 2 < 0xffffff00LL;
+  }
+  fits32 = fits32 && ((long long)N * ldw + K) * 2 < 0xffffff00LL;
+  a.fits32 = fits32;
   a.mul = mul;
   TUTEL_REQUIRE(((uintptr_t)mul % 8) == 0, "tutel_amd_expert_gemm_glu: gating operand must be 8-byte aligned");
   TUTEL_REQUIRE(a_rows == nullptr || (a_rows_mod >= 1 && a_zero != nullptr && ((uintptr_t)a_zero % 16) == 0),
