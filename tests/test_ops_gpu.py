@@ -22,12 +22,13 @@ def _ops():
     return ops
 
 
-@pytest.fixture(params=["auto", "tile256x256", "tile256x128", "tile256x128ring3"])
+@pytest.fixture(params=["auto", "tile256x256", "tile256x128", "tile256x128ring3", "pingpong256x256"])
 def big_tile(request):
     """auto: the library picks the tile (the small test shapes land on the 128-tile kernels);
-    tile256x256 / tile256x128: force the 256-row kernels wherever they apply (N >= 128; 256x128: k-major)."""
+    tile256x256 / tile256x128 / pingpong256x256: force the 256-row kernels wherever they apply (N >= 128; 256x128 and the
+    ping-pong kernel: k-major weights, else the plain 256 x 256 kernel)."""
     from tutel_amd import ops, _lib
-    ops.set_option(_lib.OPT_GEMM_TILE, {"auto": -1, "tile256x256": 1, "tile256x128": 2, "tile256x128ring3": 3}[request.param])
+    ops.set_option(_lib.OPT_GEMM_TILE, {"auto": -1, "tile256x256": 1, "tile256x128": 2, "tile256x128ring3": 3, "pingpong256x256": 4}[request.param])
     yield request.param
     ops.set_option(_lib.OPT_GEMM_TILE, -1)
 
@@ -384,24 +385,28 @@ def test_decode_expert_sliced_layout(oracle, W, E_loc, s):
 
 @pytest.mark.parametrize("kmajor", [True, False])
 def test_expert_gemm_kernels_are_bit_identical(kmajor):
-    """128-tile register-staged, 128-tile LDS-DMA, 256 x 256- and 256 x 128-tile kernels walk k in the same order for
-    every output element: same bits whatever the row count / option selects."""
+    """128-tile register-staged, 128-tile LDS-DMA, 256 x 256 (plain and ping-pong) and 256 x 128-tile kernels walk k in the
+    same order for every output element: same bits whatever the row count / option selects.  (The K-tile rotation is a
+    function of the problem -- on for R <= 128 rows per expert, off above -- never of the kernel; both regimes here.)"""
     from tutel_amd import ops, _lib
     g = torch.Generator().manual_seed(17)
-    E, R, N, K = 3, 300, 640, 1024
-    a = torch.randn([E, R, K], generator=g).bfloat16().cuda()
-    w = ((torch.rand([E, N, K] if kmajor else [E, K, N], generator=g) * 2 - 1) / 32).bfloat16().cuda()
-    b = torch.randn([E, N], generator=g).bfloat16().cuda()
-    outs = []
-    try:
-        for impl, tile in ((0, 0), (1, 0), (-1, 1), (-1, 2), (-1, 3)):
-            ops.set_option(_lib.OPT_GEMM_IMPL, impl)
-            ops.set_option(_lib.OPT_GEMM_TILE, tile)
-            outs.append(ops.expert_gemm(a, w, b, kmajor, act="gelu"))
-    finally:
-        ops.set_option(_lib.OPT_GEMM_IMPL, -1)
-        ops.set_option(_lib.OPT_GEMM_TILE, -1)
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    for E, R, N, K in ((3, 300, 640, 1024), (5, 128, 640, 1024), (2, 1000, 1024, 2048)):
+        a = torch.randn([E, R, K], generator=g).bfloat16().cuda()
+        w = ((torch.rand([E, N, K] if kmajor else [E, K, N], generator=g) * 2 - 1) / 32).bfloat16().cuda()
+        b = torch.randn([E, N], generator=g).bfloat16().cuda()
+        outs = []
+        try:
+            for impl, tile in ((0, 0), (1, 0), (-1, 1), (-1, 2), (-1, 3), (-1, 4)):
+                ops.set_option(_lib.OPT_GEMM_IMPL, impl)
+                ops.set_option(_lib.OPT_GEMM_TILE, tile)
+                outs.append(ops.expert_gemm(a, w, b, kmajor, act="gelu"))
+        finally:
+            ops.set_option(_lib.OPT_GEMM_IMPL, -1)
+            ops.set_option(_lib.OPT_GEMM_TILE, -1)
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (E, R, N, K)
+        ref = torch.nn.functional.gelu(torch.matmul(a.float(), w.float().transpose(1, 2) if kmajor else w.float()) + b.float().unsqueeze(1))
+        err = (outs[0].float() - ref).abs()
+        assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), float(err.max())
 
 
 def test_routing_randomized_shapes_vs_oracle(oracle):

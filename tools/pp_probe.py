@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tutel_amd import ops, _lib  # noqa: E402
 
-VARIANTS = (("256x256", 1), ("pingpong", 4))
+VARIANTS = (("256x256", 1), ("pingpong", 4), ("256x128", 3), ("128", 0))
 
 
 def ablation():
@@ -21,7 +21,7 @@ def ablation():
         ops.set_option(_lib.OPT_GEMM_TILE, 4)
         res = {}
         names = {0: "full", 1: "no DMA", 2: "no frag reads", 3: "no DMA, no reads", 4: "no epilogue", 7: "MFMA + barriers only",
-                 8: "no setprio", 16: "no stagger", 32: "no K rotation", 64: "K rotation per expert only", 36: "no rotation, no epilogue"}
+                 8: "no setprio", 16: "no stagger", 256: "direct-store epilogue"}
         for rep in range(3):
             for abl, name in names.items():
                 ops.set_option(_lib.OPT_GEMM_ABL, abl)

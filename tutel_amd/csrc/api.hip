@@ -32,7 +32,7 @@ int tutel_get_option(int key) {
 
 extern "C" int tutel_amd_set_option(int key, int value) {
   TUTEL_REQUIRE(key >= 0 && key <= 2, "tutel_amd_set_option: unknown key %d", key);
-  TUTEL_REQUIRE(value >= -1 && value <= (key == 2 ? 255 : 4), "tutel_amd_set_option: value %d out of range", value);
+  TUTEL_REQUIRE(value >= -1 && value <= (key == 2 ? 511 : 4), "tutel_amd_set_option: value %d out of range", value);
   g_opt[key] = value;
   return 0;
 }

@@ -93,6 +93,7 @@ struct GemmArgs {
   const int32_t *a_rows; int a_rows_mod; const void *a_zero;  // optional row gather for A (fused fast_encode)
   int a_span_bytes;                                           // gather: bytes of the token array (a_rows_mod rows)
   bool fits32;                                                // operands addressable with 32-bit byte offsets
+  bool rot_on;                                                // K-tile rotation (see launch_gemm)
   const void *mul;                                            // optional epilogue multiplier, D's layout
   int ntm, ntn;
 };
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
   // K-tile rotation per PAIR of N-tiles: the 256-column kernel below shares one token tile between the
   // pair and therefore one k order; using the same order here makes every kernel produce bit-identical
   // sums for a given output element, whatever tile size the row count selects
-  const int rot = ROT ? (int)(((long long)((nt >> 1) + 3 * e) * nk / ((p.ntn + 1) >> 1)) % nk) : 0;
+  const int rot = (ROT && p.rot_on) ? (int)(((long long)((nt >> 1) + 3 * e) * nk / ((p.ntn + 1) >> 1)) % nk) : 0;
 
   // Prefetch registers: straight-line unrolled code over fixed-size arrays (no lambdas, no
   // conditionals around the loads -- hipcc otherwise demotes them to scratch / waits vmcnt(0)).
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
   // K-tile rotation per PAIR of N-tiles: the 256-column kernel below shares one token tile between the
   // pair and therefore one k order; using the same order here makes every kernel produce bit-identical
   // sums for a given output element, whatever tile size the row count selects
-  const int rot = ROT ? (int)(((long long)((nt >> 1) + 3 * e) * nk / ((p.ntn + 1) >> 1)) % nk) : 0;
+  const int rot = (ROT && p.rot_on) ? (int)(((long long)((nt >> 1) + 3 * e) * nk / ((p.ntn + 1) >> 1)) % nk) : 0;
 
 #define GL_ISSUE(KT, BUF)                                                              \
   do {                                                                                 \
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   const int nk = p.K / GL_BK;
   // the same k order as the 128-tile kernels (rotation per PAIR of 128-column tiles)
   const int npair = NI == 4 ? p.ntn : (p.ntn + 1) >> 1, pair = NI == 4 ? nt : nt >> 1;
-  const int rot = (int)(((long long)(pair + 3 * e) * nk / npair) % nk);
+  const int rot = p.rot_on ? (int)(((long long)(pair + 3 * e) * nk / npair) % nk) : 0;
 
 #define GB_ISSUE(KT, BUF)                                                              \
   do {                                                                                 \
@@ -765,6 +766,91 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
 
   GM_PRELOAD_BIAS_N(NI);
   gemm_epilogue<T, ACT, NI>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
+}
+
+// ---- epilogue through LDS for the 8-wave 256 x 256 kernels: the MFMA layout gives a lane 4 consecutive
+// features of ONE row per register group, i.e. 8-byte stores 32 rows apart (32 store instructions per wave,
+// every 64-byte sector assembled from 4 instructions).  With one block per CU and all blocks finishing
+// together that store tail is fully exposed: 13-14 us of 68 at 8 x 1024 x 2048 x 2048 (ablation, tools/pp_probe.py).
+// Here each wave rounds its 64 x 128 sub-tile into a private LDS region (row pitch 272 B: the 8-byte writes of
+// 16 lanes spread over 8 bank pairs, the 16-byte reads of a row are contiguous) and writes it out as whole
+// 256-byte row segments, 16 bytes per lane, 4 rows per instruction: 16 store instructions per wave.
+// Values are computed exactly as in gemm_epilogue (fp32 bias add, activation, optional gating product, one
+// rounding) -- only the path to memory differs.
+#define EP_PITCH 272
+template <typename T, int ACT>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&acc)[4][2], uint2 (&bias_r)[4][4],
+                                                  unsigned char *stage, int e, int m0, int n0, int wm, int wn,
+                                                  int lane, int row_limit) {
+  const int l31 = lane & 31, kg = lane >> 5;
+  uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;
+  const uint16_t *Me = p.mul ? reinterpret_cast<const uint16_t *>(p.mul) + (size_t)e * p.d_stride_e : nullptr;
+  const bool has_bias = p.bias != nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wm * 64 + mi * 32 + l31;
+    size_t roff = 0;
+    if (Me) {
+      const int mc = min(m, p.R - 1);
+      roff = (size_t)(mc / p.d_rpw) * p.d_stride_w + (size_t)(mc % p.d_rpw) * p.ldd;
+    }
+    unsigned char *srow = stage + (mi * 32 + l31) * EP_PITCH + kg * 8;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][rg * 4 + r];
+        if (has_bias) {
+          const uint2 bb = bias_r[ni][rg];
+          uint16_t b4[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            T tb;
+            __builtin_memcpy(&tb, &b4[r], 2);
+            v[r] += Elem<T>::to_f32(tb);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = activate<ACT>(v[r]);
+        if (Me) {
+          const int n = min(n0 + wn * 128 + ni * 32 + rg * 8 + kg * 4, p.N - 4);
+          const uint2 mm = *reinterpret_cast<const uint2 *>(Me + roff + n);
+          uint16_t m4[4] = {(uint16_t)(mm.x & 0xffff), (uint16_t)(mm.x >> 16), (uint16_t)(mm.y & 0xffff), (uint16_t)(mm.y >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            T tm;
+            __builtin_memcpy(&tm, &m4[r], 2);
+            v[r] *= Elem<T>::to_f32(tm);
+          }
+        }
+        uint16_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T tv = Elem<T>::from_f32(v[r]);
+          __builtin_memcpy(&o[r], &tv, 2);
+        }
+        uint2 ov;
+        ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        *reinterpret_cast<uint2 *>(srow + (ni * 32 + rg * 8) * 2) = ov;
+      }
+    }
+  }
+  // the region is private to the wave and LDS operations of one wave complete in order: no barrier
+  const int c16 = lane & 15, r4 = lane >> 4;
+  const int n = n0 + wn * 128 + c16 * 8;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + r4;
+    const int m = m0 + wm * 64 + row;
+    const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + row * EP_PITCH + c16 * 16);
+    if (m < row_limit && n < p.N) {
+      const size_t roff = (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
+      *reinterpret_cast<u32x4 *>(De + roff + n) = val;
+    }
+  }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -893,7 +979,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   const int w_row = 2 * GL_STAGE + (wn * 32 + l31) * GL_BK;     // + q*64*64, weights follow the token tile
 
   const int nk = p.K / GL_BK;
-  const int rot = (ABL & 32) ? 0 : (ABL & 64) ? (int)(((long long)(3 * e) * nk / 8) % nk) : (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk);
+  const int rot = p.rot_on ? (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk) : 0;
 
 #define PP_KOFF(J, KO)                                     \
   int KO;                                                  \
@@ -1044,12 +1130,18 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     return;
   }
   GM_PRELOAD_BIAS_N(4);
-  gemm_epilogue<T, ACT, 4>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
+  if ((ABL & 256) || (p.ldd & 7) || (p.d_stride_e & 7) || (p.d_stride_w & 7) || (reinterpret_cast<uintptr_t>(p.D) & 15)) {
+    gemm_epilogue<T, ACT, 4>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);  // rows not 16-byte aligned
+    return;
+  }
+  // after the final barrier no wave reads the K-tile buffers any more and every DMA has landed: LDS is free
+  gemm_epilogue_lds<T, ACT>(p, acc, bias_r, smem + wid * (64 * EP_PITCH), e, m0, n0, wm, wn, lane, row_limit);
 }
 
 template <typename T, int ACT, bool W_ONCE, int ABL = 0>
 static int launch_pp_cfg(const GemmArgs &b, hipStream_t st) {
-  const size_t lds = (size_t)2 * PP_BUF * 2;  // 128 KB
+  const size_t lds = (size_t)8 * 64 * EP_PITCH;  // 136 KB: the epilogue staging (8 waves x 64 rows x 272 B) > the two K-tile buffers (128 KB)
+  static_assert((size_t)8 * 64 * EP_PITCH >= (size_t)2 * PP_BUF * 2, "LDS request must cover the K-tile buffers");
   auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, ABL>;
   static bool optin = false;
   if (!optin) {
@@ -1076,11 +1168,9 @@ static int launch_pp(const GemmArgs &a, hipStream_t st) {
       case 7: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 7>(b, st);
       case 8: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 8>(b, st);
       case 16: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 16>(b, st);
-      case 32: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 32>(b, st);
-      case 64: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 64>(b, st);
-      case 36: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 36>(b, st);
       case 128: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 128>(b, st);
       case 144: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 144>(b, st);
+      case 256: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 256>(b, st);
       default: break;
     }
   }
@@ -1247,6 +1337,15 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   }
   fits32 = fits32 && ((long long)N * ldw + K) * 2 < 0xffffff00LL;
   a.fits32 = fits32;
+  // K-tile rotation (each block starts its K loop at a different tile) is a property of the PROBLEM, not of the kernel
+  // that runs it, so every kernel produces the same bits for a given problem:
+  //   R < 256 rows per expert (weight streaming from HBM dominates, 4 KB-strided rows): ON -- without the stagger all
+  //     resident blocks sit at the same k offset and hot-spot HBM channels (fc1 158 -> 143 us at the headline shape in
+  //     round 1; dropless 64 x 160 rows: 134 us on, 153 off);
+  //   R >= 256 (full 256-row tiles, operands re-read through L2): OFF -- blocks that share a token tile then walk it
+  //     together and the later ones hit in L2 (ping-pong kernel 65.7 -> 62.6 us at 8 x 1024 x 2048 x 2048, 242 -> 224 at
+  //     4096^2, 85 -> 79 at 32 x 256 rows).
+  a.rot_on = R < GB_BM;
   a.mul = mul;
   TUTEL_REQUIRE(((uintptr_t)mul % 8) == 0, "tutel_amd_expert_gemm_glu: gating operand must be 8-byte aligned");
   TUTEL_REQUIRE(a_rows == nullptr || (a_rows_mod >= 1 && a_zero != nullptr && ((uintptr_t)a_zero % 16) == 0),
