@@ -889,7 +889,7 @@ __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rs, int voff, int 
 
 // ABL: ablation bits for on-hardware timing experiments (tools/pp_probe.py abl); 0 in the product.
 //   1 no LDS-DMA in the loop   2 no fragment reads   4 no epilogue   8 no s_setprio   16 no stagger (groups in lockstep)
-template <typename T, int ACT, bool W_ONCE, int ABL = 0>
+template <typename T, int ACT, bool W_ONCE, int ABL = 0, bool RAGGED = false>
 __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t *lds = reinterpret_cast<uint16_t *>(smem);  // [2][ tokens 2*GL_STAGE | weights 2*GL_STAGE ]
@@ -944,6 +944,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
         const int q = p.a_rows[(size_t)e * p.R + gr];
         off = q >= 0 ? (size_t)(q % p.a_rows_mod) * p.lda : (size_t)0x3ffff800u;            // elements from p.A; empty -> out of range
       }
+      if (m0 + r >= row_limit) off = (size_t)0x3ffff800u;  // rows past the expert's row count: zeros, no memory traffic
       a_off[i] = (int)(unsigned)(off * 2 + c * 16);
     }
     {
@@ -952,11 +953,11 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
       w_off[i] = (int)(unsigned)(((size_t)gn * p.ldw) * 2 + c * 16);
     }
   }
-  // descriptors: raw buffers (stride 0); the token descriptor's size is the token array when rows are gathered
-  // (so the empty-slot offset is out of range), "unbounded" otherwise
+  // descriptors: raw buffers (stride 0); the token descriptor's size is the span of the rows it addresses (the token
+  // array when rows are gathered, else this expert's rows), so that the marker offset above is out of range
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t *>(p.a_rows != nullptr ? reinterpret_cast<const uint16_t *>(p.A) : Ae), 0,
-      p.a_rows != nullptr ? p.a_span_bytes : -1, 0x00020000);
+      p.a_span_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(We), 0, -1, 0x00020000);
   const int piece_lo = 2 * wid * 512, piece_hi = (16 + 2 * wid) * 512;  // element offsets of the wave's pieces in a 32 KB tile
   // W_ONCE (one M-tile per expert and the chip covered): every weight byte is fetched by exactly one block ->
@@ -975,6 +976,11 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   int frag_k[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) frag_k[kk] = (((kk * 2 + kg) ^ sw) << 3);
+  // RAGGED (dropless capacity 157 on a 256-row tile, megablocks row counts): the MFMAs of a 32-row group entirely
+  // past the expert's row count are skipped (wave-uniform branch; its rows arrive as zeros, its accumulators are never
+  // stored).  A separate instantiation: the branches cost the full-tile kernel registers and schedule.
+  const bool mi_on[2] = {__builtin_amdgcn_readfirstlane(m0 + wm * 64) < row_limit,
+                         __builtin_amdgcn_readfirstlane(m0 + wm * 64 + 32) < row_limit};
   const int a_row = (wm * 64 + l31) * GL_BK;                    // + mi*32*64
   const int w_row = 2 * GL_STAGE + (wn * 32 + l31) * GL_BK;     // + q*64*64, weights follow the token tile
 
@@ -1017,7 +1023,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     }
   }
   // one phase: [DMA issue] [fragment reads] [counted DMA wait] barrier [8 MFMAs at raised priority] barrier
-#define PP_PHASE(Q, BUF, STEADY, ISSUE)                                                  \
+#define PP_PHASE(MODE, Q, BUF, STEADY, ISSUE)                                                  \
   do {                                                                                   \
     PP_NOW(t0_);                                                                         \
     if (!(ABL & 1)) { ISSUE; }                                                           \
@@ -1045,9 +1051,14 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     PP_NOW(t2_);                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                   \
     if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);                                       \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                     \
-      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                   \
-        acc[Q][mi] = Mma<T>::run(fw[kk], fa[kk][mi], acc[Q][mi]);                        \
+    if ((MODE) == 2) {                                                                   \
+      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                   \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
+          acc[Q][mi] = Mma<T>::run(fw[kk], fa[kk][mi], acc[Q][mi]);                      \
+    } else if ((MODE) == 1) {                                                            \
+      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                   \
+        acc[Q][0] = Mma<T>::run(fw[kk], fa[kk][0], acc[Q][0]);                           \
+    }                                                                                    \
     if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);                                       \
     __builtin_amdgcn_sched_barrier(0);                                                   \
     PP_NOW(t3_);                                                                         \
@@ -1072,28 +1083,38 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   __builtin_amdgcn_s_barrier();
   if (wid >= 4 && !(ABL & 16)) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier interval behind group 0
 
-  int j = 0;
-  // steady state: two K-tiles per iteration (static LDS buffer indices), every issue real
-  for (; j + 3 < nk; j += 2) {
-    PP_PHASE(0, 0, true, PP_ISSUE_W(j + 1, 1, 0));
-    PP_PHASE(1, 0, true, PP_ISSUE_W(j + 1, 1, 1));
-    PP_PHASE(2, 0, true, PP_ISSUE_A(j + 2, 0, 0));
-    PP_PHASE(3, 0, true, PP_ISSUE_A(j + 2, 0, 1));
-    PP_PHASE(0, 1, true, PP_ISSUE_W(j + 2, 0, 0));
-    PP_PHASE(1, 1, true, PP_ISSUE_W(j + 2, 0, 1));
-    PP_PHASE(2, 1, true, PP_ISSUE_A(j + 3, 1, 0));
-    PP_PHASE(3, 1, true, PP_ISSUE_A(j + 3, 1, 1));
-  }
-  // tail (last <= 3 tiles): issues only while tiles remain, every wait drains; one copy of the four phases with the
-  // LDS buffer chosen at run time (two static copies made hipcc hoist ~40 address registers into scratch)
-  for (; j < nk; ++j) {
-    const int cur = __builtin_amdgcn_readfirstlane(j & 1), nxt = cur ^ 1;
-    const bool more1 = j + 1 < nk, more2 = j + 2 < nk;
-    PP_PHASE(0, cur, false, if (more1) PP_ISSUE_W(j + 1, nxt, 0));
-    PP_PHASE(1, cur, false, if (more1) PP_ISSUE_W(j + 1, nxt, 1));
-    PP_PHASE(2, cur, false, if (more2) PP_ISSUE_A(j + 2, cur, 0));
-    PP_PHASE(3, cur, false, if (more2) PP_ISSUE_A(j + 2, cur, 1));
-  }
+  // the K loop, as a macro over MODE = number of live 32-row groups of this wave (2: both, 1: the first, 0: none)
+#define PP_MAINLOOP(MODE)                                                                \
+  do {                                                                                   \
+    int j = 0;                                                                           \
+    /* steady state: two K-tiles per iteration (static LDS buffer indices), every issue real */ \
+    for (; j + 3 < nk; j += 2) {                                                         \
+      PP_PHASE(MODE, 0, 0, true, PP_ISSUE_W(j + 1, 1, 0));                               \
+      PP_PHASE(MODE, 1, 0, true, PP_ISSUE_W(j + 1, 1, 1));                               \
+      PP_PHASE(MODE, 2, 0, true, PP_ISSUE_A(j + 2, 0, 0));                               \
+      PP_PHASE(MODE, 3, 0, true, PP_ISSUE_A(j + 2, 0, 1));                               \
+      PP_PHASE(MODE, 0, 1, true, PP_ISSUE_W(j + 2, 0, 0));                               \
+      PP_PHASE(MODE, 1, 1, true, PP_ISSUE_W(j + 2, 0, 1));                               \
+      PP_PHASE(MODE, 2, 1, true, PP_ISSUE_A(j + 3, 1, 0));                               \
+      PP_PHASE(MODE, 3, 1, true, PP_ISSUE_A(j + 3, 1, 1));                               \
+    }                                                                                    \
+    /* tail (last <= 3 tiles): issues only while tiles remain, every wait drains; one copy of the four phases with */ \
+    /* the LDS buffer chosen at run time (two static copies made hipcc hoist ~40 address registers into scratch)   */ \
+    for (; j < nk; ++j) {                                                                \
+      const int cur = __builtin_amdgcn_readfirstlane(j & 1), nxt = cur ^ 1;              \
+      const bool more1 = j + 1 < nk, more2 = j + 2 < nk;                                 \
+      PP_PHASE(MODE, 0, cur, false, if (more1) PP_ISSUE_W(j + 1, nxt, 0));               \
+      PP_PHASE(MODE, 1, cur, false, if (more1) PP_ISSUE_W(j + 1, nxt, 1));               \
+      PP_PHASE(MODE, 2, cur, false, if (more2) PP_ISSUE_A(j + 2, cur, 0));               \
+      PP_PHASE(MODE, 3, cur, false, if (more2) PP_ISSUE_A(j + 2, cur, 1));               \
+    }                                                                                    \
+  } while (0)
+  // RAGGED: one branch per wave OUTSIDE the loop picks the loop version (every version runs the same DMA issues,
+  // waits and barriers; only the MFMA blocks differ), so the loop bodies stay branch-free
+  if (!RAGGED || mi_on[1]) PP_MAINLOOP(2);
+  else if (mi_on[0]) PP_MAINLOOP(1);
+  else PP_MAINLOOP(0);
+#undef PP_MAINLOOP
   if (wid < 4 && !(ABL & 16)) __builtin_amdgcn_s_barrier();  // group 0 catches up: equal barrier counts for all waves
 #undef PP_PHASE
 #undef PP_ISSUE_A
@@ -1138,11 +1159,11 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   gemm_epilogue_lds<T, ACT>(p, acc, bias_r, smem + wid * (64 * EP_PITCH), e, m0, n0, wm, wn, lane, row_limit);
 }
 
-template <typename T, int ACT, bool W_ONCE, int ABL = 0>
+template <typename T, int ACT, bool W_ONCE, int ABL = 0, bool RAGGED = false>
 static int launch_pp_cfg(const GemmArgs &b, hipStream_t st) {
   const size_t lds = (size_t)8 * 64 * EP_PITCH;  // 136 KB: the epilogue staging (8 waves x 64 rows x 272 B) > the two K-tile buffers (128 KB)
   static_assert((size_t)8 * 64 * EP_PITCH >= (size_t)2 * PP_BUF * 2, "LDS request must cover the K-tile buffers");
-  auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, ABL>;
+  auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, ABL, RAGGED>;
   static bool optin = false;
   if (!optin) {
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1174,8 +1195,12 @@ static int launch_pp(const GemmArgs &a, hipStream_t st) {
       default: break;
     }
   }
-  if (b.ntm == 1 && (long long)b.E_loc * b.ntn >= 256) return launch_pp_cfg<T, ACT, true>(b, st);
-  return launch_pp_cfg<T, ACT, false>(b, st);
+  // a last M-tile with >= 32 padding rows, or per-expert row counts: the variant that skips padded 32-row groups
+  const int tail_rows = b.R % GB_BM;
+  const bool ragged = b.row_counts != nullptr || (tail_rows != 0 && tail_rows <= GB_BM - 32);
+  if (b.ntm == 1 && (long long)b.E_loc * b.ntn >= 256)
+    return ragged ? launch_pp_cfg<T, ACT, true, 0, true>(b, st) : launch_pp_cfg<T, ACT, true>(b, st);
+  return ragged ? launch_pp_cfg<T, ACT, false, 0, true>(b, st) : launch_pp_cfg<T, ACT, false>(b, st);
 }
 
 template <typename T, bool KM, int ACT, int NI, int NS = 2>
@@ -1328,12 +1353,11 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   a.a_rows = a_rows; a.a_rows_mod = a_rows_mod; a.a_zero = a_zero;
   a.a_span_bytes = 0;
   bool fits32 = true;  // the ping-pong kernel addresses rows with 32-bit byte offsets from the operand bases
-  if (a_rows != nullptr) {
-    const long long span = (long long)a_rows_mod * lda * 2;
+  {
+    const long long span = a_rows != nullptr ? (long long)a_rows_mod * lda * 2
+                                             : ((long long)((R - 1) / a_rows_per_w) * a_stride_w + (long long)a_rows_per_w * lda) * 2;
     fits32 = span < 0x7ffff000LL;
     a.a_span_bytes = (int)span;
-  } else {
-    fits32 = ((long long)((R - 1) / a_rows_per_w) * a_stride_w + (long long)a_rows_per_w * lda + K) * 2 < 0xffffff00LL;
   }
   fits32 = fits32 && ((long long)N * ldw + K) * 2 < 0xffffff00LL;
   a.fits32 = fits32;
