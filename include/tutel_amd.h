@@ -206,6 +206,87 @@ int tutel_amd_expert_gemm_glu(const void *A, int64_t a_stride_e, int64_t a_strid
                               int act, const int32_t *row_counts, int row_align,
                               tutel_stream_t stream);
 
+/* ---- expert-parallel pipeline ----------------------------------------
+ * Replaces the reference's native all-to-all layer: the private NCCL communicator
+ * (get_nccl_unique_id / init_nccl, custom_kernel.cpp:341-365), its stream + event table (:327-338,
+ * :433-461) and the asynchronous all-to-all scatter / gather the overlap path is built from
+ * (:520-654; driven from tutel/impls/overlap.py:8-67 one chunk at a time), plus the two
+ * permute+contiguous copies around the experts (communicate.py:606-622), which disappear here.
+ *
+ * A communicator owns an RCCL comm (resolved with dlopen from the RCCL already in the process), one
+ * side stream and a table of events.  Bootstrap like the reference: one rank calls
+ * tutel_amd_ep_unique_id, the host code broadcasts the bytes (torch.distributed), every rank calls
+ * tutel_amd_ep_comm_create with its device current.  One process per GPU. */
+typedef struct tutel_amd_ep_comm tutel_amd_ep_comm_t;
+#define TUTEL_AMD_EP_ID_BYTES 128
+
+int tutel_amd_ep_load_rccl(const char *path_hint /* may be NULL */);
+int tutel_amd_ep_unique_id(void *out, size_t bytes /* >= TUTEL_AMD_EP_ID_BYTES */);
+int tutel_amd_ep_comm_create(const void *id, size_t bytes, int world, int rank, tutel_amd_ep_comm_t **out);
+int tutel_amd_ep_comm_destroy(tutel_amd_ep_comm_t *comm);
+int tutel_amd_ep_comm_info(const tutel_amd_ep_comm_t *comm, int *world, int *rank);
+
+/* all_to_all_single with equal splits (simple_all_to_all, communicate.py:181-192): block r of `send`
+ * (bytes_per_peer bytes) goes to rank r and lands as block <my rank> of its `recv`; enqueued on `stream`. */
+int tutel_amd_ep_all_to_all(tutel_amd_ep_comm_t *comm, const void *send, void *recv, size_t bytes_per_peer,
+                            tutel_stream_t stream);
+
+/* Stage layouts of the pipeline (identical to tutel_amd/impls/overlap.py::OverlapPlan; a CPU test pins it):
+ *   sliced  (allow_sliced && E_loc % degree == 0): stages = groups of E_loc/degree local experts, buckets
+ *           laid out [degree, W, s, C]; every expert's weights are streamed once per forward;
+ *   chunked (otherwise; the reference's scheme, overlap.py:21-24): stages = capacity chunks of C/degree rows,
+ *           buckets laid out [degree, E, c].
+ * Stage i's message is [W, rows] bucket rows (dim 0 = peer); the GEMMs address the received rows as
+ * experts_per_stage experts x gemm_rows source-rank-major rows: (stride_e, stride_w, rows_per_w, ld) =
+ * (chunk*ld, rows*ld, chunk, ld). */
+typedef struct {
+  int sliced;            /* 1 expert-sliced, 0 capacity-chunked */
+  int experts_per_stage; /* s */
+  int chunk;             /* c: capacity rows per expert and stage */
+  int rows;              /* s*c: bucket rows per (stage, rank) block */
+  int gemm_rows;         /* W*c: GEMM rows per expert and stage */
+} tutel_amd_ep_plan_t;
+int tutel_amd_ep_plan(int num_experts, int world, int capacity, int degree, int allow_sliced, tutel_amd_ep_plan_t *out);
+
+/* One call = fast_encode -> all-to-all -> expert FFN -> all-to-all -> fast_decode for one batch of tokens
+ * whose routing is known (tutel_amd_gate_topk + tutel_amd_compute_location): what MOELayer.forward does
+ * between extract_critical and the final reshape (moe_layer.py:327-361), with a2a_ffn_overlap_degree stages
+ * pipelined over the caller's stream (RCCL all-to-alls, encode, decode) and the communicator's side stream (the
+ * stage GEMMs); capturable in a HIP graph with the caller's stream as origin.  Returns after enqueueing;
+ * when it returns, the caller's stream is ordered after every operation of the call (buffers may be reused or
+ * freed in stream order).  comm == NULL: world must be 1, the exchange is a copy; with fuse_encode and
+ * is_postscore the first GEMM then gathers its rows from the tokens and enc / recv / back are not touched. */
+typedef struct {
+  /* sizes */
+  int T, M, H, M_out;            /* tokens of this rank, model dim, hidden size per expert, output dim */
+  int num_experts, world, k;     /* GLOBAL experts (E_loc = num_experts / world local ones), ranks, top-k */
+  int capacity;                  /* C, already aligned to the degree (moe_layer.py:298-301) */
+  int degree;                    /* a2a_ffn_overlap_degree, 1..32 */
+  int allow_sliced;              /* see tutel_amd_ep_plan */
+  int dtype, gate_dtype, act;    /* TUTEL_BF16 | TUTEL_F16; dtype of `gates`; TUTEL_ACT_* fused into fc1 */
+  int is_postscore;              /* gates applied in decode (1) or encode (0), fast_dispatch.py:125,131 */
+  int w2_kmajor;                 /* w2 is [E_loc, M_out, H] (1) or the checkpoint layout [E_loc, H, M_out] (0) */
+  int fuse_encode;               /* single rank: gather fc1's rows from the tokens (needs zero_row) */
+  /* routing of this batch (device) */
+  const void *x;                 /* [T, M] */
+  const int32_t *slot_map;       /* [num_experts * C] (tutel_amd_compute_location) */
+  const int32_t *idx, *loc;      /* [k, T] */
+  const void *gates;             /* [k, T] gate_dtype */
+  /* local experts (device): batched_fc1_w [E_loc,H,M], bias [E_loc,H]; batched_fc2_w, bias [E_loc,M_out] (NULL = none) */
+  const void *w1, *b1, *w2, *b2;
+  /* workspace (device, dtype): enc / recv [num_experts*C, M]; hid [E_loc*world*C, H]; send / back [num_experts*C, M_out] */
+  void *enc, *recv, *hid, *send, *back;
+  const void *zero_row;          /* >= M zero elements (fuse_encode only) */
+  void *y;                       /* out: [T, M_out] */
+} tutel_amd_ep_args_t;
+int tutel_amd_ep_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_ep_args_t *args, tutel_stream_t stream);
+
+/* stage markers: roctx ranges (rocprofv3 --marker-trace); the pipeline above emits tutel_amd.fast_encode /
+ * all_to_all / expert_fc1 / expert_fc2 / fast_decode itself.  No-ops when libroctx64 is not in the process
+ * (set TUTEL_AMD_ROCTX=1 to load it).  The reference's only tracing is system.record_time (system.py:73-79). */
+int tutel_amd_range_push(const char *name);
+int tutel_amd_range_pop(void);
+
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG
  * seed it once), 0 / 1 = force.  Every choice computes bit-identical results.

@@ -453,3 +453,24 @@ def test_variable_size_collectives_world2_gloo():
     from tutel import net
     outs, sizes = net.batch_all_to_all_v([torch.arange(4)], [4])   # single process: identity
     assert torch.equal(outs[0], torch.arange(4)) and sizes.tolist() == [4]
+
+
+@pytest.mark.parametrize("W,E_loc,Cap,degree", [(1, 8, 128, 1), (2, 4, 8, 2), (4, 2, 6, 2), (8, 8, 128, 2), (8, 8, 128, 1), (2, 3, 8, 2),
+                                                (4, 1, 8, 4), (2, 6, 12, 4), (8, 16, 128, 4), (8, 16, 136, 8)])
+def test_native_plan_equals_python_plan(W, E_loc, Cap, degree):
+    """tutel_amd_ep_plan (the layouts tutel_amd_ep_forward hands to the encode / GEMM / decode kernels) ==
+    impls/overlap.py::OverlapPlan, which the W = 2 / 4 / 8 ranks-sharing-one-GPU runs verified against the oracle.
+    Pure arithmetic inside the library: runs without a GPU."""
+    from tutel_amd.impls import ep_native
+    from tutel_amd.impls.overlap import OverlapPlan
+    E = W * E_loc
+    for allow in (True, False):
+        if not allow and Cap % degree:
+            continue
+        py = OverlapPlan(E, W, Cap, degree, allow_sliced=allow)
+        c = ep_native.plan(E, W, Cap, degree, allow)
+        assert bool(c["sliced"]) == py.sliced and c["experts_per_stage"] == py.s and c["chunk"] == py.c
+        assert c["rows"] == py.rows and c["gemm_rows"] == py.R
+        assert py.row_layout(64) == (c["chunk"] * 64, c["rows"] * 64, c["chunk"], 64)
+        want = dict(num_experts=E, expert_slice=py.s, ep_world=W) if py.sliced else dict(num_experts=E, chunk_rows=py.c)
+        assert py.decode_kwargs == want

@@ -284,6 +284,84 @@ def test_overlapped_path_equals_plain_path(oracle, monkeypatch, degree, E, post)
     assert layer.protected_shape[1] % degree == 0
 
 
+def test_native_pipeline_equals_python_orchestration(oracle, monkeypatch):
+    """tutel_amd_ep_forward (one native call for encode .. decode) returns the bits of the Python-orchestrated
+    paths it replaces: single rank (fused-encode route), with pre-score gates (encode route), fp16."""
+    from tutel_amd.impls import ep_native
+    calls = []
+    real = ep_native.forward
+    monkeypatch.setattr(ep_native, "forward", lambda *a, **kw: calls.append(1) or real(*a, **kw))
+    for dtype, post, (T, M, H, E, k) in ((torch.bfloat16, True, (4096, 2048, 2048, 64, 2)), (torch.bfloat16, False, (1024, 256, 512, 8, 2)),
+                                         (torch.float16, True, (1000, 320, 256, 5, 3))):
+        x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=21)
+        layer = make_layer(M, H, E, k, 1.0, dtype, weights, is_postscore=post).eval()
+        xd = x.cuda()
+        with torch.no_grad():
+            monkeypatch.setattr(ep_native, "ENABLED", False)
+            want = layer(xd).clone()
+            monkeypatch.setattr(ep_native, "ENABLED", True)
+            del calls[:]
+            for _ in range(3):   # cached workspace: repeated calls must stay correct
+                got = layer(xd)
+                assert torch.equal(got, want)
+            assert len(calls) == 3, "the native pipeline must be the path taken"
+            assert layer.protected_shape == torch.Size([E, layer.protected_shape[1], M])
+
+
+def test_native_pipeline_through_rccl_single_rank():
+    """The staged native pipeline -- the library's own RCCL communicator (ncclCommInitRank from a broadcast id),
+    its communication stream and event table, ncclAllToAll per stage -- forced onto one rank: degree 2 and 4
+    (expert-sliced) and degree 3 (capacity-chunked, 8 % 3 != 0) return the bits of degree 1 and of the
+    Python-orchestrated path."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import torch.distributed as dist
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from tutel import moe
+from tutel_amd.impls import ep_native
+torch.manual_seed(0)
+torch.set_default_dtype(torch.bfloat16)
+layer = moe.moe_layer(gate_type={"type": "top", "k": 2, "fp32_gate": True},
+                      experts={"type": "ffn", "num_experts_per_device": 8, "hidden_size_per_expert": 512,
+                               "activation_fn": lambda t: torch.nn.functional.relu(t)}, model_dim=256).cuda().eval()
+torch.set_default_dtype(torch.float32)
+x = torch.randn(1536, 256).bfloat16().cuda()      # capacity 2*ceil(1536/8) = 384: divisible by 2, 3, 4
+with torch.no_grad():
+    ep_native.ENABLED = False
+    python_path = layer(x, a2a_ffn_overlap_degree=1).clone()
+    ep_native.ENABLED = True
+    plain = layer(x, a2a_ffn_overlap_degree=1).clone()
+    assert torch.equal(plain, python_path)
+    # degree 3 does not divide the 8 local experts: capacity chunks of 128 rows per launch instead of 384 -- another
+    # K-tile order inside the GEMM (rotation is on below 256 rows per expert), so its reference is the SAME chunking
+    # driven from Python (impls/overlap.py), bit for bit, and the plain result within one bf16 ulp of the output scale
+    from tutel_amd.impls import moe_layer as ml, overlap as ov
+    ep_native.ENABLED = False
+    ml._FORCE_OVERLAP = ov._FORCE_RCCL = True
+    chunked = layer(x, a2a_ffn_overlap_degree=3).clone()
+    ml._FORCE_OVERLAP = ov._FORCE_RCCL = False
+    ep_native.ENABLED = True
+    assert float((chunked.float() - plain.float()).abs().max()) <= 2 ** -7 * float(plain.float().abs().max())
+    ep_native._FORCE_COMM = True
+    for degree in (1, 2, 4, 3, 2):
+        for _ in range(3):
+            over = layer(x, a2a_ffn_overlap_degree=degree)
+            torch.cuda.synchronize()
+            assert torch.equal(chunked if degree == 3 else plain, over), degree
+    assert ep_native._comms and all(ep_native._comms.values()), "the native communicator must have been created"
+ep_native.destroy_all()
+dist.destroy_process_group()
+print("NATIVE_RCCL_OK")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert "NATIVE_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_overlapped_path_through_rccl_single_rank():
     """Same, with the exchange issued as a real RCCL all_to_all_single in a 1-rank process group
     (fresh process: the group must not leak into other tests)."""

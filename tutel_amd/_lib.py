@@ -41,6 +41,35 @@ SIGNATURES = {
     "tutel_amd_probe_tr16": (_i, [_vp, _vp]),
 }
 
+
+
+class EpPlan(ctypes.Structure):
+    """tutel_amd_ep_plan_t"""
+    _fields_ = [(n, _i) for n in ("sliced", "experts_per_stage", "chunk", "rows", "gemm_rows")]
+
+
+class EpArgs(ctypes.Structure):
+    """tutel_amd_ep_args_t (include/tutel_amd.h): field order and types must match the header"""
+    _fields_ = ([(n, _i) for n in ("T", "M", "H", "M_out", "num_experts", "world", "k", "capacity", "degree", "allow_sliced",
+                                   "dtype", "gate_dtype", "act", "is_postscore", "w2_kmajor", "fuse_encode")] +
+                [(n, _vp) for n in ("x", "slot_map", "idx", "loc", "gates", "w1", "b1", "w2", "b2",
+                                    "enc", "recv", "hid", "send", "back", "zero_row", "y")])
+
+
+SIGNATURES.update({
+    "tutel_amd_ep_load_rccl": (_i, [ctypes.c_char_p]),
+    "tutel_amd_ep_unique_id": (_i, [_vp, _sz]),
+    "tutel_amd_ep_comm_create": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(_vp)]),
+    "tutel_amd_ep_comm_destroy": (_i, [_vp]),
+    "tutel_amd_ep_comm_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "tutel_amd_ep_all_to_all": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "tutel_amd_ep_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(EpPlan)]),
+    "tutel_amd_ep_forward": (_i, [_vp, ctypes.POINTER(EpArgs), _vp]),
+    "tutel_amd_range_push": (_i, [ctypes.c_char_p]),
+    "tutel_amd_range_pop": (_i, []),
+})
+EP_ID_BYTES = 128
+
 _lib = None
 
 

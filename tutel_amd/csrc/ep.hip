@@ -1,0 +1,331 @@
+// ep.hip -- the expert-parallel pipeline of the MoE forward behind ONE native call.
+//
+//   fast_encode -> all-to-all -> expert FFN (2 grouped GEMMs) -> all-to-all -> fast_decode
+//
+// The reference drives its overlapped exchange from C++ on a PRIVATE NCCL communicator with an event
+// table and a pooled communication stream (tutel/custom/custom_kernel.cpp:341-365 unique id + init,
+// :433-461 streams / events, :520-654 async scatter / gather, one Python call per chunk).  Round 1 of
+// this repo drove the same pipeline from Python through torch.distributed: ~20 enqueues per forward
+// and 0.32-0.46 ms of host time against 0.2 ms of GPU work per rank.  Here:
+//   * an RCCL communicator of our own (ncclCommInitRank from an id the host code broadcasts), resolved
+//     with dlopen from the RCCL already in the process (torch ships one): no link-time dependency;
+//   * one call enqueues the whole pipeline on two HIP streams -- ncclAllToAll on the caller's stream, the
+//     GEMMs of the overlapped stages on a side stream owned by the communicator -- with events from a
+//     table created once; the call returns after enqueueing (no Python in between) and the whole call can
+//     be captured in a HIP graph (the caller's stream is the capture origin, where RCCL can be captured);
+//   * the stage layouts are those of tutel_amd/impls/overlap.py::OverlapPlan (expert-sliced when
+//     a2a_ffn_overlap_degree divides the local expert count, capacity-chunked otherwise); the GEMMs
+//     address the raw exchange buffers, so there are no permute copies (communicate.py:606-622) and no
+//     torch.cat; tutel_amd_ep_plan() exposes the arithmetic so a CPU test pins it to the Python plan;
+//   * degree 1 is the same plan with one stage, issued on the caller's stream alone;
+//   * world size 1 without a communicator: the exchange is the identity (stage buffers alias), and
+//     with is_postscore the first GEMM gathers its rows from the tokens (fused fast_encode).
+// Every step is one of the C-ABI entry points of this library; this file adds orchestration only.
+#include <dlfcn.h>
+#include <stdlib.h>
+
+#include <rccl/rccl.h>
+
+#include "common.h"
+
+// ---- RCCL, resolved at run time -------------------------------------------------------------
+struct RcclApi {
+  void *handle;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*AllToAll)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+  const char *(*GetErrorString)(ncclResult_t);
+};
+static RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+extern "C" int tutel_amd_ep_load_rccl(const char *path) {
+  if (g_rccl.handle != nullptr) return 0;
+  void *h = nullptr;
+  // the copy already mapped into the process first (same HIP runtime as the caller's tensors), then the hint, then the loader path
+  const char *sonames[] = {"librccl.so.1", "librccl.so"};
+  for (const char *n : sonames)
+    if (h == nullptr) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+  if (h == nullptr && path != nullptr && path[0] != 0) h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  for (const char *n : sonames)
+    if (h == nullptr) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  TUTEL_REQUIRE(h != nullptr, "tutel_amd_ep_load_rccl: cannot load librccl (%s)", dlerror());
+  RcclApi a;
+  a.handle = h;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.AllToAll = (decltype(a.AllToAll))dlsym(h, "ncclAllToAll");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  TUTEL_REQUIRE(a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllToAll && a.GetErrorString,
+                "tutel_amd_ep_load_rccl: librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllToAll");
+  g_rccl = a;
+  return 0;
+}
+
+#define RCCL_CHECK(call, what)                                                          \
+  do {                                                                                  \
+    ncclResult_t r_ = (call);                                                           \
+    if (r_ != ncclSuccess) {                                                            \
+      tutel_set_error("%s: RCCL error %d (%s)", what, (int)r_, g_rccl.GetErrorString(r_)); \
+      return (int)r_ ? (int)r_ : -1;                                                    \
+    }                                                                                   \
+  } while (0)
+#define HIP_CHECK(call, what)                                                           \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      tutel_set_error("%s: %s", what, hipGetErrorString(e_));                           \
+      return (int)e_;                                                                   \
+    }                                                                                   \
+  } while (0)
+
+// ---- stage markers (rocprofv3 --marker-trace shows them; no-ops when libroctx64 is not in the process) ----
+static int (*g_roctx_push)(const char *) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static void roctx_init() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_NOLOAD);
+  if (h == nullptr) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_NOLOAD);
+  if (h == nullptr && getenv("TUTEL_AMD_ROCTX") != nullptr) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+  if (h == nullptr) return;
+  g_roctx_push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+  g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+  if (g_roctx_push == nullptr || g_roctx_pop == nullptr) g_roctx_push = nullptr;
+}
+struct Range {
+  explicit Range(const char *name) {
+    roctx_init();
+    if (g_roctx_push) g_roctx_push(name);
+  }
+  ~Range() {
+    if (g_roctx_push) g_roctx_pop();
+  }
+};
+extern "C" int tutel_amd_range_push(const char *name) {
+  roctx_init();
+  return g_roctx_push ? g_roctx_push(name) : 0;
+}
+extern "C" int tutel_amd_range_pop(void) { return g_roctx_push ? g_roctx_pop() : 0; }
+
+// ---- communicator: RCCL comm + the communication stream + the event table -------------------------------
+#define EP_MAX_SPLIT 32  // AllToAllStatus.max_num_split of the reference (custom_kernel.cpp:328)
+struct tutel_amd_ep_comm {
+  ncclComm_t comm;
+  int world, rank, device;
+  hipStream_t side_stream;  // the GEMMs of the overlapped pipeline (the collectives run on the caller's stream)
+  hipEvent_t recv_ev[EP_MAX_SPLIT], done_ev[EP_MAX_SPLIT];
+};
+
+extern "C" int tutel_amd_ep_unique_id(void *out, size_t bytes) {
+  TUTEL_REQUIRE(out != nullptr && bytes >= sizeof(ncclUniqueId), "tutel_amd_ep_unique_id: need a %zu-byte buffer", sizeof(ncclUniqueId));
+  if (tutel_amd_ep_load_rccl(nullptr) != 0) return -1;
+  ncclUniqueId id;
+  RCCL_CHECK(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+  memcpy(out, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int tutel_amd_ep_comm_create(const void *id, size_t bytes, int world, int rank, tutel_amd_ep_comm_t **out) {
+  TUTEL_REQUIRE(out != nullptr && world >= 1 && rank >= 0 && rank < world, "tutel_amd_ep_comm_create: bad world / rank %d / %d", world, rank);
+  TUTEL_REQUIRE(id != nullptr && bytes >= sizeof(ncclUniqueId), "tutel_amd_ep_comm_create: need the %zu-byte id of tutel_amd_ep_unique_id", sizeof(ncclUniqueId));
+  if (tutel_amd_ep_load_rccl(nullptr) != 0) return -1;
+  tutel_amd_ep_comm *c = (tutel_amd_ep_comm *)calloc(1, sizeof(tutel_amd_ep_comm));
+  TUTEL_REQUIRE(c != nullptr, "tutel_amd_ep_comm_create: out of memory");
+  c->world = world;
+  c->rank = rank;
+  HIP_CHECK(hipGetDevice(&c->device), "hipGetDevice");
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  RCCL_CHECK(g_rccl.CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
+  HIP_CHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), "hipStreamCreate");
+  for (int i = 0; i < EP_MAX_SPLIT; ++i) {
+    HIP_CHECK(hipEventCreateWithFlags(&c->recv_ev[i], hipEventDisableTiming), "hipEventCreate");
+    HIP_CHECK(hipEventCreateWithFlags(&c->done_ev[i], hipEventDisableTiming), "hipEventCreate");
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int tutel_amd_ep_comm_destroy(tutel_amd_ep_comm_t *c) {
+  if (c == nullptr) return 0;
+  (void)hipStreamSynchronize(c->side_stream);
+  if (c->comm != nullptr && g_rccl.CommDestroy != nullptr) (void)g_rccl.CommDestroy(c->comm);
+  (void)hipStreamDestroy(c->side_stream);
+  for (int i = 0; i < EP_MAX_SPLIT; ++i) {
+    (void)hipEventDestroy(c->recv_ev[i]);
+    (void)hipEventDestroy(c->done_ev[i]);
+  }
+  free(c);
+  return 0;
+}
+
+extern "C" int tutel_amd_ep_comm_info(const tutel_amd_ep_comm_t *c, int *world, int *rank) {
+  TUTEL_REQUIRE(c != nullptr, "tutel_amd_ep_comm_info: null communicator");
+  if (world) *world = c->world;
+  if (rank) *rank = c->rank;
+  return 0;
+}
+
+// equal-split all-to-all of `bytes_per_peer` bytes per rank pair on `stream` (all_to_all_single semantics,
+// communicate.py:181-192): block r of `send` goes to rank r and lands as block (my rank) of its `recv`
+static int exchange(tutel_amd_ep_comm *c, const void *send, void *recv, size_t bytes_per_peer, int world, hipStream_t st) {
+  if (bytes_per_peer == 0) return 0;
+  if (c == nullptr) {  // single rank without a communicator: the exchange is a copy
+    HIP_CHECK(hipMemcpyAsync(recv, send, bytes_per_peer * (size_t)world, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+    return 0;
+  }
+  if ((bytes_per_peer & 1) == 0)
+    RCCL_CHECK(g_rccl.AllToAll(send, recv, bytes_per_peer / 2, ncclFloat16, c->comm, st), "ncclAllToAll");
+  else
+    RCCL_CHECK(g_rccl.AllToAll(send, recv, bytes_per_peer, ncclInt8, c->comm, st), "ncclAllToAll");
+  return 0;
+}
+
+extern "C" int tutel_amd_ep_all_to_all(tutel_amd_ep_comm_t *c, const void *send, void *recv, size_t bytes_per_peer,
+                                       tutel_stream_t stream) {
+  TUTEL_REQUIRE(c != nullptr && send != nullptr && recv != nullptr && send != recv, "tutel_amd_ep_all_to_all: need a communicator and two distinct buffers");
+  return exchange(c, send, recv, bytes_per_peer, c->world, (hipStream_t)stream);
+}
+
+// ---- stage layouts (== tutel_amd/impls/overlap.py::OverlapPlan) ------------------------------------------------
+extern "C" int tutel_amd_ep_plan(int E, int W, int capacity, int degree, int allow_sliced, tutel_amd_ep_plan_t *out) {
+  TUTEL_REQUIRE(out != nullptr && E >= 1 && W >= 1 && E % W == 0 && degree >= 1 && degree <= EP_MAX_SPLIT && capacity >= 0,
+                "tutel_amd_ep_plan: bad sizes E=%d W=%d C=%d degree=%d", E, W, capacity, degree);
+  const int E_loc = E / W;
+  out->sliced = (allow_sliced && E_loc >= degree && E_loc % degree == 0) ? 1 : 0;
+  if (out->sliced) {
+    out->experts_per_stage = E_loc / degree;
+    out->chunk = capacity;
+  } else {
+    TUTEL_REQUIRE(capacity % degree == 0, "tutel_amd_ep_plan: capacity %d is not a multiple of a2a_ffn_overlap_degree %d", capacity, degree);
+    out->experts_per_stage = E_loc;
+    out->chunk = capacity / degree;
+  }
+  out->rows = out->experts_per_stage * out->chunk;  // bucket rows per (stage, rank) block
+  out->gemm_rows = W * out->chunk;                  // GEMM rows per expert and stage
+  return 0;
+}
+
+// ---- the pipeline ---------------------------------------------------------------------------------------------
+extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_args_t *a, tutel_stream_t stream) {
+  TUTEL_REQUIRE(a != nullptr, "tutel_amd_ep_forward: null arguments");
+  const int W = a->world, E = a->num_experts, C = a->capacity, T = a->T, M = a->M, H = a->H, Mo = a->M_out, k = a->k;
+  TUTEL_REQUIRE(W >= 1 && E >= 1 && E % W == 0 && T >= 0 && M >= 1 && H >= 1 && Mo >= 1 && k >= 1 && C >= 0,
+                "tutel_amd_ep_forward: bad sizes");
+  TUTEL_REQUIRE(c == nullptr ? W == 1 : c->world == W, "tutel_amd_ep_forward: communicator world size does not match (%d)", W);
+  TUTEL_REQUIRE(a->dtype == TUTEL_BF16 || a->dtype == TUTEL_F16, "tutel_amd_ep_forward: bf16 / fp16 experts only (got dtype %d)", a->dtype);
+  TUTEL_REQUIRE(a->x && a->slot_map && a->idx && a->loc && a->w1 && a->w2 && a->y, "tutel_amd_ep_forward: null pointer");
+  if (T == 0) return 0;
+  const int E_loc = E / W, es = 2;
+  hipStream_t cur = (hipStream_t)stream;
+  const void *enc_gates = a->is_postscore ? nullptr : a->gates;  // fast_dispatch.py:125,131: gates on one side only
+  const void *dec_gates = a->is_postscore ? a->gates : nullptr;
+  TUTEL_REQUIRE(a->gates != nullptr, "tutel_amd_ep_forward: null gates");
+
+  if (C == 0) {  // nothing is dispatched: every token's output is the zero vector
+    HIP_CHECK(hipMemsetAsync(a->y, 0, (size_t)T * Mo * es, cur), "hipMemsetAsync");
+    return 0;
+  }
+
+  // single rank, no communicator, pure-copy encode: fc1 gathers its rows from the tokens (no bucket array at all)
+  if (c == nullptr && a->degree <= 1 && a->is_postscore && a->fuse_encode) {
+    TUTEL_REQUIRE(a->hid && a->send && a->zero_row, "tutel_amd_ep_forward: null workspace");
+    int rc;
+    {
+      Range r("tutel_amd.expert_fc1");
+      rc = tutel_amd_expert_gemm_gather(a->x, M, a->slot_map, T, a->zero_row, a->w1, 1, (int64_t)H * M, M, a->b1, H, a->hid,
+                                        (int64_t)C * H, H, E_loc, C, H, M, a->dtype, a->act, nullptr, 1, cur);
+      if (rc) return rc;
+    }
+    {
+      Range r("tutel_amd.expert_fc2");
+      rc = tutel_amd_expert_gemm(a->hid, (int64_t)C * H, 0, C, H, a->w2, a->w2_kmajor, (int64_t)H * Mo, a->w2_kmajor ? H : Mo, a->b2,
+                                 Mo, a->send, (int64_t)C * Mo, 0, C, Mo, E_loc, C, Mo, H, a->dtype, TUTEL_ACT_NONE, nullptr, 1, cur);
+      if (rc) return rc;
+    }
+    Range r("tutel_amd.fast_decode");
+    return tutel_amd_fast_decode(a->send, a->dtype, a->idx, a->loc, dec_gates, a->gate_dtype, T, Mo, k, C, E, 0, 0, 1, a->y, cur);
+  }
+
+  TUTEL_REQUIRE(a->enc && a->recv && a->hid && a->send && a->back, "tutel_amd_ep_forward: null workspace");
+  const int degree = a->degree < 1 ? 1 : a->degree;
+  tutel_amd_ep_plan_t pl;
+  if (tutel_amd_ep_plan(E, W, C, degree, a->allow_sliced, &pl) != 0) return -1;
+  const int s = pl.experts_per_stage, cc = pl.chunk, rows = pl.rows, R = pl.gemm_rows;
+  const int chunk_rows = pl.sliced ? 0 : cc, expert_slice = pl.sliced ? s : 0;
+  int rc;
+
+  {
+    Range r("tutel_amd.fast_encode");
+    rc = tutel_amd_fast_encode(a->x, a->dtype, a->slot_map, enc_gates, a->gate_dtype, T, M, E * C, C, E, chunk_rows, expert_slice, W, a->enc, cur);
+    if (rc) return rc;
+  }
+  const size_t msg_in = (size_t)W * rows * M * es, msg_out = (size_t)W * rows * Mo * es;  // bytes per stage
+  const size_t hid_stage = (size_t)s * R * H * es;
+  auto stage_gemms = [&](int i, hipStream_t st) -> int {
+    // GEMM rows addressed in the raw exchange buffer: expert el of the stage, source rank w, row l -> ((w*s + el)*cc + l)
+    const char *recv_i = (const char *)a->recv + (size_t)i * msg_in;
+    char *send_i = (char *)a->send + (size_t)i * msg_out;
+    char *hid_i = (char *)a->hid + (size_t)i * hid_stage;
+    const int e0 = pl.sliced ? i * s : 0;  // first local expert of the stage
+    const char *w1 = (const char *)a->w1 + (size_t)e0 * H * M * es, *w2 = (const char *)a->w2 + (size_t)e0 * H * Mo * es;
+    const char *b1 = a->b1 ? (const char *)a->b1 + (size_t)e0 * H * es : nullptr, *b2 = a->b2 ? (const char *)a->b2 + (size_t)e0 * Mo * es : nullptr;
+    int r1;
+    {
+      Range r("tutel_amd.expert_fc1");
+      r1 = tutel_amd_expert_gemm(recv_i, (int64_t)cc * M, (int64_t)rows * M, cc, M, w1, 1, (int64_t)H * M, M, b1, H, hid_i,
+                                 (int64_t)R * H, 0, R, H, s, R, H, M, a->dtype, a->act, nullptr, 1, st);
+      if (r1) return r1;
+    }
+    Range r("tutel_amd.expert_fc2");
+    return tutel_amd_expert_gemm(hid_i, (int64_t)R * H, 0, R, H, w2, a->w2_kmajor, (int64_t)H * Mo, a->w2_kmajor ? H : Mo, b2, Mo, send_i,
+                                 (int64_t)cc * Mo, (int64_t)rows * Mo, cc, Mo, s, R, Mo, H, a->dtype, TUTEL_ACT_NONE, nullptr, 1, st);
+  };
+
+  if (degree == 1 || c == nullptr) {
+    // one stream: exchange, GEMMs, exchange per stage, in order (degree 1; or a single rank whose exchange is a copy)
+    for (int i = 0; i < degree; ++i) {
+      {
+        Range r("tutel_amd.all_to_all");
+        rc = exchange(c, (const char *)a->enc + (size_t)i * msg_in, (char *)a->recv + (size_t)i * msg_in, (size_t)rows * M * es, W, cur);
+        if (rc) return rc;
+      }
+      rc = stage_gemms(i, cur);
+      if (rc) return rc;
+      Range r("tutel_amd.all_to_all");
+      rc = exchange(c, (const char *)a->send + (size_t)i * msg_out, (char *)a->back + (size_t)i * msg_out, (size_t)rows * Mo * es, W, cur);
+      if (rc) return rc;
+    }
+  } else {
+    // 3-stage pipeline over two streams: stage i+1 is on the links while stage i is in the GEMMs and stage i-1 travels
+    // back.  The COLLECTIVES stay on the caller's stream and the GEMMs go to the communicator's side stream: the
+    // caller's stream is the origin of a HIP-graph capture, and RCCL can be captured there but not on a stream that
+    // joined the capture through an event (segfault inside the library, tools/graph_rccl_probe.py) -- plain kernel
+    // launches are fine on either.  Eager and captured execution take this one path.
+    hipStream_t ks = c->side_stream;
+    {
+      Range r("tutel_amd.all_to_all(dispatch)");
+      for (int i = 0; i < degree; ++i) {
+        rc = exchange(c, (const char *)a->enc + (size_t)i * msg_in, (char *)a->recv + (size_t)i * msg_in, (size_t)rows * M * es, W, cur);
+        if (rc) return rc;
+        HIP_CHECK(hipEventRecord(c->recv_ev[i], cur), "hipEventRecord");
+      }
+    }
+    for (int i = 0; i < degree; ++i) {
+      HIP_CHECK(hipStreamWaitEvent(ks, c->recv_ev[i], 0), "hipStreamWaitEvent");  // first wait: the side stream joins (forks from) the caller's
+      rc = stage_gemms(i, ks);
+      if (rc) return rc;
+      HIP_CHECK(hipEventRecord(c->done_ev[i], ks), "hipEventRecord");
+      HIP_CHECK(hipStreamWaitEvent(cur, c->done_ev[i], 0), "hipStreamWaitEvent");  // last wait: the side stream is joined back
+      Range r("tutel_amd.all_to_all(combine)");
+      rc = exchange(c, (const char *)a->send + (size_t)i * msg_out, (char *)a->back + (size_t)i * msg_out, (size_t)rows * Mo * es, W, cur);
+      if (rc) return rc;
+    }
+  }
+
+  Range r("tutel_amd.fast_decode");
+  return tutel_amd_fast_decode(a->back, a->dtype, a->idx, a->loc, dec_gates, a->gate_dtype, T, Mo, k, C, E, chunk_rows, expert_slice, W, a->y, cur);
+}

@@ -216,7 +216,7 @@ class FusedExpertsNetwork(torch.nn.Module):
         if getattr(ctx, "megablocks_size", 0) > 0:
             counts, align = ctx.dispatch_count, int(ctx.megablocks_size)
         w1, b1, w2, b2 = self.batched_fc1_w, self.batched_fc1_bias, self.batched_fc2_w, self.batched_fc2_bias
-        w2_kmajor = _PREPACK and not self.training
+        w2_kmajor = self.w2_kmajor_now()
         if w2_kmajor:
             w2 = self._kmajor.get("fc2", w2)
         if b2 is not None and b2.size(-1) != self.output_dim:
@@ -234,6 +234,10 @@ class FusedExpertsNetwork(torch.nn.Module):
             h = ops.expert_gemm(x, w1, b1, True, act=self.fused_activation(), E_loc=w1.size(0), R=R,
                                 a_layout=a_layout, row_counts=counts, row_align=align)
         return ops.expert_gemm(h, w2, b2, w2_kmajor, out=out, d_layout=d_layout, row_counts=counts, row_align=align)
+
+    def w2_kmajor_now(self):
+        """eval-mode modules run fc2 on a k-major copy of its weights (KMajorCache)"""
+        return _PREPACK and not self.training
 
     def invalidate_prepacked(self):
         """Drop the eval-mode k-major weight copies (needed only after writes through `param.data`)."""

@@ -1,0 +1,204 @@
+"""The expert-parallel pipeline behind one native call (tutel_amd_ep_forward, csrc/ep.hip).
+
+    encode -> all-to-all -> expert FFN -> all-to-all -> decode
+
+One C call enqueues every kernel of the forward after routing and, with more than one rank, the
+RCCL all-to-alls on the library's own communicator and communication stream (event table inside the
+library) -- the structure of the reference's native overlap layer (custom_kernel.cpp:341-365,
+433-461, 520-654) instead of ~20 Python-driven enqueues per forward.
+
+This module owns the host side of that call:
+  * one communicator per process group: rank 0 of the group draws the RCCL unique id, the bytes are
+    broadcast with torch.distributed, every rank creates its communicator, then all ranks run a
+    tagged all-to-all and agree (all-reduce) that it delivered the right blocks.  Any failure on any
+    rank makes every rank fall back to the torch.distributed path (impls/overlap.py), loudly;
+  * the workspace of the pipeline, cached per (layer, shape, stream): buffers live as long as the
+    layer, calls on one stream are ordered, so nothing is allocated per forward except the output.
+"""
+import ctypes
+import logging
+import os
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib, ops
+
+ENABLED = int(os.environ.get("TUTEL_AMD_NATIVE_EP", "1")) != 0
+_FORCE_COMM = False  # test hook: run a single rank through a real 1-rank RCCL communicator (staged pipeline, both streams)
+_comms = {}      # id(group) / "world" -> EpComm | False (creation failed: do not retry)
+_zero_rows = {}
+
+
+class EpComm:
+    def __init__(self, handle, world, rank):
+        self.handle, self.world, self.rank = handle, world, rank
+
+    def all_to_all(self, out, inp):
+        assert out.is_contiguous() and inp.is_contiguous() and out.numel() == inp.numel() and inp.numel() % self.world == 0
+        per_peer = inp.numel() * inp.element_size() // self.world
+        _lib.check(_lib.lib().tutel_amd_ep_all_to_all(self.handle, inp.data_ptr(), out.data_ptr(), per_peer, ops._stream()),
+                   "tutel_amd_ep_all_to_all")
+
+
+def _rccl_hint():
+    return os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
+
+
+def _create(group, device):
+    """Collective over `group`: every rank must call it.  Returns EpComm or None (all ranks agree)."""
+    L = _lib.lib()
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    ok, handle = 1, ctypes.c_void_p()
+    idbuf = torch.zeros([_lib.EP_ID_BYTES], dtype=torch.uint8)
+    try:
+        if L.tutel_amd_ep_load_rccl(_rccl_hint()) != 0:
+            raise _lib.TutelAmdError(L.tutel_amd_last_error().decode())
+        if rank == 0:
+            raw = (ctypes.c_ubyte * _lib.EP_ID_BYTES)()
+            _lib.check(L.tutel_amd_ep_unique_id(raw, _lib.EP_ID_BYTES), "tutel_amd_ep_unique_id")
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+    except Exception as ex:  # keep going: the broadcast below is collective
+        logging.warning("tutel_amd: native expert-parallel path unavailable on rank %d (%s)", rank, ex)
+        ok = 0
+    # the id travels through the existing process group (the reference broadcasts it the same way, communicate.py:150-163)
+    on_dev = dist.get_backend(group) == "nccl"
+    t = idbuf.to(device) if on_dev else idbuf
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    idbytes = bytes(t.cpu().tolist())
+    if ok:
+        try:
+            with torch.cuda.device(device):
+                _lib.check(L.tutel_amd_ep_comm_create(idbytes, len(idbytes), W, rank, ctypes.byref(handle)), "tutel_amd_ep_comm_create")
+            comm = EpComm(handle, W, rank)
+            # self-check: block p of my send buffer carries (my rank, p); after the exchange block r must carry (r, my rank)
+            n = 1024
+            send = (torch.arange(W, device=device, dtype=torch.int32).view(W, 1) + 1000 * rank).repeat(1, n).contiguous()
+            recv = torch.full_like(send, -1)
+            comm.all_to_all(recv, send)
+            torch.cuda.synchronize(device)
+            want = (torch.arange(W, device=device, dtype=torch.int32).view(W, 1) * 1000 + rank).repeat(1, n)
+            if not torch.equal(recv, want):
+                raise _lib.TutelAmdError("tagged all-to-all returned wrong blocks")
+        except Exception as ex:
+            logging.warning("tutel_amd: native expert-parallel communicator failed its self-check on rank %d (%s)", rank, ex)
+            ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=device if on_dev else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag) == 0:
+        if handle:
+            L.tutel_amd_ep_comm_destroy(handle)
+        if rank == 0:
+            logging.warning("tutel_amd: falling back to the torch.distributed all-to-all path (impls/overlap.py)")
+        return None
+    return comm
+
+
+def communicator(group, device):
+    """EpComm of `group` (created on first use; collective), or None when the native path is unavailable."""
+    key = id(group) if group is not None else "world"
+    c = _comms.get(key)
+    if c is None:
+        c = _create(group, device) or False
+        _comms[key] = c
+    return c or None
+
+
+def destroy_all():
+    L = _lib.lib()
+    for c in _comms.values():
+        if c:
+            L.tutel_amd_ep_comm_destroy(c.handle)
+    _comms.clear()
+
+
+def plan(E, W, capacity, degree, allow_sliced=True):
+    """tutel_amd_ep_plan as a dict (CPU-callable: pure arithmetic inside the library)."""
+    p = _lib.EpPlan()
+    _lib.check(_lib.lib().tutel_amd_ep_plan(E, W, capacity, degree, int(allow_sliced), ctypes.byref(p)), "tutel_amd_ep_plan")
+    return {n: int(getattr(p, n)) for n, _ in _lib.EpPlan._fields_}
+
+
+def usable(layer, x, crit, degree):
+    """Can this forward run through tutel_amd_ep_forward?  (Everything else takes the Python-orchestrated paths.)"""
+    if not ENABLED or getattr(layer, "megablocks_size", 0) > 0 or crit.gates2d is None or crit[4] <= 0:
+        return False
+    W = layer.world_size
+    if W > 1:
+        if not dist.is_initialized() or dist.get_backend(layer.group) != "nccl":
+            return False  # gloo rendezvous (ranks sharing a GPU in the tests): host-staged exchange in impls/overlap.py
+    return crit[4] % max(degree, 1) == 0 and degree <= 32
+
+
+class _Workspace:
+    def __init__(self, layer, x, crit, degree, comm):
+        ex = layer.experts
+        W, E, C, k = layer.world_size, crit[0], crit[4], crit.idx2d.shape[0]
+        T, M = x.shape
+        H, Mo = ex.batched_fc1_w.size(1), ex.output_dim
+        dev, dt = x.device, x.dtype
+        E_loc = E // W
+        fuse = comm is None and degree <= 1 and layer.is_postscore
+        a = _lib.EpArgs()
+        a.T, a.M, a.H, a.M_out, a.num_experts, a.world, a.k, a.capacity, a.degree = T, M, H, Mo, E, W, k, C, max(degree, 1)
+        a.allow_sliced, a.dtype, a.act = 1, ops._DT[dt], ops.ACT_CODES[ex.fused_activation()]
+        a.is_postscore, a.fuse_encode = int(bool(layer.is_postscore)), int(fuse)
+        self.bufs = {}
+
+        def buf(name, rows, cols):
+            t = torch.empty([rows, cols], dtype=dt, device=dev)
+            self.bufs[name] = t
+            setattr(a, name, t.data_ptr())
+        buf("hid", E_loc * W * C, H)
+        buf("send", E * C, Mo)
+        if not fuse:
+            buf("enc", E * C, M)
+            buf("recv", E * C, M)
+            buf("back", E * C, Mo)
+        else:
+            z = _zero_rows.get((dev, dt))
+            if z is None or z.numel() < M:
+                z = _zero_rows[(dev, dt)] = torch.zeros([max(M, 8192)], dtype=dt, device=dev)
+            self.bufs["zero_row"] = z
+            a.zero_row = z.data_ptr()
+        self.args, self.comm = a, comm
+
+
+def forward(layer, x, crit, degree):
+    """x [T, M] (contiguous, expert dtype) -> y [T, M_out].  The caller has checked usable() and experts.can_fuse()."""
+    ex = layer.experts
+    W = layer.world_size
+    with_comm = W > 1 or (_FORCE_COMM and dist.is_initialized())
+    comm = communicator(layer.group, x.device) if with_comm else None
+    if with_comm and comm is None:
+        return None
+    if not with_comm:
+        degree = 1  # a single rank has nothing to overlap (the reference returns expert_fn(input) there, overlap.py:16-17)
+    key = (tuple(x.shape), x.dtype, x.device, crit[0], crit[4], crit.idx2d.shape[0], degree, bool(layer.is_postscore),
+           ex.fused_activation(), ops._stream(), with_comm)
+    cache = layer.__dict__.setdefault("_ep_workspaces", {})
+    ws = cache.get(key)
+    if ws is None:
+        if len(cache) > 8:
+            cache.clear()
+        ws = cache[key] = _Workspace(layer, x, crit, degree, comm)
+    a = ws.args
+    w1, b1, w2, b2 = ex.batched_fc1_w, ex.batched_fc1_bias, ex.batched_fc2_w, ex.batched_fc2_bias
+    kmajor = ex.w2_kmajor_now()
+    if kmajor:
+        w2 = ex._kmajor.get("fc2", w2)
+    if b2 is not None and b2.size(-1) != ex.output_dim:
+        b2 = b2[:, :ex.output_dim].contiguous()
+    gates = crit.gates2d
+    y = torch.empty([x.shape[0], ex.output_dim], dtype=x.dtype, device=x.device)
+    a.w2_kmajor = int(kmajor)
+    a.x, a.slot_map, a.idx, a.loc, a.gates = x.data_ptr(), crit.slot_map.data_ptr(), crit.idx2d.data_ptr(), crit.loc2d.data_ptr(), gates.data_ptr()
+    a.gate_dtype = ops._DT[gates.dtype]
+    a.w1, a.w2 = w1.data_ptr(), w2.data_ptr()
+    a.b1 = b1.data_ptr() if b1 is not None else None
+    a.b2 = b2.data_ptr() if b2 is not None else None
+    a.y = y.data_ptr()
+    _lib.check(_lib.lib().tutel_amd_ep_forward(comm.handle if comm is not None else None, ctypes.byref(a), ops._stream()),
+               "tutel_amd_ep_forward")
+    layer.protected_shape = torch.Size([layer.num_local_experts, W * crit[4], ex.output_dim])
+    return y

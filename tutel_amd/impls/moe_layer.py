@@ -28,6 +28,7 @@ from . import communicate as C
 from . import losses
 from .fast_dispatch import RoutingPlan, extract_critical, fast_decode, fast_encode, get_dispatch_count
 from .overlap import a2a_ffn_overlap_forward, a2a_ffn_overlap_fused
+from . import ep_native
 from ..experts.ffn import FusedExpertsNetwork
 
 
@@ -285,6 +286,19 @@ class MOELayer(torch.nn.Module):
         self.dispatch_count = get_dispatch_count(crit)
         if adaptive_r is not None:
             self.adaptive_degree = adaptive_r
+
+        # the whole post-routing pipeline behind ONE native call (csrc/ep.hip): encode -> all-to-all -> expert FFN ->
+        # all-to-all -> decode, `degree` stages pipelined over the caller's stream and the library's RCCL stream
+        if (x.is_cuda and self.adaptive_degree != 0 and len(reserve_shape) == 1 and not _FORCE_OVERLAP
+                and self.num_global_experts >= self.world_size and isinstance(self.experts, FusedExpertsNetwork)
+                and isinstance(crit, RoutingPlan) and not C.SKIP_A2A and (degree == 1 or not self.use_2dh)
+                and (x.dtype == logits_dtype or (logits_dtype == torch.float32 and x.dtype == original_dtype))
+                and ep_native.usable(self, x, crit, degree) and self.experts.can_fuse(x, self)):
+            y = ep_native.forward(self, x if x.is_contiguous() else x.contiguous(), crit, degree)
+            if y is not None:
+                y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
+                self.l_aux = y.l_aux = l_aux
+                return self.result_func(y) if self.result_func is not None else y
 
         # overlapped expert parallelism on the HIP path: one fused routine, no layout copies
         if (degree > 1 and x.is_cuda and self.adaptive_degree != 0 and len(reserve_shape) == 1
