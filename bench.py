@@ -12,23 +12,25 @@ reference's `helloworld.py --eval` (helloworld.py:141-146).
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
     per GPU: 4096 tokens (batch 16 x 256) x model_dim 2048, hidden 2048, 64 GLOBAL experts,
     top-2, capacity_factor 1.0 (capacity 128/expert/rank), bf16, ReLU, biases on.
-N > 1: experts are sharded E_loc = 64/N per rank (expert parallel, RCCL all_to_all_single over
-xGMI), every rank keeps its own 4096 tokens -> per-GPU work is fixed: weak scaling,
-value = N * 4096 / t.
+N > 1: experts are sharded E_loc = 64/N per rank (expert parallel, RCCL all-to-all over xGMI through the
+library's own communicator, a2a_ffn_overlap_degree 2), every rank keeps its own 4096 tokens -> per-GPU work
+is fixed: weak scaling, value = N * 4096 / t.
 
-Timing: untimed initialisation passes (--settle: allocator / weight pre-layout / clock state), W untimed
-warm-up steps; barrier + synchronize; exactly K steps; synchronize + barrier; MAX over ranks.  Rank 0
-prints ONE JSON line.
+Timing: `--settle` untimed initialisation passes (allocator / weight pre-layout / clock state; reported in
+the JSON), W untimed warm-up steps; barrier + synchronize; exactly K steps; synchronize + barrier; MAX over
+ranks.  Rank 0 prints ONE JSON line.  Inside the timed region the two expert GEMM launches are bracketed by HIP events
+on their launch stream (tutel_amd_stage_timing(2)) -- `roofline` is computed from those -- and one event per step gives
+min / median step times next to the mean; `stages` (every launch bracketed) comes from a separate untimed pass, because a
+dozen event records per step slow the step down by ~10 %.
 
 `roofline`: the dominant kernel is the fc1 grouped GEMM.  N = 1 (128 rows per expert):
 expert_gemm_glds_kernel<bf16,k-major,relu>, HBM-bound; achieved = algorithmic bytes per launch
 (E_loc*H*M weights + E_loc*R*M tokens + E_loc*R*H hidden out, x2 bytes) / its average duration.
-More than 128 rows per expert and launch (N > 1, --tokens 65536, dropless): expert_gemm_big_kernel,
-MFMA-bound; achieved = flop per launch / its average duration.  Durations are measured with HIP events
-on the launch stream inside the timed region.
-`cpu_baseline`: the CPU oracle (a port of the reference CPU path, oracle/moe_oracle.py) timed on
-this box's host cores on a bounded sample, rank 0, N=1 only.  Checker code is used here ONLY as
-that reported baseline; it is never part of the measured GPU path.
+256 rows or more per expert and launch (N > 1, --tokens 65536): expert_gemm_pp_kernel, MFMA-bound; achieved = flop
+per launch / its average duration.
+`cpu_baseline`: the CPU oracle (a port of the reference CPU path, oracle/moe_oracle.py) timed on this box's host
+cores on a bounded sample, rank 0, N=1 only, next to the figure BASELINE.md measured with the reference itself.
+Checker code is used here ONLY as that reported baseline; it is never part of the measured GPU path.
 """
 import argparse
 import json
@@ -42,8 +44,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
-MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide: measured float4 copy (79 % of spec)
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak, same guide
 
 
 def build_layer(M, H, E_loc, k, rank, overlap, dtype, fp32_gate, capacity_factor=1.0):
@@ -60,70 +63,91 @@ def build_layer(M, H, E_loc, k, rank, overlap, dtype, fp32_gate, capacity_factor
     return layer
 
 
-class GemmTimer:
-    """Wraps tutel_amd.ops.expert_gemm: HIP events around every launch of the dominant kernel."""
+class GateTimer:
+    """HIP events around the gate projection (a library GEMM issued by torch, so not covered by the C-ABI stage timer)."""
 
-    def __init__(self):
-        from tutel_amd import ops
-        self.ops, self.real, self.events, self.on = ops, ops.expert_gemm, {True: [], False: []}, False
-        self.bytes, self.flops = {True: 0, False: 0}, {True: 0, False: 0}  # algorithmic, per launch (last seen)
-        self.rows = {True: 0, False: 0}                                    # rows per expert of the last launch
-        ops.expert_gemm = self
-        self.real_gather = ops.expert_gemm_gather
-        ops.expert_gemm_gather = self.gather
+    def __init__(self, gate):
+        self.gate, self.real, self.events, self.on = gate, gate.forward, [], False
+        gate.forward = self
 
-    def __call__(self, a, w, bias, w_kmajor, *args, **kw):
+    def __call__(self, x):
         if not self.on:
-            return self.real(a, w, bias, w_kmajor, *args, **kw)
+            return self.real(x)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        out = self.real(a, w, bias, w_kmajor, *args, **kw)
+        out = self.real(x)
         e.record()
-        km = kw.get("act", "none") != "none"  # True: fc1 (bias + ReLU fused), False: fc2
-        self.events[km].append((s, e))
-        E_loc, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w_kmajor else (w.shape[0], w.shape[2], w.shape[1])
-        R = kw.get("R") or a.shape[1]
-        self.rows[km] = R
-        self.bytes[km] = (w.numel() + E_loc * R * K + E_loc * R * N) * w.element_size()
-        self.flops[km] = 2 * E_loc * R * N * K
+        self.events.append((s, e))
         return out
 
-    def gather(self, x, smap, w, bias, w_kmajor, act, R, **kw):
-        """fc1 with fast_encode fused (single rank): same kernel, rows gathered from the tokens.  Algorithmic
-        bytes are counted exactly as for the plain fc1 launch (weights + E*R token rows + hidden out)."""
-        if not self.on:
-            return self.real_gather(x, smap, w, bias, w_kmajor, act, R, **kw)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        out = self.real_gather(x, smap, w, bias, w_kmajor, act, R, **kw)
-        e.record()
-        km = True  # the gathered launch is always fc1
-        self.rows[km] = R
-        self.events[km].append((s, e))
-        E_loc, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w_kmajor else (w.shape[0], w.shape[2], w.shape[1])
-        self.bytes[km] = (w.numel() + E_loc * R * K + E_loc * R * N) * w.element_size()
-        self.flops[km] = 2 * E_loc * R * N * K
-        return out
-
-    def avg_us(self, fc1):
-        ev = self.events[fc1]
-        return sum(s.elapsed_time(e) for s, e in ev) * 1e3 / max(1, len(ev)), len(ev)
+    def avg_us(self):
+        return sum(s.elapsed_time(e) for s, e in self.events) * 1e3 / max(1, len(self.events))
 
 
-def cpu_baseline(T, M, H, E, k, max_seconds=25.0):
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(T, M, H, E, k, max_seconds=20.0):
     from oracle import moe_oracle as O
-    x, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=torch.float32, seed=0)
-    with torch.no_grad():
-        O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)  # warm-up (page-in, thread pool)
-        t0, n = time.time(), 0
-        while n < 10 and (time.time() - t0) < max_seconds:
-            O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)
-            n += 1
-        dt = (time.time() - t0) / max(1, n)
-    return {"value": round(T / dt, 1), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "ms_per_step": round(dt * 1e3, 2), "dtype": "f32",
-            "sample": f"{n} forward passes of the same {T}-token workload (fp32, oracle/moe_oracle.py moe_forward = "
-                      f"the reference's CPU path restated: ATen softmax/matmul + C scatter/gather loops), host cores only"}
+    threads = min(physical_cores(), 32)  # ATen GEMMs stop scaling (and the C scatter loops are single-threaded) well before that
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        x, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=torch.float32, seed=0)
+        with torch.no_grad():
+            O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)  # warm-up (page-in, thread pool)
+            times = []
+            t_all = time.time()
+            while len(times) < 10 and (time.time() - t_all) < max_seconds:
+                t0 = time.time()
+                O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)
+                times.append(time.time() - t0)
+    finally:
+        torch.set_num_threads(old)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": round(T / dt, 1), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "kind_note": "oracle/moe_oracle.py moe_forward: the reference's CPU path restated (ATen softmax / matmul + C scatter / gather "
+                         "loops); /root/reference does not exist on the GPU box, so the reference itself cannot be timed here",
+            "ms_per_step": round(dt * 1e3, 2), "dtype": "f32", "host_logical_cpus": os.cpu_count(), "host_physical_cores": physical_cores(),
+            "sample": f"median of {len(times)} forward passes of the same {T}-token workload (fp32), torch.set_num_threads({threads})",
+            "reference_measured": {"value": "13-15 k tokens/s (0.27-0.31 s per forward)", "cores": 8, "kind": "reference",
+                                   "source": "BASELINE.md section 2: the reference's own helloworld --device=cpu --eval at this shape, survey container (8 x Xeon 2.1 GHz)"}}
+
+
+def run_timed(step, x, steps, world, timer_gate, mode=2):
+    """exactly `steps` steps between barrier + synchronize pairs; returns (elapsed_s, per-step ms list, stage report).
+    mode 2: HIP events around the two expert GEMMs only (the timed region); mode 1: around every launch (breakdown pass)."""
+    from tutel_amd import ops
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.stage_timing(mode)
+    timer_gate.on = mode == 1
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    y = None
+    for i in range(steps):
+        y = step(x)
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ops.stage_timing(0)
+    timer_gate.on = False
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    return t1 - t0, per_step, ops.stage_report(), y
 
 
 def main():
@@ -131,7 +155,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--settle", type=int, default=1500, help="untimed initialisation passes before the warm-up steps")
+    ap.add_argument("--settle", type=int, default=200,
+                    help="untimed initialisation passes before the warm-up steps (~60 ms: allocator steady state, k-major weight "
+                         "copies, the GPU leaving its idle clock state); reported in the JSON line")
     ap.add_argument("--tokens", type=int, default=4096)
     ap.add_argument("--model_dim", type=int, default=2048)
     ap.add_argument("--hidden_size", type=int, default=2048)
@@ -144,7 +170,8 @@ def main():
                     help="BASELINE configs[2]: 0 = dropless (capacity read back from the device each step)")
     ap.add_argument("--megablocks_size", type=int, default=0, help="configs[2]: row granularity of the dropless expert GEMMs")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured HIP graph (N=1 only)")
+    ap.add_argument("--no_extra", action="store_true", help="skip the short BASELINE configs[2] (dropless) measurement appended at N=1")
+    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured HIP graph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -166,7 +193,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from tutel_amd import _lib
+    from tutel_amd import _lib, ops
+    from tutel_amd.impls import ep_native
     _lib.lib()  # fail loudly if the HIP library is missing
     T, M, H, E, k = args.tokens, args.model_dim, args.hidden_size, args.experts, args.top
     assert E % world == 0
@@ -174,43 +202,33 @@ def main():
     overlap = args.a2a_ffn_overlap_degree or (2 if world > 1 else 1)
     dtype = getattr(torch, args.dtype)
     dname = "bf16" if dtype == torch.bfloat16 else "fp16"
+    es = 2
 
     # like helloworld.py:77,93-94: the capacity factor belongs to the gate, megablocks_size to the forward call
     layer = build_layer(M, H, E_loc, k, rank, overlap, dtype, args.fp32_gate, args.capacity_factor).to(dev).eval()
     torch.manual_seed(0)  # same tokens on every rank, like helloworld.py:112-113
     x = torch.randn([16, T // 16, M], dtype=torch.float32).to(dtype).to(dev)
-    timer = GemmTimer()
-    fwd_kw = {}
-    if args.megablocks_size:
-        fwd_kw = dict(megablocks_size=args.megablocks_size)
+    gate_timer = GateTimer(layer.gates[0])
+    fwd_kw = dict(megablocks_size=args.megablocks_size) if args.megablocks_size else {}
     step = (lambda t: layer(t, **fwd_kw)) if fwd_kw else layer
-    if args.graph and world == 1:
+    launch = "eager"
+    if args.graph:
         from tutel_amd.impls.graph import GraphedForward
-        step = GraphedForward(layer, x)  # same kernels, enqueued by one hipGraphLaunch per step
+        step = GraphedForward(layer, x, **fwd_kw)  # same kernels (and collectives), enqueued by one hipGraphLaunch per step
+        launch = "hip-graph replay"
 
     with torch.no_grad():
-        # initialisation passes before the W warm-up steps of the contract: the caching allocator reaches its
-        # steady state, the k-major weight copies are laid out, and the GPU leaves its idle clock state (the
-        # first few hundred ms after start-up run 5-8 % slower: 20 timed steps measured 0.313 ms without, 0.283 with); never timed
         for _ in range(args.settle):
             step(x)
         for _ in range(args.warmup):
             y = step(x)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        timer.on = not (args.graph and world == 1)  # events cannot be recorded inside a replayed graph
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            y = step(x)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        timer.on = False
-    elapsed = t1 - t0
+        elapsed, per_step, gemms, y = run_timed(step, x, args.steps, world, gate_timer, mode=2)
+        # the per-stage table comes from a separate, untimed pass with events around EVERY launch (a dozen event records
+        # per step perturb the step by ~10 %; the timed region carries only those of the two dominant kernels)
+        nb = 20
+        _, _, stages, _ = run_timed((lambda t: layer(t, **fwd_kw)), x, nb, world, gate_timer, mode=1)
+        if args.graph:  # events cannot be recorded inside a replayed graph: the GEMM times come from the eager pass as well
+            gemms = stages
     if world > 1:
         tt = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -218,59 +236,95 @@ def main():
     assert torch.isfinite(y.float()).all()
 
     C = int(layer.protected_shape[1]) // world  # capacity the layer actually used (dropless: max expert load)
-    if not timer.events[True]:  # graph mode: time the two GEMM launches in a short eager pass after the timed region
-        timer.on = True
-        with torch.no_grad():
-            for _ in range(20):
-                step(x)
-        torch.cuda.synchronize()
-        timer.on = False
-    fc1_us, n1 = timer.avg_us(True)
-    fc2_us, n2 = timer.avg_us(False)
-    fc1_bytes, fc2_bytes = timer.bytes[True], timer.bytes[False]  # per LAUNCH (one overlap chunk when N > 1)
+    R = world * C                               # rows per local expert
+    stage_us = {name: round(tot / nb, 2) for name, (tot, cnt) in stages.items() if cnt}
+    launches = {name: cnt for name, (tot, cnt) in stages.items() if cnt}
+    stage_us["gate_projection(hipBLASLt)"] = round(gate_timer.avg_us(), 2)
+    fc1_tot, fc1_n = gemms["expert_fc1"]
+    fc2_tot, fc2_n = gemms["expert_fc2"]
+    fc1_us, fc2_us = fc1_tot / max(1, fc1_n), fc2_tot / max(1, fc2_n)   # per LAUNCH (one pipeline stage when N > 1)
+    rows_per_launch, experts_per_launch = R, E_loc
+    if world > 1 and overlap > 1:
+        pl = ep_native.plan(E, world, C, overlap)
+        rows_per_launch, experts_per_launch = pl["gemm_rows"], pl["experts_per_stage"]
+    gemm_bytes = (experts_per_launch * H * M + experts_per_launch * rows_per_launch * (M + H)) * es
+    gemm_flops = 2 * experts_per_launch * rows_per_launch * M * H
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and world == 1 and (T, M, H, E, k) == (4096, 2048, 2048, 64, 2):
+    if os.path.exists(tpath) and world == 1 and (T, M, H, E, k) == (4096, 2048, 2048, 64, 2) and args.capacity_factor == 1.0:
         traffic = json.load(open(tpath)).get("expert_gemm_fc1_hbm_bytes_per_launch")
 
-    fc2_obj = {"avg_launch_us": round(fc2_us, 2), "achieved_GBs": round(fc2_bytes / max(fc2_us, 1e-9) * 1e-3, 1),
-               "tflops": round(timer.flops[False] / max(fc2_us, 1e-9) * 1e-6, 1), "launches_timed": n2}
-    if timer.rows[True] >= 256:
-        # >= 256 rows per expert and launch (expert-parallel ranks): the 256 x 256-tile kernel, bound by the MFMA rate
-        tf = timer.flops[True] / fc1_us * 1e-6
-        roofline = {"bound": "mfma", "kernel": f"expert_gemm_big_kernel<{dname},k-major,relu> (fc1 grouped GEMM, 256-row tile: 256x256 or 256x128 by grid size, LDS-DMA)",
+    fc2_obj = {"avg_launch_us": round(fc2_us, 2), "achieved_GBs": round(gemm_bytes / max(fc2_us, 1e-9) * 1e-3, 1),
+               "tflops": round(gemm_flops / max(fc2_us, 1e-9) * 1e-6, 1), "launches_timed": fc2_n}
+    if rows_per_launch >= 256:
+        tf = gemm_flops / fc1_us * 1e-6
+        roofline = {"bound": "mfma", "kernel": f"expert_gemm_pp_kernel<{dname},relu> (fc1 grouped GEMM; 256x256 ping-pong tile, or 256x128 / 128x128 when the grid is small)",
                     "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": None, "flops_per_launch": timer.flops[True], "rows_per_expert": timer.rows[True],
-                    "avg_launch_us": round(fc1_us, 2), "launches_timed": n1, "fc2_gemm": fc2_obj}
+                    "traffic": None, "flops_per_launch": gemm_flops, "rows_per_expert": rows_per_launch,
+                    "avg_launch_us": round(fc1_us, 2), "launches_timed": fc1_n, "fc2_gemm": fc2_obj}
     else:
+        gbs = gemm_bytes / fc1_us * 1e-3
         roofline = {"bound": "hbm", "kernel": f"expert_gemm_glds_kernel<{dname},k-major,relu> (fc1 grouped GEMM, LDS-DMA)",
-                    "achieved": round(fc1_bytes / fc1_us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(fc1_bytes / fc1_us * 1e-3 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": fc1_bytes, "avg_launch_us": round(fc1_us, 2), "launches_timed": n1,
-                    "fc2_gemm": fc2_obj, "mfma_tflops_fc1": round(timer.flops[True] / fc1_us * 1e-6, 1)}
+                    "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_GBs": HBM_ACHIEVABLE_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": gemm_bytes, "avg_launch_us": round(fc1_us, 2), "launches_timed": fc1_n,
+                    "fc2_gemm": fc2_obj, "mfma_tflops_fc1": round(gemm_flops / fc1_us * 1e-6, 1)}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * T / (elapsed / args.steps)
+        # algorithmic bytes of the whole forward on one rank: gate reads x; encode (T + E*C) rows; FFN weights + rows in/out;
+        # decode (n_kept + T) rows; all-to-all bytes are link traffic, not HBM, and are listed separately
+        layer_bytes = (T * M + (T + E * C) * M + 2 * E_loc * H * M + 2 * E_loc * R * (M + H) + (min(k * T, E * C) + T) * M) * es
+        srt = sorted(per_step)
         out = {
             "metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "settle": args.settle,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dname, "data": "synthetic" if not share else "synthetic; TEST HOOK: all ranks share one GPU, host-staged all-to-all -- not a measurement",
+            "step_ms": {"mean_wall": round(ms, 4), "min": round(srt[0], 4), "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4),
+                        "note": "min / median / max from one HIP event per step (rank 0); mean_wall = the timed region / steps"},
             "config": {"workload": "BASELINE.json configs[1]: tutel.moe.moe_layer forward (eval), per GPU 4096 tokens "
                                    "(batch 16 x 256) x model_dim 2048, hidden 2048, 64 global experts, top-2, "
                                    f"capacity_factor {args.capacity_factor}, ReLU, {dname}, random-init weights",
                        "tokens_per_gpu": T, "model_dim": M, "hidden_size": H, "global_experts": E, "top_k": k,
                        "capacity": C, "parallelism": f"ep{world}" if world > 1 else "single-gpu",
                        "a2a_ffn_overlap_degree": overlap, "fp32_gate": bool(args.fp32_gate),
-                       "capacity_factor": args.capacity_factor, "megablocks_size": args.megablocks_size,
-                       "launch": "hip-graph replay" if (args.graph and world == 1) else "eager"},
+                       "capacity_factor": args.capacity_factor, "megablocks_size": args.megablocks_size, "launch": launch,
+                       "exchange": ("library RCCL communicator (tutel_amd_ep_forward)" if ep_native._comms and any(ep_native._comms.values())
+                                    else "torch.distributed all_to_all_single") if world > 1 else "none (single rank)"},
             "roofline": roofline,
+            "stages": {"avg_us_per_step": stage_us, "launches_timed": launches,
+                       "sum_us": round(sum(stage_us.values()), 2),
+                       "steps": nb,
+                       "note": "separate untimed pass after the timed region, HIP events around EVERY launch (tutel_amd_stage_timing(1)); "
+                               "the timed region itself carries events around the two expert GEMMs only (roofline object)"},
+            "layer_roofline": {"algorithmic_bytes_per_step": layer_bytes, "achieved_GBs": round(layer_bytes / (ms * 1e-3) * 1e-9, 1),
+                               "frac_of_hbm_peak": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
+                               "frac_of_hbm_achievable": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_ACHIEVABLE_GBS, 4)},
         }
+        if world == 1 and not args.no_extra and args.capacity_factor == 1.0 and not args.graph and (T, M, H, E, k) == (4096, 2048, 2048, 64, 2):
+            # BASELINE configs[2] (same shape, dropless + megablocks): a short secondary measurement, recorded next to the headline one
+            del layer, step
+            lay2 = build_layer(M, H, E_loc, k, rank, 1, dtype, args.fp32_gate, 0.0).to(dev).eval()
+            gt2 = GateTimer(lay2.gates[0])
+            with torch.no_grad():
+                for _ in range(30):
+                    lay2(x, megablocks_size=4)
+                el2, ps2, st2, _ = run_timed(lambda t: lay2(t, megablocks_size=4), x, 30, 1, gt2, mode=2)
+            ms2 = el2 / 30 * 1e3
+            out["extra"] = {"dropless_configs2": {
+                "workload": "BASELINE.json configs[2]: same shape, capacity_factor 0 (capacity = max expert load, read back each step), megablocks_size 4",
+                "value": round(T / (el2 / 30), 1), "unit": "tokens/s", "ms_per_step": round(ms2, 4), "steps": 30,
+                "capacity": int(lay2.protected_shape[1]),
+                "fc1_avg_us": round(st2["expert_fc1"][0] / max(1, st2["expert_fc1"][1]), 2),
+                "fc2_avg_us": round(st2["expert_fc2"][0] / max(1, st2["expert_fc2"][1]), 2)}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, M, H, E, k)
         print(json.dumps(out), flush=True)
     if world > 1:
+        ep_native.destroy_all()
         dist.destroy_process_group()
 
 

@@ -277,6 +277,8 @@ typedef struct {
   /* workspace (device, dtype): enc / recv [num_experts*C, M]; hid [E_loc*world*C, H]; send / back [num_experts*C, M_out] */
   void *enc, *recv, *hid, *send, *back;
   const void *zero_row;          /* >= M zero elements (fuse_encode only) */
+  const int32_t *row_counts;     /* dropless / megablocks (moe_layer.py:278-280: single rank only): per-expert row counts, */
+  int row_align;                 /*   rows >= ceil(count/row_align)*row_align are skipped by both GEMMs; NULL / 1 = all rows */
   void *y;                       /* out: [T, M_out] */
 } tutel_amd_ep_args_t;
 int tutel_amd_ep_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_ep_args_t *args, tutel_stream_t stream);
@@ -286,6 +288,19 @@ int tutel_amd_ep_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_ep_args_t *a
  * (set TUTEL_AMD_ROCTX=1 to load it).  The reference's only tracing is system.record_time (system.py:73-79). */
 int tutel_amd_range_push(const char *name);
 int tutel_amd_range_pop(void);
+
+/* ---- per-stage timing (measurement only; bench.py) ------------------------------------------------
+ * tutel_amd_stage_timing(1): from now on every entry point above brackets its kernel launch with a pair of HIP
+ * timing events on the launch stream (skipped while that stream is being captured); (2): only the two expert GEMMs
+ * (the dominant kernels: what a timed region can carry without being perturbed); (0): off.  tutel_amd_stage_report
+ * waits for the recorded events, returns per-stage totals (microseconds) and launch counts, and clears the
+ * records.  The reference's counterpart is system.record_time around whole steps (system.py:73-79). */
+enum {
+  TUTEL_STAGE_GATE_TOPK = 0, TUTEL_STAGE_LOCATION = 1, TUTEL_STAGE_ENCODE = 2, TUTEL_STAGE_FC1 = 3, TUTEL_STAGE_FC2 = 4,
+  TUTEL_STAGE_DECODE = 5, TUTEL_STAGE_A2A_DISPATCH = 6, TUTEL_STAGE_A2A_COMBINE = 7, TUTEL_STAGE_OTHER = 8, TUTEL_STAGE_COUNT = 9
+};
+int tutel_amd_stage_timing(int enable);
+int tutel_amd_stage_report(double *total_us, int *counts, int n_stages /* >= TUTEL_STAGE_COUNT */);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG

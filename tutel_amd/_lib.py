@@ -53,7 +53,8 @@ class EpArgs(ctypes.Structure):
     _fields_ = ([(n, _i) for n in ("T", "M", "H", "M_out", "num_experts", "world", "k", "capacity", "degree", "allow_sliced",
                                    "dtype", "gate_dtype", "act", "is_postscore", "w2_kmajor", "fuse_encode")] +
                 [(n, _vp) for n in ("x", "slot_map", "idx", "loc", "gates", "w1", "b1", "w2", "b2",
-                                    "enc", "recv", "hid", "send", "back", "zero_row", "y")])
+                                    "enc", "recv", "hid", "send", "back", "zero_row", "row_counts")] +
+                [("row_align", _i), ("y", _vp)])
 
 
 SIGNATURES.update({
@@ -65,10 +66,13 @@ SIGNATURES.update({
     "tutel_amd_ep_all_to_all": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tutel_amd_ep_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(EpPlan)]),
     "tutel_amd_ep_forward": (_i, [_vp, ctypes.POINTER(EpArgs), _vp]),
+    "tutel_amd_stage_timing": (_i, [_i]),
+    "tutel_amd_stage_report": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), _i]),
     "tutel_amd_range_push": (_i, [ctypes.c_char_p]),
     "tutel_amd_range_pop": (_i, []),
 })
 EP_ID_BYTES = 128
+STAGES = ("gate_topk", "location", "fast_encode", "expert_fc1", "expert_fc2", "fast_decode", "all_to_all_dispatch", "all_to_all_combine", "other")
 
 _lib = None
 

@@ -36,3 +36,60 @@ extern "C" int tutel_amd_set_option(int key, int value) {
   g_opt[key] = value;
   return 0;
 }
+
+// ---- per-stage timing (measurement only) -------------------------------------------------------------------
+// When enabled, every C-ABI entry point that launches a kernel brackets its launch with a pair of HIP events on
+// the launch stream (timing events; ~2 us of host time each, nothing on the device between kernels of one stream).
+// bench.py turns it on for the timed steps and reads back per-stage totals: the HIP-event durations the roofline
+// object is computed from, for every stage of the forward, with no Python between the launches.
+#include <vector>
+struct StageRec { hipEvent_t a, b; int stage; };
+static std::vector<StageRec> g_recs;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free;
+static int g_timing = 0;
+static thread_local int g_stage_hint = -1;
+
+void tutel_stage_hint(int stage) { g_stage_hint = stage; }
+
+int tutel_stage_begin(int stage, hipStream_t st) {
+  if (!g_timing) return -1;
+  if (g_stage_hint >= 0) stage = g_stage_hint;
+  if (g_timing == 2 && stage != TUTEL_STAGE_FC1 && stage != TUTEL_STAGE_FC2) return -1;  // mode 2: the two expert GEMMs only
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;  // never inside a graph capture
+  StageRec r;
+  r.stage = stage;
+  if (!g_free.empty()) {
+    r.a = g_free.back().first;
+    r.b = g_free.back().second;
+    g_free.pop_back();
+  } else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+    return -1;
+  }
+  (void)hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+  return (int)g_recs.size() - 1;
+}
+void tutel_stage_end(int token, hipStream_t st) {
+  if (token >= 0 && token < (int)g_recs.size()) (void)hipEventRecord(g_recs[token].b, st);
+}
+
+extern "C" int tutel_amd_stage_timing(int enable) {
+  g_timing = enable < 0 ? 0 : enable > 2 ? 1 : enable;
+  return 0;
+}
+
+extern "C" int tutel_amd_stage_report(double *total_us, int *counts, int n_stages) {
+  TUTEL_REQUIRE(total_us != nullptr && counts != nullptr && n_stages >= TUTEL_STAGE_COUNT, "tutel_amd_stage_report: need arrays of %d entries", TUTEL_STAGE_COUNT);
+  for (int i = 0; i < n_stages; ++i) { total_us[i] = 0.0; counts[i] = 0; }
+  for (auto &r : g_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.stage >= 0 && r.stage < n_stages) {
+      total_us[r.stage] += 1e3 * ms;
+      counts[r.stage] += 1;
+    }
+    g_free.push_back({r.a, r.b});
+  }
+  g_recs.clear();
+  return 0;
+}

@@ -13,6 +13,17 @@
 void tutel_set_error(const char *fmt, ...);
 int tutel_get_option(int key);  // TUTEL_OPT_*: -1 automatic, 0 / 1 forced (api.hip)
 
+// ---- per-stage timing (api.hip): HIP events around the launches of one C-ABI call, when enabled -------------
+int tutel_stage_begin(int stage, hipStream_t st);  // returns a token (-1: timing off)
+void tutel_stage_end(int token, hipStream_t st);
+void tutel_stage_hint(int stage);                  // the next launches of this thread belong to `stage` (-1: clear)
+struct StageScope {
+  int token;
+  hipStream_t st;
+  StageScope(int stage, hipStream_t s) : token(tutel_stage_begin(stage, s)), st(s) {}
+  ~StageScope() { tutel_stage_end(token, st); }
+};
+
 #define TUTEL_REQUIRE(cond, ...)           \
   do {                                     \
     if (!(cond)) {                         \

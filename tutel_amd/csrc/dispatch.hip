@@ -265,6 +265,7 @@ extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *sl
   TUTEL_REQUIRE(slot_map && out && (x || T == 0), "tutel_amd_fast_encode: null pointer");
   TUTEL_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_amd_fast_encode: x/out must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  StageScope stage(TUTEL_STAGE_ENCODE, st);
   int grid = dp_grid(n_slots);
   int Tn = T > 0 ? T : 1;
   if (dtype == TUTEL_F32)
@@ -308,6 +309,7 @@ extern "C" int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *
   TUTEL_REQUIRE(idx && loc && out && (buf || capacity == 0), "tutel_amd_fast_decode: null pointer");
   TUTEL_REQUIRE(((uintptr_t)buf % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_amd_fast_decode: buf/out must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  StageScope stage(TUTEL_STAGE_DECODE, st);
   if (dtype == TUTEL_F32) launch_decode<float>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
   else if (dtype == TUTEL_BF16) launch_decode<bf16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
   else launch_decode<f16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
@@ -324,6 +326,7 @@ extern "C" int tutel_amd_gate_grad(const void *x, const void *buf, int dtype, co
   TUTEL_REQUIRE(x && idx && loc && ggate && (buf || capacity == 0), "tutel_amd_gate_grad: null pointer");
   TUTEL_REQUIRE(((uintptr_t)buf % 16) == 0 && ((uintptr_t)x % 16) == 0, "tutel_amd_gate_grad: x/buf must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  StageScope stage(TUTEL_STAGE_OTHER, st);
   int grid = dp_grid(k * T);
   if (dtype == TUTEL_F32)
     hipLaunchKernelGGL(gate_grad_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)x, (const float *)buf, idx, loc, T, M, k, capacity, ggate);
@@ -334,3 +337,4 @@ extern "C" int tutel_amd_gate_grad(const void *x, const void *buf, int dtype, co
   TUTEL_CHECK_LAUNCH("tutel_amd_gate_grad");
   return 0;
 }
+

@@ -171,8 +171,10 @@ extern "C" int tutel_amd_ep_comm_info(const tutel_amd_ep_comm_t *c, int *world, 
 
 // equal-split all-to-all of `bytes_per_peer` bytes per rank pair on `stream` (all_to_all_single semantics,
 // communicate.py:181-192): block r of `send` goes to rank r and lands as block (my rank) of its `recv`
-static int exchange(tutel_amd_ep_comm *c, const void *send, void *recv, size_t bytes_per_peer, int world, hipStream_t st) {
+static int exchange(tutel_amd_ep_comm *c, const void *send, void *recv, size_t bytes_per_peer, int world, hipStream_t st,
+                    int stage = TUTEL_STAGE_OTHER) {
   if (bytes_per_peer == 0) return 0;
+  StageScope scope(stage, st);
   if (c == nullptr) {  // single rank without a communicator: the exchange is a copy
     HIP_CHECK(hipMemcpyAsync(recv, send, bytes_per_peer * (size_t)world, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
     return 0;
@@ -224,6 +226,9 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
   const void *enc_gates = a->is_postscore ? nullptr : a->gates;  // fast_dispatch.py:125,131: gates on one side only
   const void *dec_gates = a->is_postscore ? a->gates : nullptr;
   TUTEL_REQUIRE(a->gates != nullptr, "tutel_amd_ep_forward: null gates");
+  TUTEL_REQUIRE(a->row_counts == nullptr || (W == 1 && c == nullptr && a->degree <= 1), "tutel_amd_ep_forward: row counts (megablocks) need a single rank");
+  const int32_t *rcnt = a->row_counts;
+  const int ralign = a->row_counts != nullptr && a->row_align >= 1 ? a->row_align : 1;
 
   if (C == 0) {  // nothing is dispatched: every token's output is the zero vector
     HIP_CHECK(hipMemsetAsync(a->y, 0, (size_t)T * Mo * es, cur), "hipMemsetAsync");
@@ -237,13 +242,13 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     {
       Range r("tutel_amd.expert_fc1");
       rc = tutel_amd_expert_gemm_gather(a->x, M, a->slot_map, T, a->zero_row, a->w1, 1, (int64_t)H * M, M, a->b1, H, a->hid,
-                                        (int64_t)C * H, H, E_loc, C, H, M, a->dtype, a->act, nullptr, 1, cur);
+                                        (int64_t)C * H, H, E_loc, C, H, M, a->dtype, a->act, rcnt, ralign, cur);
       if (rc) return rc;
     }
     {
       Range r("tutel_amd.expert_fc2");
       rc = tutel_amd_expert_gemm(a->hid, (int64_t)C * H, 0, C, H, a->w2, a->w2_kmajor, (int64_t)H * Mo, a->w2_kmajor ? H : Mo, a->b2,
-                                 Mo, a->send, (int64_t)C * Mo, 0, C, Mo, E_loc, C, Mo, H, a->dtype, TUTEL_ACT_NONE, nullptr, 1, cur);
+                                 Mo, a->send, (int64_t)C * Mo, 0, C, Mo, E_loc, C, Mo, H, a->dtype, TUTEL_ACT_NONE, rcnt, ralign, cur);
       if (rc) return rc;
     }
     Range r("tutel_amd.fast_decode");
@@ -251,6 +256,7 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
   }
 
   TUTEL_REQUIRE(a->enc && a->recv && a->hid && a->send && a->back, "tutel_amd_ep_forward: null workspace");
+  TUTEL_REQUIRE(rcnt == nullptr, "tutel_amd_ep_forward: row counts need the fused-encode single-rank route (is_postscore, fuse_encode)");
   const int degree = a->degree < 1 ? 1 : a->degree;
   tutel_amd_ep_plan_t pl;
   if (tutel_amd_ep_plan(E, W, C, degree, a->allow_sliced, &pl) != 0) return -1;
@@ -276,8 +282,10 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     int r1;
     {
       Range r("tutel_amd.expert_fc1");
+      tutel_stage_hint(TUTEL_STAGE_FC1);
       r1 = tutel_amd_expert_gemm(recv_i, (int64_t)cc * M, (int64_t)rows * M, cc, M, w1, 1, (int64_t)H * M, M, b1, H, hid_i,
                                  (int64_t)R * H, 0, R, H, s, R, H, M, a->dtype, a->act, nullptr, 1, st);
+      tutel_stage_hint(-1);
       if (r1) return r1;
     }
     Range r("tutel_amd.expert_fc2");
@@ -290,13 +298,13 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     for (int i = 0; i < degree; ++i) {
       {
         Range r("tutel_amd.all_to_all");
-        rc = exchange(c, (const char *)a->enc + (size_t)i * msg_in, (char *)a->recv + (size_t)i * msg_in, (size_t)rows * M * es, W, cur);
+        rc = exchange(c, (const char *)a->enc + (size_t)i * msg_in, (char *)a->recv + (size_t)i * msg_in, (size_t)rows * M * es, W, cur, TUTEL_STAGE_A2A_DISPATCH);
         if (rc) return rc;
       }
       rc = stage_gemms(i, cur);
       if (rc) return rc;
       Range r("tutel_amd.all_to_all");
-      rc = exchange(c, (const char *)a->send + (size_t)i * msg_out, (char *)a->back + (size_t)i * msg_out, (size_t)rows * Mo * es, W, cur);
+      rc = exchange(c, (const char *)a->send + (size_t)i * msg_out, (char *)a->back + (size_t)i * msg_out, (size_t)rows * Mo * es, W, cur, TUTEL_STAGE_A2A_COMBINE);
       if (rc) return rc;
     }
   } else {
@@ -309,7 +317,7 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     {
       Range r("tutel_amd.all_to_all(dispatch)");
       for (int i = 0; i < degree; ++i) {
-        rc = exchange(c, (const char *)a->enc + (size_t)i * msg_in, (char *)a->recv + (size_t)i * msg_in, (size_t)rows * M * es, W, cur);
+        rc = exchange(c, (const char *)a->enc + (size_t)i * msg_in, (char *)a->recv + (size_t)i * msg_in, (size_t)rows * M * es, W, cur, TUTEL_STAGE_A2A_DISPATCH);
         if (rc) return rc;
         HIP_CHECK(hipEventRecord(c->recv_ev[i], cur), "hipEventRecord");
       }
@@ -321,7 +329,7 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
       HIP_CHECK(hipEventRecord(c->done_ev[i], ks), "hipEventRecord");
       HIP_CHECK(hipStreamWaitEvent(cur, c->done_ev[i], 0), "hipStreamWaitEvent");  // last wait: the side stream is joined back
       Range r("tutel_amd.all_to_all(combine)");
-      rc = exchange(c, (const char *)a->send + (size_t)i * msg_out, (char *)a->back + (size_t)i * msg_out, (size_t)rows * Mo * es, W, cur);
+      rc = exchange(c, (const char *)a->send + (size_t)i * msg_out, (char *)a->back + (size_t)i * msg_out, (size_t)rows * Mo * es, W, cur, TUTEL_STAGE_A2A_COMBINE);
       if (rc) return rc;
     }
   }

@@ -1380,6 +1380,9 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   TUTEL_REQUIRE(grid_ll < 0x7fffffffLL, "tutel_amd_expert_gemm: grid too large");
   const int grid = (int)grid_ll;
   hipStream_t st = (hipStream_t)stream;
+  // per-stage timing: the launch with a fused activation is fc1, the one without is fc2 (callers that know better --
+  // the native pipeline -- set a hint)
+  StageScope stage(act != TUTEL_ACT_NONE ? TUTEL_STAGE_FC1 : TUTEL_STAGE_FC2, st);
   if (dtype == TUTEL_BF16)
     return w_kmajor ? launch_gemm_act<bf16_t, true>(a, act, grid, st) : launch_gemm_act<bf16_t, false>(a, act, grid, st);
   return w_kmajor ? launch_gemm_act<f16_t, true>(a, act, grid, st) : launch_gemm_act<f16_t, false>(a, act, grid, st);

@@ -607,6 +607,7 @@ extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax,
   TUTEL_REQUIRE(clear_n >= 0 && (clear_map != nullptr || clear_n == 0), "tutel_amd_gate_topk: bad clear_map");
   if (clear_n == 0) clear_map = nullptr;
   hipStream_t st = (hipStream_t)stream;
+  StageScope stage(TUTEL_STAGE_GATE_TOPK, st);
   if (dtype == TUTEL_F64) return launch_gate_topk<double>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
@@ -638,6 +639,7 @@ extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int 
   const int tile = rt_tile(T), nt = rt_ntiles(T);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
+  StageScope stage(TUTEL_STAGE_LOCATION, st);
   if (!hist_ready) {
     hipLaunchKernelGGL(tile_hist_kernel, dim3(nt), dim3(RT_THREADS), (size_t)k * E * 4, st, idx, T, E, k, tile, ws_hist);
     TUTEL_CHECK_LAUNCH("tutel_amd_compute_location(hist)");
@@ -664,6 +666,7 @@ extern "C" int tutel_amd_slot_map(const int32_t *idx, const int32_t *loc, int T,
   hipStream_t st = (hipStream_t)stream;
   if (capacity == 0) return 0;
   TUTEL_REQUIRE(slot_map != nullptr, "tutel_amd_slot_map: null slot_map");
+  StageScope stage(TUTEL_STAGE_OTHER, st);
   hipError_t e = hipMemsetAsync(slot_map, 0xFF, (size_t)E * capacity * 4, st);
   TUTEL_REQUIRE(e == hipSuccess, "tutel_amd_slot_map: memset failed: %s", hipGetErrorString(e));
   int n = k * T;

@@ -121,9 +121,11 @@ def plan(E, W, capacity, degree, allow_sliced=True):
 
 def usable(layer, x, crit, degree):
     """Can this forward run through tutel_amd_ep_forward?  (Everything else takes the Python-orchestrated paths.)"""
-    if not ENABLED or getattr(layer, "megablocks_size", 0) > 0 or crit.gates2d is None or crit[4] <= 0:
+    if not ENABLED or crit.gates2d is None or crit[4] <= 0:
         return False
     W = layer.world_size
+    if getattr(layer, "megablocks_size", 0) > 0 and (W > 1 or not layer.is_postscore):
+        return False  # row counts ride on the single-rank fused-encode route only
     if W > 1:
         if not dist.is_initialized() or dist.get_backend(layer.group) != "nccl":
             return False  # gloo rendezvous (ranks sharing a GPU in the tests): host-staged exchange in impls/overlap.py
@@ -172,6 +174,8 @@ def forward(layer, x, crit, degree):
     comm = communicator(layer.group, x.device) if with_comm else None
     if with_comm and comm is None:
         return None
+    if getattr(layer, "megablocks_size", 0) > 0 and with_comm:
+        return None
     if not with_comm:
         degree = 1  # a single rank has nothing to overlap (the reference returns expert_fn(input) there, overlap.py:16-17)
     key = (tuple(x.shape), x.dtype, x.device, crit[0], crit[4], crit.idx2d.shape[0], degree, bool(layer.is_postscore),
@@ -198,6 +202,11 @@ def forward(layer, x, crit, degree):
     a.b1 = b1.data_ptr() if b1 is not None else None
     a.b2 = b2.data_ptr() if b2 is not None else None
     a.y = y.data_ptr()
+    mega = int(getattr(layer, "megablocks_size", 0))
+    if mega > 0 and not with_comm:
+        a.row_counts, a.row_align = layer.dispatch_count.data_ptr(), mega
+    else:
+        a.row_counts, a.row_align = None, 1
     _lib.check(_lib.lib().tutel_amd_ep_forward(comm.handle if comm is not None else None, ctypes.byref(a), ops._stream()),
                "tutel_amd_ep_forward")
     layer.protected_shape = torch.Size([layer.num_local_experts, W * crit[4], ex.output_dim])

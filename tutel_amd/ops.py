@@ -266,3 +266,19 @@ def probe_tr16():
     out = torch.empty([256], dtype=torch.int16, device="cuda")
     _lib.check(_lib.lib().tutel_amd_probe_tr16(_ptr(out), _stream()), "tutel_amd_probe_tr16")
     return out
+
+
+def stage_timing(mode):
+    """0 off; 1 HIP events around every kernel launch of the C ABI from now on; 2 around the two expert GEMMs only
+    (measurement only; see include/tutel_amd.h)."""
+    _lib.check(_lib.lib().tutel_amd_stage_timing(int(mode)), "tutel_amd_stage_timing")
+
+
+def stage_report():
+    """{stage: (total_us, launches)} of the launches recorded since the last report (waits for them)."""
+    import ctypes
+    n = len(_lib.STAGES)
+    tot, cnt = (ctypes.c_double * n)(), (ctypes.c_int * n)()
+    _lib.check(_lib.lib().tutel_amd_stage_report(tot, cnt, n), "tutel_amd_stage_report")
+    return {name: (float(tot[i]), int(cnt[i])) for i, name in enumerate(_lib.STAGES)}
+
