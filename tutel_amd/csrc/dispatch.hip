@@ -149,11 +149,15 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
     T *dst = out + (size_t)t * M;
     if (vec_ok) {
       vec16 *d = reinterpret_cast<vec16 *>(dst);
-      for (int i = lane; i < nvec; i += 64) {
-        vec16 v[KMAX];
+      // UNR vectors per lane per pass: all UNR * k loads are issued before the first use (8 x 16 B in flight per lane at
+      // k = 2; two in flight left the kernel at 4.2 TB/s although its input was just written by fc2)
+      constexpr int UNR = KMAX >= 8 ? 1 : (8 / KMAX);
+      // loads are unconditional (a dropped choice reads bucket row 0 and its value is discarded): a branch around each
+      // load would make hipcc wait for every load separately
+      const T *src[KMAX];
 #pragma unroll
-        for (int j = 0; j < KMAX; ++j)
-          if (rows[j]) v[j] = reinterpret_cast<const vec16 *>(rows[j])[i];
+      for (int j = 0; j < KMAX; ++j) src[j] = rows[j] ? rows[j] : buf;
+      auto combine = [&](const vec16 (&v)[KMAX], vec16 &o) {
         float acc[VN];
 #pragma unroll
         for (int u = 0; u < VN; ++u) acc[u] = 0.f;
@@ -177,8 +181,29 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
             for (int u = 0; u < VN; ++u) acc[u] = add_rn(acc[u], f[u]);
           }
         }
-        vec16 o;
         Vec<T>::pack(acc, o);
+      };
+      int i = lane;
+      for (; i + 64 * (UNR - 1) < nvec; i += 64 * UNR) {
+        vec16 v[UNR][KMAX];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q)
+#pragma unroll
+          for (int j = 0; j < KMAX; ++j)
+            v[q][j] = reinterpret_cast<const vec16 *>(src[j])[i + 64 * q];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+          vec16 o;
+          combine(v[q], o);
+          d[i + 64 * q] = o;
+        }
+      }
+      for (; i < nvec; i += 64) {
+        vec16 v[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) v[j] = reinterpret_cast<const vec16 *>(src[j])[i];
+        vec16 o;
+        combine(v, o);
         d[i] = o;
       }
     } else {
@@ -307,6 +332,11 @@ extern "C" int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *
                 expert_slice, ep_world > 0 ? num_experts / ep_world : 0, ep_world);
   if (T == 0) return 0;
   TUTEL_REQUIRE(idx && loc && out && (buf || capacity == 0), "tutel_amd_fast_decode: null pointer");
+  if (capacity == 0 || buf == nullptr) {  // nothing was dispatched: every token combines to the zero vector
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)T * M * dtype_size(dtype), (hipStream_t)stream);
+    TUTEL_REQUIRE(e == hipSuccess, "tutel_amd_fast_decode: memset failed: %s", hipGetErrorString(e));
+    return 0;
+  }
   TUTEL_REQUIRE(((uintptr_t)buf % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_amd_fast_decode: buf/out must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   StageScope stage(TUTEL_STAGE_DECODE, st);
