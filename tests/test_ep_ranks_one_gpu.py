@@ -198,6 +198,80 @@ def test_overlapped_training_keeps_autograd_graph(frozen_experts):
         assert ok, f"rank {rank}: {info}"
 
 
+def _sharded_worker(rank, world, port, q):
+    """one expert's hidden dim sliced over the ranks (num_local_experts = -world): parallel_type data / model / adaptive:0
+    agree with each other (reference tests/test_tutel.py:154-159) and with the un-sharded oracle, in bf16 on the GPU --
+    where the gathered weights now run on the MFMA grouped GEMM, not on ATen."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import torch.distributed as dist
+        from oracle import moe_oracle as O
+        from tutel import moe, net
+        from tutel_amd import ops
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        T, M, H, k = 512, 128, 256, 1
+        dtype = torch.bfloat16
+        calls = []
+        real = ops.expert_gemm
+        ops.expert_gemm = lambda *a, **kw: calls.append(1) or real(*a, **kw)
+        outs, ok, info = {}, True, ""
+        for ptype in ("data", "model", "adaptive:0"):
+            old = torch.get_default_dtype()
+            torch.set_default_dtype(dtype)
+            layer = moe.moe_layer(gate_type={"type": "top", "k": k, "fp32_gate": True}, model_dim=M,
+                                  experts={"type": "ffn", "num_experts_per_device": -world, "hidden_size_per_expert": H,
+                                           "activation_fn": lambda t: torch.nn.functional.relu(t)},
+                                  parallel_type=ptype, seeds=(1, rank + 1, 1))
+            torch.set_default_dtype(old)
+            layer = layer.cuda().eval()
+            assert layer.num_global_experts == 1 and layer.sharded_count == world
+            torch.manual_seed(0)
+            x = torch.randn(T, M).to(dtype)
+            del calls[:]
+            with torch.no_grad():
+                outs[ptype] = layer(x.cuda()).float().cpu()
+            if not calls:
+                ok, info = False, f"{ptype}: the MFMA grouped GEMM was not used"
+                break
+            gather = lambda t: net.simple_all_gather(t.data[0].cpu() if False else t.data[0]).cpu()
+            w1 = gather(layer.experts.batched_fc1_w).view(1, H, M)
+            w2 = gather(layer.experts.batched_fc2_w).view(1, H, M)
+            b1 = gather(layer.experts.batched_fc1_bias).view(1, H)
+            b2 = gather(layer.experts.batched_fc2_bias).view(1, -1)[:, :M]
+            wg = layer.gates[0].wg.weight.data.cpu()
+            want, _, _, _ = O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k, fp32_gate=True, accum_fp32=True)
+            err = (outs[ptype].double() - want.double()).abs()
+            tol = 2 ** -6 * want.double().abs() + 2 ** -7 * float(want.double().abs().max())   # partial sums of the shards are rounded to bf16 before they are added
+            if not bool((err <= tol).all()):
+                ok, info = False, f"{ptype}: max err {float(err.max()):.3e}"
+                break
+        if ok:
+            d = float((outs["data"] - outs["model"]).abs().max())
+            ok, info = d <= 2 ** -6 * float(outs["data"].abs().max()), f"data vs model: {d:.3e}"
+        q.put((rank, bool(ok), info, []))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc(), []))
+
+
+def test_sharded_expert_modes_two_ranks_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, info, _ in res:
+        assert ok, f"rank {rank}: {info}"
+
+
 def test_bench_script_multi_rank_code_path():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the
     single-GPU test hook: the N > 1 branch of the script (sharded experts, overlap degree 2, max-over-ranks

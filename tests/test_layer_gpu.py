@@ -284,6 +284,41 @@ def test_overlapped_path_equals_plain_path(oracle, monkeypatch, degree, E, post)
     assert layer.protected_shape[1] % degree == 0
 
 
+@pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
+def test_autocast_runs_the_mfma_gemm_vs_oracle(oracle, monkeypatch, amp_dtype):
+    """torch.autocast over an fp32 layer (the reference's AMP recipe, examples/helloworld_amp.py:76-79): tokens travel in
+    the autocast dtype (moe_layer.py:26-39,265-266) and the expert GEMMs run on the MFMA kernel with cached low-precision
+    casts of the fp32 master weights (ATen autocasts matmul the same way) -- checked against the oracle on weights
+    rounded to that dtype, and the casts follow weight updates."""
+    from tutel_amd import ops
+    T, M, H, E, k = 1024, 256, 512, 8, 2
+    x, wg, w1, b1, w2, b2 = oracle.make_problem(T, M, H, E, dtype=torch.float32, seed=31)
+    layer = make_layer(M, H, E, k, 1.0, torch.float32, (wg, w1, b1, w2, b2), gate={"fp32_gate": True}).eval()
+    calls = []
+    real = ops.expert_gemm
+    monkeypatch.setattr(ops, "expert_gemm", lambda *a, **kw: calls.append(a[0].dtype) or real(*a, **kw))
+    xd = x.cuda()
+    with torch.no_grad(), torch.autocast("cuda", dtype=amp_dtype):
+        y = layer(xd)
+    assert y.dtype == torch.float32 and calls == [amp_dtype, amp_dtype], calls
+    lp = lambda t: t.to(amp_dtype)
+    yo, lo, crit, _ = oracle.moe_forward(lp(x), wg, lp(w1), lp(b1), lp(w2), lp(b2), top_k=k, fp32_gate=True, accum_fp32=True)
+    assert torch.equal(layer.dispatch_count.cpu(), crit[5])
+    _close(y, yo.float(), amp_dtype)
+    with torch.no_grad():
+        layer.experts.batched_fc2_w.mul_(2.0)       # in-place update bumps the version counter: the cached cast must follow
+        layer.experts.batched_fc2_bias.mul_(2.0)
+        with torch.autocast("cuda", dtype=amp_dtype):
+            y2 = layer(xd)
+    _close(y2, 2 * yo.float(), amp_dtype)
+    # grad enabled + trainable experts: autograd is needed, so the ATen path (as the reference) -- and it still works
+    del calls[:]
+    layer.train()
+    with torch.autocast("cuda", dtype=amp_dtype):
+        y3 = layer(xd)
+    assert y3.requires_grad and calls == []
+
+
 def test_native_pipeline_equals_python_orchestration(oracle, monkeypatch):
     """tutel_amd_ep_forward (one native call for encode .. decode) returns the bits of the Python-orchestrated
     paths it replaces: single rank (fused-encode route), with pre-score gates (encode route), fp16."""
@@ -404,6 +439,8 @@ print("RCCL_OVERLAP_OK")
     "--dtype=float32 --batch_size=4 --num_tokens=512 --hidden_size=128 --num_local_experts=2 --top=1 --num_steps=5",                # configs[0] flags, on the GPU (training)
     "--eval --dtype=float16 --batch_size=8 --num_tokens=512 --model_dim=1024 --hidden_size=1024 --num_local_experts=16 --fp32_gate --a2a_ffn_overlap_degree=2 --num_steps=12",
     "--eval --dtype=bfloat16 --batch_size=8 --num_tokens=256 --model_dim=512 --hidden_size=1024 --num_local_experts=8 --expert_type=llama_ffn --use_tensorcore --num_steps=12",
+    "--switch --eval --dtype=float16 --batch_size=8 --num_tokens=512 --model_dim=1024 --hidden_size=1024 --num_local_experts=16 --use_2dh --cap_factor=1.0 --num_steps=16",   # configs[4]'s sweep driver (helloworld_switch.py)
+    "--amp --eval --dtype=float32 --batch_size=8 --num_tokens=256 --model_dim=512 --hidden_size=512 --num_local_experts=8 --num_steps=12",                                    # helloworld_amp.py
 ])
 def test_helloworld_driver(flags):
     """The reference's benchmark/driver script surface (examples/helloworld.py flags)."""
@@ -417,7 +454,9 @@ def test_helloworld_driver(flags):
     assert r.returncode == 0 and "[Summary] Average synchronized step_time" in out, out[-3000:]
     losses = [float(l.split("loss = ")[1].split(",")[0]) for l in out.splitlines() if l.startswith("STEP-")]
     assert len(losses) >= 5 and all(l == l for l in losses)
-    if "--eval" in flags:
+    if "--switch" in flags:  # the overlap degree enters the capacity alignment (moe_layer.py:298-301): losses move in the last digits
+        assert max(losses) - min(losses) <= 0.02 * abs(losses[0]) and out.count("(f = 1.0, r = ") == len(losses)
+    elif "--eval" in flags:
         assert len(set(losses)) == 1, "eval steps are deterministic"
     else:
         assert losses[-1] < losses[0], "SGD on the MoE layer must reduce the loss"

@@ -18,7 +18,7 @@ from tutel import moe as tutel_moe
 from tutel import net, system
 
 
-def main():
+def main(argv=None, switch=False, amp=False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--local_rank", type=int, default=-1)
     ap.add_argument("--batch_size", type=int, default=16)
@@ -42,7 +42,13 @@ def main():
     ap.add_argument("--checkpoint_path", type=str, default="")
     ap.add_argument("--use_tensorcore", default=False, action="store_true")  # accepted for CLI compatibility: no TF32 on gfx950
     ap.add_argument("--expert_type", type=str, default="ffn")
-    args = ap.parse_args()
+    ap.add_argument("--cap_factor", type=float, default=None, help="helloworld_switch.py's name for --capacity_factor")
+    ap.add_argument("--switch", default=switch, action="store_true",
+                    help="helloworld_switch.py: every step takes the next (adaptive_r, a2a_ffn_overlap_degree) of valid_rs x 1..8")
+    ap.add_argument("--amp", default=amp, action="store_true", help="helloworld_amp.py: forward under torch.autocast")
+    args = ap.parse_args(argv)
+    if args.cap_factor is not None:
+        args.capacity_factor = args.cap_factor
 
     env = system.init_data_model_parallel(backend="nccl" if args.device == "cuda" else "gloo")
     rank, world, dprint, device = env.global_rank, env.global_size, env.dist_print, env.local_device
@@ -65,9 +71,26 @@ def main():
         else:
             print("Checkpoint not loaded: file `%s` is not found. Will train the model from start." % checkpoint_path)
 
+    state = {"r_index": -1}
+
     def model(inp):
-        out = layer(inp, megablocks_size=args.megablocks_size) if args.megablocks_size > 0 else layer(inp)
+        if args.switch:  # the sweep of the reference's helloworld_switch.py:84-88: r over valid_rs, overlap degree 1..8
+            rs = layer.valid_rs
+            r, o = rs[(state["r_index"] // 8) % len(rs)], state["r_index"] % 8 + 1
+            state["r_index"] += 1
+            out = layer(inp, capacity_factor=args.capacity_factor, adaptive_r=r, a2a_ffn_overlap_degree=o)
+        elif args.megablocks_size > 0:
+            out = layer(inp, megablocks_size=args.megablocks_size)
+        else:
+            out = layer(inp)
         return F.log_softmax(torch.sum(out, dim=2), dim=1)
+
+    if args.amp:  # helloworld_amp.py:76-79: the whole forward under autocast (fp32 master weights)
+        plain_model = model
+
+        def model(inp):  # noqa: F811
+            with torch.autocast(device.type if device is not None else "cuda"):
+                return plain_model(inp)
 
     opt = torch.optim.SGD(layer.parameters(), lr=1e-5)
     torch.manual_seed(0)
@@ -97,7 +120,11 @@ def main():
         t1 = system.record_time()
         E = tutel_moe.moe_layer.global_expert_count(args.num_local_experts, group=system.get_local_session().model_group)
         tflops = (args.batch_size * args.num_tokens * args.model_dim * args.hidden_size) * 4 * (1 if args.eval else 3) * min(args.top, E) * 1e-12 / (t1 - t0)
-        dprint("STEP-%s: loss = %.5f, step_time = %.6f sec, perf = %.2f tflops." % (i, float(loss.data), t1 - t0, tflops))
+        if args.switch:
+            dprint("STEP-%s: loss = %.5f, step_time = %.6f sec, perf = %.2f tflops. (f = %.1f, r = %d, o = %d)"
+                   % (i, float(loss.data), t1 - t0, tflops, args.capacity_factor, layer.adaptive_degree, layer.a2a_ffn_overlap_degree))
+        else:
+            dprint("STEP-%s: loss = %.5f, step_time = %.6f sec, perf = %.2f tflops." % (i, float(loss.data), t1 - t0, tflops))
         if i + 10 >= args.num_steps:
             avg += t1 - t0
     dprint("\n[Summary] Average synchronized step_time = %s sec." % (avg / 10))

@@ -39,15 +39,21 @@ class KMajorCache:
     def __init__(self):
         self._store = {}
 
-    def get(self, name, w):
+    def get(self, name, w, transpose=True, dtype=None):
+        """cached derived copy of parameter `w`: transposed to k-major ([E, K, N] -> [E, N, K]) and / or cast to `dtype`
+        (autocast: fp32 master weights, low-precision compute copies)"""
         try:
             version = w._version
         except RuntimeError:  # inference tensors (module built under torch.inference_mode()) carry no version counter
             version = -1
-        key = (w.data_ptr(), version, w.dtype, w.device, tuple(w.shape))
+        key = (w.data_ptr(), version, w.dtype, w.device, tuple(w.shape), bool(transpose), dtype)
         hit = self._store.get(name)
         if hit is None or hit[0] != key:
-            hit = (key, w.detach().transpose(1, 2).contiguous())
+            t = w.detach()
+            if dtype is not None and t.dtype != dtype:
+                t = t.to(dtype)
+            t = t.transpose(1, 2).contiguous() if transpose else t.contiguous()
+            hit = (key, t)
             self._store[name] = hit
         return hit[1]
 
@@ -194,17 +200,48 @@ class FusedExpertsNetwork(torch.nn.Module):
             self._act_cache[key] = classify_activation(self.activation_fn, key[1])
         return self._act_cache[key]
 
+    def _no_autograd(self, x):
+        return not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+
+    def compute_dtype(self, x):
+        """dtype the MFMA GEMMs would run in for input x, or None.  Same dtype as the weights; or, under autocast,
+        low-precision x against fp32 master weights -- ATen's matmul autocasts those (the reference relies on it,
+        moe_layer.py:26-39,265-266, examples/helloworld_amp.py:76-79), the grouped GEMM uses cached casts instead."""
+        w = self.batched_fc1_w
+        if x.dtype not in (torch.bfloat16, torch.float16):
+            return None
+        if w.dtype == x.dtype:
+            return x.dtype
+        if torch.is_autocast_enabled() and w.dtype == torch.float32 and x.dtype == torch.get_autocast_dtype(x.device.type):
+            return x.dtype
+        return None
+
     def can_fuse(self, x, ctx):
-        if self.skip_expert or not x.is_cuda or torch.is_grad_enabled() and (
-                x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        """the plain fused route: this rank's own local experts (no weight gathering), no autograd, MFMA-able shapes"""
+        if self.skip_expert or not x.is_cuda or not self._no_autograd(x):
             return False
         if getattr(ctx, "adaptive_degree", 1) == 0 or getattr(ctx, "sharded_count", 1) > 1:
             return False
         w1, w2 = self.batched_fc1_w, self.batched_fc2_w
-        if x.dtype != w1.dtype or torch.is_autocast_enabled():
-            return False
-        return (ops.gemm_supported(w1.dtype, w1.size(1), w1.size(2)) and
-                ops.gemm_supported(w2.dtype, w2.size(2), w2.size(1)) and self.fused_activation() is not None)
+        dt = self.compute_dtype(x)
+        return (dt is not None and ops.gemm_supported(dt, w1.size(1), w1.size(2)) and
+                ops.gemm_supported(dt, w2.size(2), w2.size(1)) and self.fused_activation() is not None)
+
+    def fused_params(self, dtype):
+        """(w1, b1, w2, b2, w2_kmajor) of this rank's experts in the GEMM's compute dtype: the parameters themselves, or
+        cached casts under autocast; fc2 as a k-major copy in eval mode."""
+        w1, b1, w2, b2 = self.batched_fc1_w, self.batched_fc1_bias, self.batched_fc2_w, self.batched_fc2_bias
+        cast = None if w1.dtype == dtype else dtype
+        kmajor = self.w2_kmajor_now()
+        if cast is not None:
+            w1 = self._kmajor.get("fc1.cast", w1, transpose=False, dtype=cast)
+            b1 = self._kmajor.get("b1.cast", b1, transpose=False, dtype=cast) if b1 is not None else None
+        if kmajor or cast is not None:
+            w2 = self._kmajor.get("fc2", w2, transpose=kmajor, dtype=cast)
+        if b2 is not None:
+            if b2.size(-1) != self.output_dim or cast is not None:
+                b2 = self._kmajor.get("b2.cast", b2[:, :self.output_dim], transpose=False, dtype=cast)
+        return w1, b1, w2, b2, kmajor
 
     def forward_fused(self, x, ctx, a_layout=None, R=None, out=None, d_layout=None, slot_map=None, expert_range=None):
         """x [E_loc,R,M] (or the raw all-to-all buffer described by a_layout) -> [E_loc,R,M_out]
@@ -215,12 +252,7 @@ class FusedExpertsNetwork(torch.nn.Module):
         counts, align = None, 1
         if getattr(ctx, "megablocks_size", 0) > 0:
             counts, align = ctx.dispatch_count, int(ctx.megablocks_size)
-        w1, b1, w2, b2 = self.batched_fc1_w, self.batched_fc1_bias, self.batched_fc2_w, self.batched_fc2_bias
-        w2_kmajor = self.w2_kmajor_now()
-        if w2_kmajor:
-            w2 = self._kmajor.get("fc2", w2)
-        if b2 is not None and b2.size(-1) != self.output_dim:
-            b2 = b2[:, :self.output_dim].contiguous()
+        w1, b1, w2, b2, w2_kmajor = self.fused_params(self.compute_dtype(x))
         if expert_range is not None:
             lo, hi = expert_range
             w1, w2 = w1[lo:hi], w2[lo:hi]
@@ -255,7 +287,7 @@ class FusedExpertsNetwork(torch.nn.Module):
         self._kmajor.invalidate()
         return super()._load_from_state_dict(*args, **kwargs)
 
-    # -- reference-equivalent ATen path -----------------------------------------------------
+    # -- gathered-weight modes + the reference-equivalent ATen path ------------------------------
     def forward(self, x, ctx):
         if self.skip_expert:
             return x
@@ -292,6 +324,19 @@ class FusedExpertsNetwork(torch.nn.Module):
                     b2 = b2 * (1.0 / ctx.adaptive_degree)
         if b2 is not None and b2.size(-1) != self.output_dim:
             b2 = b2[:, :, :self.output_dim]
+
+        # the gathered / sliced weights on the MFMA grouped GEMM as well (adaptive_r = 0 and sharded experts used to leave
+        # the hand-written path): weights as they come out of the gather -- fc2 in its [E, H', M_out] checkpoint layout
+        dt = self.compute_dtype(x)
+        if (dt is not None and x.is_cuda and self._no_autograd(x) and self.fused_activation() is not None and x.dim() == 3
+                and x.size(0) == w1.size(0) and ops.gemm_supported(dt, w1.size(1), w1.size(2))
+                and ops.gemm_supported(dt, w2.size(2), w2.size(1))):
+            def prep(t):
+                return None if t is None else t.detach().to(dt).contiguous()
+            b1f = prep(b1.squeeze(1)) if b1 is not None else None
+            b2f = prep(b2.squeeze(1)) if b2 is not None else None
+            h = ops.expert_gemm(x.contiguous(), prep(w1), b1f, True, act=self.fused_activation())
+            return ops.expert_gemm(h, prep(w2), b2f, False)
 
         y = torch.matmul(x, w1.permute(0, 2, 1))
         if b1 is not None:

@@ -187,12 +187,7 @@ def forward(layer, x, crit, degree):
             cache.clear()
         ws = cache[key] = _Workspace(layer, x, crit, degree, comm)
     a = ws.args
-    w1, b1, w2, b2 = ex.batched_fc1_w, ex.batched_fc1_bias, ex.batched_fc2_w, ex.batched_fc2_bias
-    kmajor = ex.w2_kmajor_now()
-    if kmajor:
-        w2 = ex._kmajor.get("fc2", w2)
-    if b2 is not None and b2.size(-1) != ex.output_dim:
-        b2 = b2[:, :ex.output_dim].contiguous()
+    w1, b1, w2, b2, kmajor = ex.fused_params(x.dtype)
     gates = crit.gates2d
     y = torch.empty([x.shape[0], ex.output_dim], dtype=x.dtype, device=x.device)
     a.w2_kmajor = int(kmajor)
