@@ -37,6 +37,40 @@ extern "C" int tutel_amd_set_option(int key, int value) {
   return 0;
 }
 
+// ---- stage markers: roctx ranges (rocprofv3 --marker-trace); no-ops when libroctx64 is not in the process ----------------
+#include <dlfcn.h>
+static thread_local int g_stage_hint = -1;  // set by callers that know which stage their next launches belong to
+static int (*g_roctx_push)(const char *) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static void roctx_init() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_NOLOAD);
+  if (h == nullptr) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_NOLOAD);
+  if (h == nullptr && getenv("TUTEL_AMD_ROCTX") != nullptr) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+  if (h == nullptr) return;
+  g_roctx_push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+  g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+  if (g_roctx_push == nullptr || g_roctx_pop == nullptr) g_roctx_push = nullptr;
+}
+extern "C" int tutel_amd_range_push(const char *name) {
+  roctx_init();
+  return g_roctx_push ? g_roctx_push(name) : 0;
+}
+extern "C" int tutel_amd_range_pop(void) { return g_roctx_push ? g_roctx_pop() : 0; }
+static const char *const g_stage_names[TUTEL_STAGE_COUNT] = {
+    "tutel_amd.gate_topk", "tutel_amd.compute_location", "tutel_amd.fast_encode", "tutel_amd.expert_fc1", "tutel_amd.expert_fc2",
+    "tutel_amd.fast_decode", "tutel_amd.all_to_all_dispatch", "tutel_amd.all_to_all_combine", "tutel_amd.other"};
+void tutel_stage_range_push(int stage) {
+  roctx_init();
+  if (g_stage_hint >= 0) stage = g_stage_hint;
+  if (g_roctx_push) g_roctx_push(g_stage_names[stage >= 0 && stage < TUTEL_STAGE_COUNT ? stage : TUTEL_STAGE_OTHER]);
+}
+void tutel_stage_range_pop() {
+  if (g_roctx_push) g_roctx_pop();
+}
+
 // ---- per-stage timing (measurement only) -------------------------------------------------------------------
 // When enabled, every C-ABI entry point that launches a kernel brackets its launch with a pair of HIP events on
 // the launch stream (timing events; ~2 us of host time each, nothing on the device between kernels of one stream).
@@ -47,7 +81,6 @@ struct StageRec { hipEvent_t a, b; int stage; };
 static std::vector<StageRec> g_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free;
 static int g_timing = 0;
-static thread_local int g_stage_hint = -1;
 
 void tutel_stage_hint(int stage) { g_stage_hint = stage; }
 

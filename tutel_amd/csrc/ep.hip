@@ -80,35 +80,12 @@ extern "C" int tutel_amd_ep_load_rccl(const char *path) {
     }                                                                                   \
   } while (0)
 
-// ---- stage markers (rocprofv3 --marker-trace shows them; no-ops when libroctx64 is not in the process) ----
-static int (*g_roctx_push)(const char *) = nullptr;
-static int (*g_roctx_pop)() = nullptr;
-static void roctx_init() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-  void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_NOLOAD);
-  if (h == nullptr) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_NOLOAD);
-  if (h == nullptr && getenv("TUTEL_AMD_ROCTX") != nullptr) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
-  if (h == nullptr) return;
-  g_roctx_push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
-  g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
-  if (g_roctx_push == nullptr || g_roctx_pop == nullptr) g_roctx_push = nullptr;
-}
+// stage markers: every C-ABI entry point opens a roctx range named after its stage (StageScope, api.hip), so the
+// calls below show up as tutel_amd.fast_encode / all_to_all_* / expert_fc1 / expert_fc2 / fast_decode in a marker trace
 struct Range {
-  explicit Range(const char *name) {
-    roctx_init();
-    if (g_roctx_push) g_roctx_push(name);
-  }
-  ~Range() {
-    if (g_roctx_push) g_roctx_pop();
-  }
+  explicit Range(const char *name) { tutel_amd_range_push(name); }
+  ~Range() { tutel_amd_range_pop(); }
 };
-extern "C" int tutel_amd_range_push(const char *name) {
-  roctx_init();
-  return g_roctx_push ? g_roctx_push(name) : 0;
-}
-extern "C" int tutel_amd_range_pop(void) { return g_roctx_push ? g_roctx_pop() : 0; }
 
 // ---- communicator: RCCL comm + the communication stream + the event table -------------------------------
 #define EP_MAX_SPLIT 32  // AllToAllStatus.max_num_split of the reference (custom_kernel.cpp:328)

@@ -166,11 +166,11 @@ template <bool NT> __device__ __forceinline__ u32x4 ld16(const uint16_t *p) {
   return *reinterpret_cast<const u32x4 *>(p);
 }
 
-// Tile configuration: BK = K-tile depth (64 | 128); NBUF = LDS buffers (2: one barrier per K-tile;
-// 1: two barriers, half the LDS -> more blocks per CU); OCC = blocks per CU the register
-// allocator is asked to allow; NT = non-temporal weight loads.
-template <typename T, bool W_KMAJOR, int ACT, int BK, int NBUF, int OCC, bool NT, bool ROT, bool PF2>
-__global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p) {
+// Register-staged 128 x 128 kernel: K-tile depth 64, double-buffered LDS (one barrier per K-tile), 2 blocks per CU.
+// NT = non-temporal weight loads, ROT = K-tile rotation when the problem asks for it.
+template <typename T, bool W_KMAJOR, int ACT, bool NT, bool ROT>
+__global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_kernel(GemmArgs p) {
+  constexpr int BK = 64, NBUF = 2;
   constexpr int LDK = BK + 8;                                       // padded [rows][k] LDS row (elements)
   constexpr int A_TILE = GM_BM * LDK;                               // elements
   constexpr int W_TILE = W_KMAJOR ? GM_BN * LDK : BK * GM_LDN;      // elements
@@ -277,12 +277,9 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
 
   // Prefetch registers: straight-line unrolled code over fixed-size arrays (no lambdas, no
   // conditionals around the loads -- hipcc otherwise demotes them to scratch / waits vmcnt(0)).
-  // Two register sets = prefetch distance 2: the loads of K-tile kt+2 are issued while tile kt is
-  // multiplied and tile kt+1 (issued one iteration earlier) is written to LDS.  With a single set
-  // every barrier waits for the slowest load of a tile issued only ~one MFMA block earlier (tail
-  // latency under full HBM load): measured 136 us vs the 91 us the same access pattern reaches
-  // with pure loads (tools/wstream_bench.hip).
-  u32x4 ra0[NLA], rw0[NLW], ra1[NLA], rw1[NLW];
+  // One register set: the loads of K-tile kt+1 are issued before tile kt is multiplied and written to
+  // LDS after it (a second set, prefetch distance 2, was measured and did not pay).
+  u32x4 ra0[NLA], rw0[NLW];
 #define GM_GLOAD(RA, RW, KT)                                                           \
   do {                                                                                 \
     int kr_ = (KT); kr_ = kr_ < nk ? kr_ : nk - 1; /* past the end: re-read the last tile */ \
@@ -329,40 +326,17 @@ __global__ __launch_bounds__(GM_THREADS, OCC) void expert_gemm_kernel(GemmArgs p
           acc[ni][mi] = Mma<T>::run(fw[kk][ni], fa[kk][mi], acc[ni][mi]);              \
   } while (0)
 
-  static_assert(NBUF == 2, "the K loop below is written for the double-buffered LDS layout");
   GM_GLOAD(ra0, rw0, 0);
   GM_LSTORE(ra0, rw0, 0);
   __syncthreads();                      // tile 0 in LDS buffer 0
-  if (PF2) GM_GLOAD(ra1, rw1, 1);       // tile 1 in flight in set 1
-
-  if (PF2) {
-    for (int kt = 0; kt < nk; kt += 2) {
-      // even step: buffer 0 holds tile kt, set 1 holds (or is receiving) tile kt+1
-      GM_GLOAD(ra0, rw0, kt + 2);
-      __builtin_amdgcn_sched_barrier(0);  // keep the loads ABOVE the MFMA block (hipcc sinks them)
-      GM_COMPUTE(0);
-      __builtin_amdgcn_sched_barrier(0);
-      GM_LSTORE(ra1, rw1, 1);
-      __syncthreads();
-      if (kt + 1 >= nk) break;            // block-uniform
-      // odd step: buffer 1 holds tile kt+1, set 0 is receiving tile kt+2
-      GM_GLOAD(ra1, rw1, kt + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      GM_COMPUTE(1);
-      __builtin_amdgcn_sched_barrier(0);
-      GM_LSTORE(ra0, rw0, 0);
-      __syncthreads();
-    }
-  } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      GM_GLOAD(ra0, rw0, kt + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      GM_COMPUTE(buf);
-      __builtin_amdgcn_sched_barrier(0);
-      GM_LSTORE(ra0, rw0, buf ^ 1);
-      __syncthreads();
-    }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    GM_GLOAD(ra0, rw0, kt + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads ABOVE the MFMA block (hipcc sinks them)
+    GM_COMPUTE(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    GM_LSTORE(ra0, rw0, buf ^ 1);
+    __syncthreads();
   }
 #undef GM_GLOAD
 #undef GM_LSTORE
@@ -1252,15 +1226,14 @@ extern "C" int tutel_amd_probe_tr16(uint16_t *out, tutel_stream_t stream) {
 // -------------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------------
-template <int BK, int NBUF>
 static constexpr size_t gemm_lds_bytes(bool kmajor) {
-  return (size_t)(NBUF * GM_BM * (BK + 8) + NBUF * (kmajor ? GM_BN * (BK + 8) : BK * GM_LDN)) * 2;
+  return (size_t)(2 * GM_BM * (64 + 8) + 2 * (kmajor ? GM_BN * (64 + 8) : 64 * GM_LDN)) * 2;
 }
 
-template <typename T, bool KM, int ACT, int BK, int NBUF, int OCC, bool NT, bool ROT, bool PF2>
+template <typename T, bool KM, int ACT>
 static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
-  const size_t lds = gemm_lds_bytes<BK, NBUF>(KM);
-  auto kern = expert_gemm_kernel<T, KM, ACT, BK, NBUF, OCC, NT, ROT, PF2>;
+  const size_t lds = gemm_lds_bytes(KM);
+  auto kern = expert_gemm_kernel<T, KM, ACT, true, true>;
   static bool optin = false;  // one flag per instantiation: > 64 KiB of dynamic LDS needs the opt-in
   if (!optin) {
     if (lds > 65536) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1306,7 +1279,7 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   }
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
-  return launch_cfg<T, KM, ACT, 64, 2, 2, true, true, false>(a, grid, st);
+  return launch_cfg<T, KM, ACT>(a, grid, st);
 }
 
 template <typename T, bool KM>

@@ -5,10 +5,16 @@ The capacity dimension is cut into `degree` chunks; chunk i's dispatch all-to-al
 combine all-to-all form a 3-stage pipeline across two HIP streams: RCCL kernels run on a
 dedicated communication stream, the grouped GEMMs on the caller's stream, HIP events hand chunks
 over.  While chunk i is in the FFN, chunk i+1 is on the xGMI links and chunk i-1 is travelling
-back.  Tensors that cross streams are registered with the caching allocator (record_stream), the
-discipline the reference implements with CUDACachingAllocator::recordStream
-(custom_kernel.cpp:536-550,609-618).  Result is identical to the non-overlapped path -- exactly
-what the reference asserts in tests/test_tutel.py:161-176."""
+back.  Stream discipline: the generic routine (a2a_ffn_overlap_forward: custom experts, training fallback)
+registers every tensor that crosses streams with the caching allocator (record_stream), as the reference
+does with CUDACachingAllocator::recordStream (custom_kernel.cpp:536-550,609-618); the copy-free routine
+(a2a_ffn_overlap_fused) allocates its stage buffers once on the caller's stream and keeps them referenced
+until the communication stream has been joined back -- no record_stream bookkeeping.  Result is identical to
+the non-overlapped path -- exactly what the reference asserts in tests/test_tutel.py:161-176.
+
+Production path since round 2: the same pipeline behind ONE native call (impls/ep_native.py ->
+tutel_amd_ep_forward, csrc/ep.hip) on the library's own RCCL communicator; the routines here remain as
+the torch.distributed fallback (gloo rendezvous, custom expert modules, training)."""
 import torch
 import torch.distributed as dist
 
