@@ -283,6 +283,24 @@ typedef struct {
 } tutel_amd_ep_args_t;
 int tutel_amd_ep_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_ep_args_t *args, tutel_stream_t stream);
 
+/* Routing + the pipeline above in ONE call: what MOELayer.forward does after the gate projection (moe_layer.py:290-361)
+ * for the common inference configuration -- softmax + top-k + locations + gshard loss (tutel_amd_gate_topk,
+ * tutel_amd_compute_location with the capacity known up front, capacity_factor > 0) and then tutel_amd_ep_forward on
+ * the routing just computed.  ep.slot_map / idx / loc / gates are OUTPUT buffers here ([E*C], [k,T], [k,T], [k,T] in
+ * the logits dtype); ep.gate_dtype is ignored (= logits_dtype). */
+typedef struct {
+  tutel_amd_ep_args_t ep;
+  const void *logits;        /* [T, num_experts] gate logits */
+  int logits_dtype;          /* TUTEL_F32 | TUTEL_F16 | TUTEL_BF16 */
+  int normalize_gate;
+  void *ws;                  /* tutel_amd_routing_workspace_bytes(T, E, k) bytes */
+  size_t ws_bytes;
+  int32_t *dispatch_count;   /* out [num_experts] */
+  int32_t *stats;            /* out [1] max expert load (may be NULL) */
+  void *l_aux;               /* out [1], logits dtype (NULL to skip the loss) */
+} tutel_amd_moe_args_t;
+int tutel_amd_moe_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_moe_args_t *args, tutel_stream_t stream);
+
 /* stage markers: roctx ranges (rocprofv3 --marker-trace); the pipeline above emits tutel_amd.fast_encode /
  * all_to_all / expert_fc1 / expert_fc2 / fast_decode itself.  No-ops when libroctx64 is not in the process
  * (set TUTEL_AMD_ROCTX=1 to load it).  The reference's only tracing is system.record_time (system.py:73-79). */

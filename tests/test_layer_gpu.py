@@ -334,13 +334,25 @@ def test_native_pipeline_equals_python_orchestration(oracle, monkeypatch):
         with torch.no_grad():
             monkeypatch.setattr(ep_native, "ENABLED", False)
             want = layer(xd).clone()
+            want_aux, want_cnt = float(layer.l_aux), layer.dispatch_count.clone()
             monkeypatch.setattr(ep_native, "ENABLED", True)
+            monkeypatch.setattr(ep_native, "FAST_PATH", False)
             del calls[:]
             for _ in range(3):   # cached workspace: repeated calls must stay correct
                 got = layer(xd)
                 assert torch.equal(got, want)
             assert len(calls) == 3, "the native pipeline must be the path taken"
             assert layer.protected_shape == torch.Size([E, layer.protected_shape[1], M])
+            # routing + pipeline in one call (tutel_amd_moe_forward): same bits, same loss, same counts
+            monkeypatch.setattr(ep_native, "FAST_PATH", True)
+            fcalls = []
+            real_fast = ep_native.forward_from_logits
+            monkeypatch.setattr(ep_native, "forward_from_logits", lambda *a, **kw: fcalls.append(1) or real_fast(*a, **kw))
+            for _ in range(3):
+                got = layer(xd)
+                assert torch.equal(got, want) and float(got.l_aux) == want_aux and torch.equal(layer.dispatch_count, want_cnt)
+            assert len(fcalls) == 3 and len(calls) == 3, "the one-call path must be the path taken"
+            monkeypatch.setattr(ep_native, "forward_from_logits", real_fast)
 
 
 def test_native_pipeline_through_rccl_single_rank():

@@ -57,7 +57,14 @@ class EpArgs(ctypes.Structure):
                 [("row_align", _i), ("y", _vp)])
 
 
+class MoeArgs(ctypes.Structure):
+    """tutel_amd_moe_args_t"""
+    _fields_ = [("ep", EpArgs), ("logits", _vp), ("logits_dtype", _i), ("normalize_gate", _i), ("ws", _vp), ("ws_bytes", _sz),
+                ("dispatch_count", _vp), ("stats", _vp), ("l_aux", _vp)]
+
+
 SIGNATURES.update({
+    "tutel_amd_moe_forward": (_i, [_vp, ctypes.POINTER(MoeArgs), _vp]),
     "tutel_amd_ep_load_rccl": (_i, [ctypes.c_char_p]),
     "tutel_amd_ep_unique_id": (_i, [_vp, _sz]),
     "tutel_amd_ep_comm_create": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(_vp)]),

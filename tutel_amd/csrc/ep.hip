@@ -314,3 +314,23 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
   Range r("tutel_amd.fast_decode");
   return tutel_amd_fast_decode(a->back, a->dtype, a->idx, a->loc, dec_gates, a->gate_dtype, T, Mo, k, C, E, chunk_rows, expert_slice, W, a->y, cur);
 }
+
+// ---- routing + pipeline in one call ------------------------------------------------------------------------------
+extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe_args_t *m, tutel_stream_t stream) {
+  TUTEL_REQUIRE(m != nullptr, "tutel_amd_moe_forward: null arguments");
+  const tutel_amd_ep_args_t &a = m->ep;
+  TUTEL_REQUIRE(m->logits != nullptr && m->ws != nullptr && m->dispatch_count != nullptr, "tutel_amd_moe_forward: null pointer");
+  TUTEL_REQUIRE(a.slot_map && a.idx && a.loc && a.gates, "tutel_amd_moe_forward: null routing buffers");
+  TUTEL_REQUIRE(a.capacity > 0, "tutel_amd_moe_forward: the capacity must be known up front (capacity_factor > 0)");
+  const int T = a.T, E = a.num_experts, k = a.k;
+  if (T == 0) return 0;
+  int rc = tutel_amd_gate_topk(m->logits, m->logits_dtype, 1, T, E, k, m->normalize_gate, nullptr, const_cast<int32_t *>(a.idx),
+                               const_cast<void *>(a.gates), m->ws, m->ws_bytes, const_cast<int32_t *>(a.slot_map), E * a.capacity, stream);
+  if (rc) return rc;
+  rc = tutel_amd_compute_location(a.idx, T, E, k, 1, m->ws, m->ws_bytes, const_cast<int32_t *>(a.loc), m->dispatch_count, m->stats,
+                                  m->l_aux, m->logits_dtype, a.capacity, const_cast<int32_t *>(a.slot_map), 1, stream);
+  if (rc) return rc;
+  tutel_amd_ep_args_t e = a;
+  e.gate_dtype = m->logits_dtype;
+  return tutel_amd_ep_forward(c, &e, stream);
+}

@@ -25,6 +25,7 @@ import torch.distributed as dist
 from .. import _lib, ops
 
 ENABLED = int(os.environ.get("TUTEL_AMD_NATIVE_EP", "1")) != 0
+FAST_PATH = int(os.environ.get("TUTEL_AMD_FAST_PATH", "1")) != 0  # routing + pipeline in one call (tutel_amd_moe_forward)
 _FORCE_COMM = False  # test hook: run a single rank through a real 1-rank RCCL communicator (staged pipeline, both streams)
 _comms = {}      # id(group) / "world" -> EpComm | False (creation failed: do not retry)
 _zero_rows = {}
@@ -206,3 +207,74 @@ def forward(layer, x, crit, degree):
                "tutel_amd_ep_forward")
     layer.protected_shape = torch.Size([layer.num_local_experts, W * crit[4], ex.output_dim])
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# routing + pipeline in one call (tutel_amd_moe_forward)
+# ---------------------------------------------------------------------------------------------
+class _MoeWorkspace(_Workspace):
+    """_Workspace + the routing buffers (idx / loc / gates / slot map / per-tile histograms), all reused call after call"""
+
+    def __init__(self, layer, x, logits, k, capacity, degree, comm):
+        E, T = logits.shape[1], logits.shape[0]
+        dev = x.device
+
+        class _Crit(tuple):   # what _Workspace reads from a RoutingPlan
+            pass
+        crit = _Crit((E, None, None, None, capacity, None))
+        crit.idx2d = torch.empty([k, T], dtype=torch.int32, device=dev)
+        crit.loc2d = torch.empty([k, T], dtype=torch.int32, device=dev)
+        crit.gates2d = torch.empty([k, T], dtype=logits.dtype, device=dev)
+        crit.slot_map = torch.empty([E * capacity], dtype=torch.int32, device=dev)
+        super().__init__(layer, x, crit, degree, comm)
+        self.crit = crit
+        self.ws = ops.routing_workspace(T, E, k, dev)
+        self.stats = torch.empty([1], dtype=torch.int32, device=dev)
+        m = _lib.MoeArgs()
+        m.ep = self.args
+        m.ep.slot_map, m.ep.idx, m.ep.loc, m.ep.gates = (crit.slot_map.data_ptr(), crit.idx2d.data_ptr(), crit.loc2d.data_ptr(),
+                                                          crit.gates2d.data_ptr())
+        m.logits_dtype = ops._DT[logits.dtype]
+        m.ws, m.ws_bytes, m.stats = self.ws.data_ptr(), self.ws.numel(), self.stats.data_ptr()
+        self.margs = m
+
+
+def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss):
+    """x [T, M], logits [T, E] -> (y [T, M_out], l_aux | None, dispatch_count [E]); None when the native path is unavailable.
+    One C call: softmax + top-k + locations + loss, encode, exchange(s), expert FFN, exchange(s), decode."""
+    ex = layer.experts
+    W = layer.world_size
+    with_comm = W > 1 or (_FORCE_COMM and dist.is_initialized())
+    comm = communicator(layer.group, x.device) if with_comm else None
+    if with_comm and comm is None:
+        return None
+    if not with_comm:
+        degree = 1
+    key = ("moe", tuple(x.shape), x.dtype, x.device, tuple(logits.shape), logits.dtype, k, capacity, degree, bool(layer.is_postscore),
+           ex.fused_activation(), ops._stream(), with_comm)
+    cache = layer.__dict__.setdefault("_ep_workspaces", {})
+    ws = cache.get(key)
+    if ws is None:
+        if len(cache) > 8:
+            cache.clear()
+        ws = cache[key] = _MoeWorkspace(layer, x, logits, k, capacity, degree, comm)
+    m = ws.margs
+    a = m.ep
+    w1, b1, w2, b2, kmajor = ex.fused_params(x.dtype)
+    dev = x.device
+    y = torch.empty([x.shape[0], ex.output_dim], dtype=x.dtype, device=dev)
+    cnt = torch.empty([logits.shape[1]], dtype=torch.int32, device=dev)
+    l_aux = torch.empty([1], dtype=logits.dtype, device=dev) if want_loss else None
+    a.w2_kmajor = int(kmajor)
+    a.x, a.w1, a.w2 = x.data_ptr(), w1.data_ptr(), w2.data_ptr()
+    a.b1 = b1.data_ptr() if b1 is not None else None
+    a.b2 = b2.data_ptr() if b2 is not None else None
+    a.y = y.data_ptr()
+    a.row_counts, a.row_align = None, 1
+    m.logits, m.normalize_gate = logits.data_ptr(), int(bool(normalize_gate))
+    m.dispatch_count = cnt.data_ptr()
+    m.l_aux = l_aux.data_ptr() if l_aux is not None else None
+    _lib.check(_lib.lib().tutel_amd_moe_forward(comm.handle if comm is not None else None, ctypes.byref(m), ops._stream()),
+               "tutel_amd_moe_forward")
+    layer.protected_shape = torch.Size([layer.num_local_experts, W * capacity, ex.output_dim])
+    return y, (l_aux[0] if l_aux is not None else None), cnt

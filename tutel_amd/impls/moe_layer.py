@@ -228,6 +228,46 @@ class MOELayer(torch.nn.Module):
         self.protected_shape = torch.Size([E_loc, W * Cc, Mo])
         return C.simple_all_to_all(send, group=self.group)
 
+    def _fast_path(self, x, gate, top_k, capacity_factor, degree, alignment, reserve_shape, inequivalent_tokens,
+                   megablocks_size, adaptive_r, original_dtype):
+        cf = capacity_factor or gate.capacity_factor
+        if (not ep_native.ENABLED or not ep_native.FAST_PATH or not x.is_cuda or _FORCE_OVERLAP or torch.is_autocast_enabled() or cf <= 0 or inequivalent_tokens or megablocks_size > 0
+                or self.batch_prioritized_routing or not self.is_gshard_loss or len(reserve_shape) != 1 or C.SKIP_A2A
+                or (adaptive_r if adaptive_r is not None else self.adaptive_degree) == 0
+                or self.num_global_experts < self.world_size or not isinstance(self.experts, FusedExpertsNetwork)
+                or (degree > 1 and self.use_2dh) or degree > 32 or (self.training and gate.gate_noise > 0)
+                or not self.experts.can_fuse(x, self)):
+            return None
+        if self.world_size > 1 and not (dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
+            return None
+        with torch.autocast("cuda", enabled=False):
+            logits = gate(x)
+        if (logits.dtype not in (torch.float32, torch.bfloat16, torch.float16) or logits.dim() != 2
+                or (torch.is_grad_enabled() and logits.requires_grad)
+                or not (x.dtype == logits.dtype or (logits.dtype == torch.float32 and x.dtype == original_dtype))):
+            return None   # (the gate projection is recomputed by the general path: rare configurations only)
+        T, E = logits.shape
+        k = min(top_k, E)
+        if k > 16 or E > 1024 or k * E > 8192:
+            return None
+        capacity = k * int(cf * ((T + E - 1) // E))
+        rem = capacity % alignment
+        capacity += (alignment - rem) if rem > 0 else 0
+        if capacity <= 0 or capacity % max(degree, 1) != 0:
+            return None
+        res = ep_native.forward_from_logits(self, x if x.is_contiguous() else x.contiguous(), logits.contiguous(), k, capacity,
+                                            degree, self.normalize_gate, want_loss=True)
+        if res is None:
+            return None
+        y, l_aux, cnt = res
+        self.megablocks_size = 0
+        self.dispatch_count = cnt
+        if adaptive_r is not None:
+            self.adaptive_degree = adaptive_r
+        if C.get_world_rank(self.group) == 0 and logging.getLogger().isEnabledFor(logging.INFO):
+            logging.info("Capacity = %d, real-time capacity-factor for top-%d = %s", capacity, top_k, capacity / max(1, k * ((T + E - 1) // E)))
+        return y, l_aux
+
     # ---- forward ------------------------------------------------------------------------
     def forward(self, input, gate_index=0, capacity_factor=None, top_k=None, a2a_ffn_overlap_degree=None,
                 reserve_dims=1, inequivalent_tokens=False, adaptive_r=None, megablocks_size=0):
@@ -259,6 +299,17 @@ class MOELayer(torch.nn.Module):
         alignment = (self.sharded_count * degree + mega - 1) // mega * mega
         if alignment > 256:
             alignment = (alignment + 127) // 128 * 128
+
+        # ---- fast path: everything after the gate projection in ONE native call (tutel_amd_moe_forward) -----------------
+        # inference configuration of the headline metric: capacity known up front (capacity_factor > 0), gshard loss,
+        # no batch-prioritised routing, no autograd, fused-able FFN experts
+        fast = self._fast_path(x, gate, top_k, capacity_factor, degree, alignment, reserve_shape, inequivalent_tokens,
+                               megablocks_size, adaptive_r, original_dtype)
+        if fast is not None:
+            y, l_aux = fast
+            y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
+            self.l_aux = y.l_aux = l_aux
+            return self.result_func(y) if self.result_func is not None else y
 
         def routing():
             logits = gate(x)
