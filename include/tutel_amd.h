@@ -287,7 +287,7 @@ int tutel_amd_ep_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_ep_args_t *a
  * for the common inference configuration -- softmax + top-k + locations + gshard loss (tutel_amd_gate_topk,
  * tutel_amd_compute_location with the capacity known up front, capacity_factor > 0) and then tutel_amd_ep_forward on
  * the routing just computed.  ep.slot_map / idx / loc / gates are OUTPUT buffers here ([E*C], [k,T], [k,T], [k,T] in
- * the logits dtype); ep.gate_dtype is ignored (= logits_dtype). */
+ * the logits dtype); ep.gate_dtype is ignored (= logits_dtype).  Dropless routing: see the last fields. */
 typedef struct {
   tutel_amd_ep_args_t ep;
   const void *logits;        /* [T, num_experts] gate logits */
@@ -296,9 +296,17 @@ typedef struct {
   void *ws;                  /* tutel_amd_routing_workspace_bytes(T, E, k) bytes */
   size_t ws_bytes;
   int32_t *dispatch_count;   /* out [num_experts] */
-  int32_t *stats;            /* out [1] max expert load (may be NULL) */
+  int32_t *stats;            /* out [1] max expert load (may be NULL; required for dropless) */
   void *l_aux;               /* out [1], logits dtype (NULL to skip the loss) */
+  /* dropless routing (capacity_factor <= 0, fast_dispatch.py:191-199), single rank only: set ep.capacity = 0.  The call then
+   * reads the maximum expert load back (the ONE host synchronisation the reference's API implies, `int(capacity)`), clamps it
+   * to capacity_limit (> 0: k * int(-capacity_factor * samples_per_expert); 0: none), rounds it up to `alignment`, and runs
+   * the rest with that capacity.  The workspace must hold max_capacity rows per expert; if the capacity exceeds it nothing
+   * further is enqueued and the call returns TUTEL_AMD_EAGAIN with the needed value in *capacity_out (grow and call again). */
+  int capacity_limit, alignment, max_capacity;
+  int *capacity_out;         /* host pointer, out: the capacity used (may be NULL when ep.capacity > 0) */
 } tutel_amd_moe_args_t;
+#define TUTEL_AMD_EAGAIN 1000
 int tutel_amd_moe_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_moe_args_t *args, tutel_stream_t stream);
 
 /* stage markers: roctx ranges (rocprofv3 --marker-trace); the pipeline above emits tutel_amd.fast_encode /

@@ -60,7 +60,8 @@ class EpArgs(ctypes.Structure):
 class MoeArgs(ctypes.Structure):
     """tutel_amd_moe_args_t"""
     _fields_ = [("ep", EpArgs), ("logits", _vp), ("logits_dtype", _i), ("normalize_gate", _i), ("ws", _vp), ("ws_bytes", _sz),
-                ("dispatch_count", _vp), ("stats", _vp), ("l_aux", _vp)]
+                ("dispatch_count", _vp), ("stats", _vp), ("l_aux", _vp),
+                ("capacity_limit", _i), ("alignment", _i), ("max_capacity", _i), ("capacity_out", ctypes.POINTER(_i))]
 
 
 SIGNATURES.update({
@@ -79,6 +80,7 @@ SIGNATURES.update({
     "tutel_amd_range_pop": (_i, []),
 })
 EP_ID_BYTES = 128
+EAGAIN = 1000
 STAGES = ("gate_topk", "location", "fast_encode", "expert_fc1", "expert_fc2", "fast_decode", "all_to_all_dispatch", "all_to_all_combine", "other")
 
 _lib = None

@@ -113,14 +113,30 @@ extern "C" int tutel_amd_ep_comm_create(const void *id, size_t bytes, int world,
   TUTEL_REQUIRE(c != nullptr, "tutel_amd_ep_comm_create: out of memory");
   c->world = world;
   c->rank = rank;
-  HIP_CHECK(hipGetDevice(&c->device), "hipGetDevice");
+  // every failure below releases what was created so far (tutel_amd_ep_comm_destroy tolerates the zeroed fields)
+  auto fail = [&](int rc) {
+    (void)tutel_amd_ep_comm_destroy(c);
+    return rc;
+  };
+  if (hipGetDevice(&c->device) != hipSuccess) {
+    tutel_set_error("tutel_amd_ep_comm_create: hipGetDevice failed");
+    return fail(-1);
+  }
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
-  RCCL_CHECK(g_rccl.CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
-  HIP_CHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), "hipStreamCreate");
-  for (int i = 0; i < EP_MAX_SPLIT; ++i) {
-    HIP_CHECK(hipEventCreateWithFlags(&c->recv_ev[i], hipEventDisableTiming), "hipEventCreate");
-    HIP_CHECK(hipEventCreateWithFlags(&c->done_ev[i], hipEventDisableTiming), "hipEventCreate");
+  ncclResult_t nr = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+  if (nr != ncclSuccess) {
+    c->comm = nullptr;
+    tutel_set_error("ncclCommInitRank: RCCL error %d (%s)", (int)nr, g_rccl.GetErrorString(nr));
+    return fail((int)nr);
+  }
+  bool ok = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < EP_MAX_SPLIT; ++i)
+    ok = hipEventCreateWithFlags(&c->recv_ev[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->done_ev[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    tutel_set_error("tutel_amd_ep_comm_create: cannot create the side stream / event table: %s", hipGetErrorString(hipGetLastError()));
+    return fail(-1);
   }
   *out = c;
   return 0;
@@ -128,12 +144,12 @@ extern "C" int tutel_amd_ep_comm_create(const void *id, size_t bytes, int world,
 
 extern "C" int tutel_amd_ep_comm_destroy(tutel_amd_ep_comm_t *c) {
   if (c == nullptr) return 0;
-  (void)hipStreamSynchronize(c->side_stream);
+  if (c->side_stream != nullptr) (void)hipStreamSynchronize(c->side_stream);
   if (c->comm != nullptr && g_rccl.CommDestroy != nullptr) (void)g_rccl.CommDestroy(c->comm);
-  (void)hipStreamDestroy(c->side_stream);
+  if (c->side_stream != nullptr) (void)hipStreamDestroy(c->side_stream);
   for (int i = 0; i < EP_MAX_SPLIT; ++i) {
-    (void)hipEventDestroy(c->recv_ev[i]);
-    (void)hipEventDestroy(c->done_ev[i]);
+    if (c->recv_ev[i] != nullptr) (void)hipEventDestroy(c->recv_ev[i]);
+    if (c->done_ev[i] != nullptr) (void)hipEventDestroy(c->done_ev[i]);
   }
   free(c);
   return 0;
@@ -321,16 +337,40 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
   const tutel_amd_ep_args_t &a = m->ep;
   TUTEL_REQUIRE(m->logits != nullptr && m->ws != nullptr && m->dispatch_count != nullptr, "tutel_amd_moe_forward: null pointer");
   TUTEL_REQUIRE(a.slot_map && a.idx && a.loc && a.gates, "tutel_amd_moe_forward: null routing buffers");
-  TUTEL_REQUIRE(a.capacity > 0, "tutel_amd_moe_forward: the capacity must be known up front (capacity_factor > 0)");
   const int T = a.T, E = a.num_experts, k = a.k;
   if (T == 0) return 0;
+  const bool dropless = a.capacity <= 0;
+  TUTEL_REQUIRE(!dropless || (c == nullptr && a.world == 1 && m->stats != nullptr && m->capacity_out != nullptr && m->max_capacity >= 1),
+                "tutel_amd_moe_forward: dropless routing needs a single rank, stats, capacity_out and max_capacity");
+  int32_t *smap = const_cast<int32_t *>(a.slot_map);
   int rc = tutel_amd_gate_topk(m->logits, m->logits_dtype, 1, T, E, k, m->normalize_gate, nullptr, const_cast<int32_t *>(a.idx),
-                               const_cast<void *>(a.gates), m->ws, m->ws_bytes, const_cast<int32_t *>(a.slot_map), E * a.capacity, stream);
+                               const_cast<void *>(a.gates), m->ws, m->ws_bytes, dropless ? nullptr : smap, dropless ? 0 : E * a.capacity, stream);
   if (rc) return rc;
   rc = tutel_amd_compute_location(a.idx, T, E, k, 1, m->ws, m->ws_bytes, const_cast<int32_t *>(a.loc), m->dispatch_count, m->stats,
-                                  m->l_aux, m->logits_dtype, a.capacity, const_cast<int32_t *>(a.slot_map), 1, stream);
+                                  m->l_aux, m->logits_dtype, dropless ? 0 : a.capacity, dropless ? nullptr : smap, dropless ? 0 : 1, stream);
   if (rc) return rc;
   tutel_amd_ep_args_t e = a;
   e.gate_dtype = m->logits_dtype;
+  if (dropless) {
+    // the one host synchronisation of the dropless API (fast_dispatch.py:192-193), taken here so that nothing but this
+    // function stands between the read-back and the next launch
+    static int *h_cap = nullptr;  // pinned
+    if (h_cap == nullptr) HIP_CHECK(hipHostMalloc((void **)&h_cap, sizeof(int), hipHostMallocDefault), "hipHostMalloc");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipMemcpyAsync(h_cap, m->stats, sizeof(int), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+    HIP_CHECK(hipStreamSynchronize(st), "hipStreamSynchronize");
+    int cap = *h_cap;
+    if (m->capacity_limit > 0 && cap > m->capacity_limit) cap = m->capacity_limit;
+    const int al = m->alignment >= 1 ? m->alignment : 1;
+    cap = (cap + al - 1) / al * al;
+    *m->capacity_out = cap;
+    if (cap > m->max_capacity) return TUTEL_AMD_EAGAIN;
+    if (cap == 0) return hipMemsetAsync(a.y, 0, (size_t)T * a.M_out * 2, st) == hipSuccess ? 0 : -1;
+    rc = tutel_amd_slot_map(a.idx, a.loc, T, E, k, cap, smap, stream);
+    if (rc) return rc;
+    e.capacity = cap;
+  } else if (m->capacity_out != nullptr) {
+    *m->capacity_out = a.capacity;
+  }
   return tutel_amd_ep_forward(c, &e, stream);
 }

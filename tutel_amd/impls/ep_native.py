@@ -239,42 +239,68 @@ class _MoeWorkspace(_Workspace):
         self.margs = m
 
 
-def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss):
-    """x [T, M], logits [T, E] -> (y [T, M_out], l_aux | None, dispatch_count [E]); None when the native path is unavailable.
-    One C call: softmax + top-k + locations + loss, encode, exchange(s), expert FFN, exchange(s), decode."""
+def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss, dropless=None, megablocks_size=0):
+    """x [T, M], logits [T, E] -> (y [T, M_out], l_aux | None, dispatch_count [E], capacity); None when the native path is
+    unavailable.  One C call: softmax + top-k + locations + loss, encode, exchange(s), expert FFN, exchange(s), decode.
+    dropless = (capacity_limit, alignment): capacity_factor <= 0 on a single rank -- the capacity is read back inside the call
+    (`capacity` is then only the first guess for the workspace size)."""
     ex = layer.experts
     W = layer.world_size
     with_comm = W > 1 or (_FORCE_COMM and dist.is_initialized())
+    if dropless is not None and with_comm:
+        return None
     comm = communicator(layer.group, x.device) if with_comm else None
     if with_comm and comm is None:
         return None
     if not with_comm:
         degree = 1
-    key = ("moe", tuple(x.shape), x.dtype, x.device, tuple(logits.shape), logits.dtype, k, capacity, degree, bool(layer.is_postscore),
-           ex.fused_activation(), ops._stream(), with_comm)
-    cache = layer.__dict__.setdefault("_ep_workspaces", {})
-    ws = cache.get(key)
-    if ws is None:
-        if len(cache) > 8:
-            cache.clear()
-        ws = cache[key] = _MoeWorkspace(layer, x, logits, k, capacity, degree, comm)
-    m = ws.margs
-    a = m.ep
-    w1, b1, w2, b2, kmajor = ex.fused_params(x.dtype)
-    dev = x.device
-    y = torch.empty([x.shape[0], ex.output_dim], dtype=x.dtype, device=dev)
-    cnt = torch.empty([logits.shape[1]], dtype=torch.int32, device=dev)
-    l_aux = torch.empty([1], dtype=logits.dtype, device=dev) if want_loss else None
-    a.w2_kmajor = int(kmajor)
-    a.x, a.w1, a.w2 = x.data_ptr(), w1.data_ptr(), w2.data_ptr()
-    a.b1 = b1.data_ptr() if b1 is not None else None
-    a.b2 = b2.data_ptr() if b2 is not None else None
-    a.y = y.data_ptr()
-    a.row_counts, a.row_align = None, 1
-    m.logits, m.normalize_gate = logits.data_ptr(), int(bool(normalize_gate))
-    m.dispatch_count = cnt.data_ptr()
-    m.l_aux = l_aux.data_ptr() if l_aux is not None else None
-    _lib.check(_lib.lib().tutel_amd_moe_forward(comm.handle if comm is not None else None, ctypes.byref(m), ops._stream()),
-               "tutel_amd_moe_forward")
-    layer.protected_shape = torch.Size([layer.num_local_experts, W * capacity, ex.output_dim])
-    return y, (l_aux[0] if l_aux is not None else None), cnt
+    sizes = layer.__dict__.setdefault("_ep_dropless_cap", {})
+    skey = (tuple(x.shape), logits.shape[1], k)
+    if dropless is not None:
+        capacity = max(capacity, sizes.get(skey, 0))
+    cap_out = ctypes.c_int(0)
+    for attempt in range(4):
+        key = ("moe", tuple(x.shape), x.dtype, x.device, tuple(logits.shape), logits.dtype, k, capacity, degree, bool(layer.is_postscore),
+               ex.fused_activation(), ops._stream(), with_comm)
+        cache = layer.__dict__.setdefault("_ep_workspaces", {})
+        ws = cache.get(key)
+        if ws is None:
+            if len(cache) > 8:
+                cache.clear()
+            ws = cache[key] = _MoeWorkspace(layer, x, logits, k, capacity, degree, comm)
+        m = ws.margs
+        a = m.ep
+        w1, b1, w2, b2, kmajor = ex.fused_params(x.dtype)
+        dev = x.device
+        y = torch.empty([x.shape[0], ex.output_dim], dtype=x.dtype, device=dev)
+        cnt = torch.empty([logits.shape[1]], dtype=torch.int32, device=dev)
+        l_aux = torch.empty([1], dtype=logits.dtype, device=dev) if want_loss else None
+        a.w2_kmajor = int(kmajor)
+        a.x, a.w1, a.w2 = x.data_ptr(), w1.data_ptr(), w2.data_ptr()
+        a.b1 = b1.data_ptr() if b1 is not None else None
+        a.b2 = b2.data_ptr() if b2 is not None else None
+        a.y = y.data_ptr()
+        if megablocks_size > 0 and not with_comm:
+            a.row_counts, a.row_align = cnt.data_ptr(), int(megablocks_size)
+        else:
+            a.row_counts, a.row_align = None, 1
+        m.logits, m.normalize_gate = logits.data_ptr(), int(bool(normalize_gate))
+        m.dispatch_count = cnt.data_ptr()
+        m.l_aux = l_aux.data_ptr() if l_aux is not None else None
+        m.capacity_out = ctypes.pointer(cap_out)
+        if dropless is not None:
+            a.capacity = 0
+            m.capacity_limit, m.alignment, m.max_capacity = int(dropless[0]), int(dropless[1]), int(capacity)
+        else:
+            a.capacity = int(capacity)
+            m.capacity_limit, m.alignment, m.max_capacity = 0, 1, int(capacity)
+        rc = _lib.lib().tutel_amd_moe_forward(comm.handle if comm is not None else None, ctypes.byref(m), ops._stream())
+        if rc == _lib.EAGAIN and dropless is not None:   # the batch needs more rows per expert than the workspace holds: grow, redo
+            capacity = (int(cap_out.value) * 5 // 4 + 31) // 32 * 32
+            sizes[skey] = capacity
+            continue
+        _lib.check(rc, "tutel_amd_moe_forward")
+        used = int(cap_out.value) if dropless is not None else int(capacity)
+        layer.protected_shape = torch.Size([layer.num_local_experts, W * used, ex.output_dim])
+        return y, (l_aux[0] if l_aux is not None else None), cnt, used
+    raise _lib.TutelAmdError("tutel_amd_moe_forward: the dropless capacity kept growing")

@@ -231,7 +231,10 @@ class MOELayer(torch.nn.Module):
     def _fast_path(self, x, gate, top_k, capacity_factor, degree, alignment, reserve_shape, inequivalent_tokens,
                    megablocks_size, adaptive_r, original_dtype):
         cf = capacity_factor or gate.capacity_factor
-        if (not ep_native.ENABLED or not ep_native.FAST_PATH or not x.is_cuda or _FORCE_OVERLAP or torch.is_autocast_enabled() or cf <= 0 or inequivalent_tokens or megablocks_size > 0
+        dropless = cf <= 0   # capacity = max expert load: read back inside the native call, single rank only
+        if (not ep_native.ENABLED or not ep_native.FAST_PATH or not x.is_cuda or _FORCE_OVERLAP or torch.is_autocast_enabled()
+                or (dropless and self.world_size > 1) or inequivalent_tokens
+                or (megablocks_size > 0 and not (dropless and self.is_postscore))
                 or self.batch_prioritized_routing or not self.is_gshard_loss or len(reserve_shape) != 1 or C.SKIP_A2A
                 or (adaptive_r if adaptive_r is not None else self.adaptive_degree) == 0
                 or self.num_global_experts < self.world_size or not isinstance(self.experts, FusedExpertsNetwork)
@@ -250,17 +253,24 @@ class MOELayer(torch.nn.Module):
         k = min(top_k, E)
         if k > 16 or E > 1024 or k * E > 8192:
             return None
-        capacity = k * int(cf * ((T + E - 1) // E))
-        rem = capacity % alignment
-        capacity += (alignment - rem) if rem > 0 else 0
-        if capacity <= 0 or capacity % max(degree, 1) != 0:
-            return None
-        res = ep_native.forward_from_logits(self, x if x.is_contiguous() else x.contiguous(), logits.contiguous(), k, capacity,
-                                            degree, self.normalize_gate, want_loss=True)
+        spe = (T + E - 1) // E
+        if dropless:   # capacity = max expert load, read back inside the native call (fast_dispatch.py:191-199)
+            guess = (k * spe * 3 // 2 + 31) // 32 * 32
+            res = ep_native.forward_from_logits(self, x if x.is_contiguous() else x.contiguous(), logits.contiguous(), k, guess, 1,
+                                                self.normalize_gate, want_loss=True, dropless=(k * int(-cf * spe) if cf < 0 else 0, alignment),
+                                                megablocks_size=megablocks_size)
+        else:
+            capacity = k * int(cf * spe)
+            rem = capacity % alignment
+            capacity += (alignment - rem) if rem > 0 else 0
+            if capacity <= 0 or capacity % max(degree, 1) != 0:
+                return None
+            res = ep_native.forward_from_logits(self, x if x.is_contiguous() else x.contiguous(), logits.contiguous(), k, capacity,
+                                                degree, self.normalize_gate, want_loss=True)
         if res is None:
             return None
-        y, l_aux, cnt = res
-        self.megablocks_size = 0
+        y, l_aux, cnt, capacity = res
+        self.megablocks_size = megablocks_size
         self.dispatch_count = cnt
         if adaptive_r is not None:
             self.adaptive_degree = adaptive_r
