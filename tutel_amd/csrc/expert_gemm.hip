@@ -527,6 +527,99 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
   gemm_epilogue<T, ACT>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
 }
 
+// 16 bytes per lane, global -> LDS, through a buffer descriptor: address = base + voff (VGPR) + soff (SGPR)
+template <bool NT>
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint16_t *l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)l, 16, voff, soff, 0, NT ? 2 : 0);
+}
+
+// ---- epilogue through LDS for the 8-wave 256 x 256 kernels: the MFMA layout gives a lane 4 consecutive
+// features of ONE row per register group, i.e. 8-byte stores 32 rows apart (32 store instructions per wave,
+// every 64-byte sector assembled from 4 instructions).  With one block per CU and all blocks finishing
+// together that store tail is fully exposed: 13-14 us of 68 at 8 x 1024 x 2048 x 2048 (ablation, tools/pp_probe.py).
+// Here each wave rounds its 64 x 128 sub-tile into a private LDS region (row pitch 272 B: the 8-byte writes of
+// 16 lanes spread over 8 bank pairs, the 16-byte reads of a row are contiguous) and writes it out as whole
+// 256-byte row segments, 16 bytes per lane, 4 rows per instruction: 16 store instructions per wave.
+// Values are computed exactly as in gemm_epilogue (fp32 bias add, activation, optional gating product, one
+// rounding) -- only the path to memory differs.
+#define EP_PITCH 272   // NI = 4 (128 columns per wave); NI = 2: 144
+template <typename T, int ACT, int NI = 4>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&acc)[NI][2], uint2 (&bias_r)[NI][4],
+                                                  unsigned char *stage, int e, int m0, int n0, int wm, int wn,
+                                                  int lane, int row_limit) {
+  constexpr int PITCH = NI * 64 + 16;  // bytes per staged row (NI*32 features + 16 B: see EP_PITCH)
+  const int l31 = lane & 31, kg = lane >> 5;
+  uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;
+  const uint16_t *Me = p.mul ? reinterpret_cast<const uint16_t *>(p.mul) + (size_t)e * p.d_stride_e : nullptr;
+  const bool has_bias = p.bias != nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wm * 64 + mi * 32 + l31;
+    size_t roff = 0;
+    if (Me) {
+      const int mc = min(m, p.R - 1);
+      roff = (size_t)(mc / p.d_rpw) * p.d_stride_w + (size_t)(mc % p.d_rpw) * p.ldd;
+    }
+    unsigned char *srow = stage + (mi * 32 + l31) * PITCH + kg * 8;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][rg * 4 + r];
+        if (has_bias) {
+          const uint2 bb = bias_r[ni][rg];
+          uint16_t b4[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            T tb;
+            __builtin_memcpy(&tb, &b4[r], 2);
+            v[r] += Elem<T>::to_f32(tb);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = activate<ACT>(v[r]);
+        if (Me) {
+          const int n = min(n0 + wn * (NI * 32) + ni * 32 + rg * 8 + kg * 4, p.N - 4);
+          const uint2 mm = *reinterpret_cast<const uint2 *>(Me + roff + n);
+          uint16_t m4[4] = {(uint16_t)(mm.x & 0xffff), (uint16_t)(mm.x >> 16), (uint16_t)(mm.y & 0xffff), (uint16_t)(mm.y >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            T tm;
+            __builtin_memcpy(&tm, &m4[r], 2);
+            v[r] *= Elem<T>::to_f32(tm);
+          }
+        }
+        uint16_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T tv = Elem<T>::from_f32(v[r]);
+          __builtin_memcpy(&o[r], &tv, 2);
+        }
+        uint2 ov;
+        ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        *reinterpret_cast<uint2 *>(srow + (ni * 32 + rg * 8) * 2) = ov;
+      }
+    }
+  }
+  // the region is private to the wave and LDS operations of one wave complete in order: no barrier
+  constexpr int LPR = NI * 4, RPI = 64 / LPR;  // lanes per row (16 bytes each), rows per store instruction
+  const int c16 = lane % LPR, r4 = lane / LPR;
+  const int n = n0 + wn * (NI * 32) + c16 * 8;
+#pragma unroll 4
+  for (int it = 0; it < 64 / RPI; ++it) {
+    const int row = it * RPI + r4;
+    const int m = m0 + wm * 64 + row;
+    const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + row * PITCH + c16 * 16);
+    if (m < row_limit && n < p.N) {
+      const size_t roff = (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
+      *reinterpret_cast<u32x4 *>(De + roff + n) = val;
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------
 // 256 x 256 tile variant for R >= 256 rows per expert (expert-parallel ranks, large batches).
 // There the GEMM is no longer bound by streaming the weights once from HBM but by the bytes that
@@ -543,7 +636,9 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
 
 // NI = 32-column MFMA tiles per wave: 4 -> 256 x 256 block tile (two 128-column weight sub-tiles per
 // stage), 2 -> 256 x 128 (one sub-tile; for launches whose 256 x 256 grid would leave CUs idle).
-template <typename T, bool W_KMAJOR, int ACT, int NI, int NS>
+// BUF: LDS-DMA through buffer descriptors (no VALU on the issue path) and the epilogue through LDS -- the two levers of
+// the ping-pong kernel below that carry over to this lockstep structure (k-major weights, 32-bit addressable operands).
+template <typename T, bool W_KMAJOR, int ACT, int NI, int NS, bool BUF = false>
 __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs p) {
   constexpr int NSUB = NI / 2;              // 128-column weight sub-tiles per stage
   constexpr int WPW = 2 * NSUB;             // weight DMA pieces per wave and stage
@@ -613,6 +708,23 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   }
   const size_t w_step = W_KMAJOR ? (size_t)GL_BK : (size_t)GL_BK * p.ldw;
   const int piece_a = wid * 4 * 512, piece_w = wid * WPW * 512;  // weight pieces are consecutive across the sub-tiles
+  int a_off[4], w_off[WPW];
+  if (BUF) {
+    const uint16_t *abase = p.a_rows != nullptr ? reinterpret_cast<const uint16_t *>(p.A) : Ae;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8 * (wid * 4 + i) + (lane >> 3);
+      const int gr = min(m0 + r, p.R - 1);
+      a_off[i] = (int)(unsigned)((const char *)a_src[i] - (const char *)abase);
+      if ((p.a_rows != nullptr && p.a_rows[(size_t)e * p.R + gr] < 0) || m0 + r >= row_limit)
+        a_off[i] = (int)0x7ffff000u + (((lane & 7) ^ ((r >> 1) & 7)) << 4);  // empty slot / past the row count: out of range -> zeros
+    }
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) w_off[i] = (int)(unsigned)((const char *)w_src[i] - (const char *)We);
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t *>(p.a_rows != nullptr ? reinterpret_cast<const uint16_t *>(p.A) : Ae), 0, p.a_span_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(We), 0, -1, 0x00020000);
   // one M-tile per expert: every weight byte is fetched by exactly one block -> no-allocate loads pay on the
   // 256 x 256 tile with the chip covered (32 x 256 rows: 720 -> 758 TFLOP/s, dropless 64 x 157: 171 -> 156 us).
   // With several M-tiles the blocks re-read each other's weight tiles from L2 and the hint costs 6-15 %; it also
@@ -646,13 +758,20 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   const int npair = NI == 4 ? p.ntn : (p.ntn + 1) >> 1, pair = NI == 4 ? nt : nt >> 1;
   const int rot = p.rot_on ? (int)(((long long)(pair + 3 * e) * nk / npair) % nk) : 0;
 
-#define GB_ISSUE(KT, BUF)                                                              \
+#define GB_ISSUE(KT, STG)                                                              \
   do {                                                                                 \
     int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
-    const size_t ao_ = (size_t)kr_ * GL_BK, wo_ = (size_t)kr_ * w_step;                \
-    uint16_t *da_ = sA + (BUF) * 2 * GL_STAGE + piece_a, *dw_ = sW + (BUF) * NSUB * GL_STAGE + piece_w; \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
-    _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, w_once); \
+    uint16_t *da_ = sA + (STG) * 2 * GL_STAGE + piece_a, *dw_ = sW + (STG) * NSUB * GL_STAGE + piece_w; \
+    if (BUF) {                                                                         \
+      const int ao_ = kr_ * (GL_BK * 2), wo_ = (int)(kr_ * (w_step * 2));              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) bdma16<false>(rs_a, a_off[i_], ao_, da_ + i_ * 512); \
+      if (w_once) { _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) bdma16<true>(rs_w, w_off[i_], wo_, dw_ + i_ * 512); } \
+      else { _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) bdma16<false>(rs_w, w_off[i_], wo_, dw_ + i_ * 512); } \
+    } else {                                                                           \
+      const size_t ao_ = (size_t)kr_ * GL_BK, wo_ = (size_t)kr_ * w_step;              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
+      _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, w_once); \
+    }                                                                                  \
   } while (0)
 #define GB_LOAD_FRAGS(FA, FW, KK)                                                      \
   do {                                                                                 \
@@ -739,92 +858,12 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
 #undef GB_MMA
 
   GM_PRELOAD_BIAS_N(NI);
+  if (BUF && !((p.ldd & 7) || (p.d_stride_e & 7) || (p.d_stride_w & 7) || (reinterpret_cast<uintptr_t>(p.D) & 15))) {
+    __syncthreads();  // every wave is done with the K-tile stages: LDS is free for the staging regions
+    gemm_epilogue_lds<T, ACT, NI>(p, acc, bias_r, smem + wid * (64 * (NI * 64 + 16)), e, m0, n0, wm, wn, lane, row_limit);
+    return;
+  }
   gemm_epilogue<T, ACT, NI>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
-}
-
-// ---- epilogue through LDS for the 8-wave 256 x 256 kernels: the MFMA layout gives a lane 4 consecutive
-// features of ONE row per register group, i.e. 8-byte stores 32 rows apart (32 store instructions per wave,
-// every 64-byte sector assembled from 4 instructions).  With one block per CU and all blocks finishing
-// together that store tail is fully exposed: 13-14 us of 68 at 8 x 1024 x 2048 x 2048 (ablation, tools/pp_probe.py).
-// Here each wave rounds its 64 x 128 sub-tile into a private LDS region (row pitch 272 B: the 8-byte writes of
-// 16 lanes spread over 8 bank pairs, the 16-byte reads of a row are contiguous) and writes it out as whole
-// 256-byte row segments, 16 bytes per lane, 4 rows per instruction: 16 store instructions per wave.
-// Values are computed exactly as in gemm_epilogue (fp32 bias add, activation, optional gating product, one
-// rounding) -- only the path to memory differs.
-#define EP_PITCH 272
-template <typename T, int ACT>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&acc)[4][2], uint2 (&bias_r)[4][4],
-                                                  unsigned char *stage, int e, int m0, int n0, int wm, int wn,
-                                                  int lane, int row_limit) {
-  const int l31 = lane & 31, kg = lane >> 5;
-  uint16_t *De = reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e;
-  const uint16_t *Me = p.mul ? reinterpret_cast<const uint16_t *>(p.mul) + (size_t)e * p.d_stride_e : nullptr;
-  const bool has_bias = p.bias != nullptr;
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = m0 + wm * 64 + mi * 32 + l31;
-    size_t roff = 0;
-    if (Me) {
-      const int mc = min(m, p.R - 1);
-      roff = (size_t)(mc / p.d_rpw) * p.d_stride_w + (size_t)(mc % p.d_rpw) * p.ldd;
-    }
-    unsigned char *srow = stage + (mi * 32 + l31) * EP_PITCH + kg * 8;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][rg * 4 + r];
-        if (has_bias) {
-          const uint2 bb = bias_r[ni][rg];
-          uint16_t b4[4] = {(uint16_t)(bb.x & 0xffff), (uint16_t)(bb.x >> 16), (uint16_t)(bb.y & 0xffff), (uint16_t)(bb.y >> 16)};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            T tb;
-            __builtin_memcpy(&tb, &b4[r], 2);
-            v[r] += Elem<T>::to_f32(tb);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = activate<ACT>(v[r]);
-        if (Me) {
-          const int n = min(n0 + wn * 128 + ni * 32 + rg * 8 + kg * 4, p.N - 4);
-          const uint2 mm = *reinterpret_cast<const uint2 *>(Me + roff + n);
-          uint16_t m4[4] = {(uint16_t)(mm.x & 0xffff), (uint16_t)(mm.x >> 16), (uint16_t)(mm.y & 0xffff), (uint16_t)(mm.y >> 16)};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            T tm;
-            __builtin_memcpy(&tm, &m4[r], 2);
-            v[r] *= Elem<T>::to_f32(tm);
-          }
-        }
-        uint16_t o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          T tv = Elem<T>::from_f32(v[r]);
-          __builtin_memcpy(&o[r], &tv, 2);
-        }
-        uint2 ov;
-        ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-        ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-        *reinterpret_cast<uint2 *>(srow + (ni * 32 + rg * 8) * 2) = ov;
-      }
-    }
-  }
-  // the region is private to the wave and LDS operations of one wave complete in order: no barrier
-  const int c16 = lane & 15, r4 = lane >> 4;
-  const int n = n0 + wn * 128 + c16 * 8;
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int row = it * 4 + r4;
-    const int m = m0 + wm * 64 + row;
-    const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + row * EP_PITCH + c16 * 16);
-    if (m < row_limit && n < p.N) {
-      const size_t roff = (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
-      *reinterpret_cast<u32x4 *>(De + roff + n) = val;
-    }
-  }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -854,12 +893,6 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&ac
 // results are bit-identical to theirs.
 // -------------------------------------------------------------------------------------------
 #define PP_BUF (4 * GL_STAGE)   // elements per LDS K-tile buffer: [256][64] tokens + [256][64] weights = 64 KB
-
-// 16 bytes per lane, global -> LDS, through a buffer descriptor: address = base + voff (VGPR) + soff (SGPR)
-template <bool NT>
-__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, uint16_t *l) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)l, 16, voff, soff, 0, NT ? 2 : 0);
-}
 
 // ABL: ablation bits for on-hardware timing experiments (tools/pp_probe.py abl); 0 in the product.
 //   1 no LDS-DMA in the loop   2 no fragment reads   4 no epilogue   8 no s_setprio   16 no stagger (groups in lockstep)
@@ -1177,13 +1210,14 @@ static int launch_pp(const GemmArgs &a, hipStream_t st) {
   return ragged ? launch_pp_cfg<T, ACT, false, 0, true>(b, st) : launch_pp_cfg<T, ACT, false>(b, st);
 }
 
-template <typename T, bool KM, int ACT, int NI, int NS = 2>
+template <typename T, bool KM, int ACT, int NI, int NS = 2, bool BUF = false>
 static int launch_big(const GemmArgs &a, hipStream_t st) {
   GemmArgs b = a;
   b.ntm = (a.R + GB_BM - 1) / GB_BM;
   b.ntn = (a.N + NI * 64 - 1) / (NI * 64);
-  const size_t lds = (size_t)NS * (2 + NI / 2) * GL_STAGE * 2;
-  auto kern = expert_gemm_big_kernel<T, KM, ACT, NI, NS>;
+  const size_t lds_k = (size_t)NS * (2 + NI / 2) * GL_STAGE * 2, lds_e = BUF ? (size_t)8 * 64 * (NI * 64 + 16) : 0;
+  const size_t lds = lds_k > lds_e ? lds_k : lds_e;
+  auto kern = expert_gemm_big_kernel<T, KM, ACT, NI, NS, BUF>;
   static bool optin = false;
   if (!optin) {
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1275,7 +1309,8 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
     // 256 x 128: a three-slot ring (3 x 48 KB of LDS) keeps two tiles in flight: +3-4 % over two slots on the
     // stage shapes it is chosen for (tools/stage_probe.py); big = 2 forces the two-slot form for A/B runs
     if (KM && big == 2) return launch_big<T, true, ACT, 2, 2>(a, st);
-    if (KM && (big == 3 || (big < 0 && a.R > GM_BM && t128 >= 192))) return launch_big<T, true, ACT, 2, 3>(a, st);
+    if (KM && (big == 3 || (big < 0 && a.R > GM_BM && t128 >= 192)))
+      return a.fits32 && tutel_get_option(TUTEL_OPT_GEMM_IMPL) != 2 ? launch_big<T, true, ACT, 2, 3, true>(a, st) : launch_big<T, true, ACT, 2, 3>(a, st);
   }
   const bool use_dma = impl < 0 ? KM : (impl == 1);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
