@@ -18,10 +18,10 @@ is fixed: weak scaling, value = N * 4096 / t.
 
 Timing: `--settle` untimed initialisation passes (allocator / weight pre-layout / clock state; reported in
 the JSON), W untimed warm-up steps; barrier + synchronize; exactly K steps; synchronize + barrier; MAX over
-ranks.  Rank 0 prints ONE JSON line.  Inside the timed region the two expert GEMM launches are bracketed by HIP events
-on their launch stream (tutel_amd_stage_timing(2)) -- `roofline` is computed from those -- and one event per step gives
-min / median step times next to the mean; `stages` (every launch bracketed) comes from a separate untimed pass, because a
-dozen event records per step slow the step down by ~10 %.
+ranks.  Rank 0 prints ONE JSON line.  The timed region carries NO events (a HIP event record drains the queue: 5-15 % of a
+step here).  Three more passes of the same K steps follow it, bracketed the same way: one device-scope event per step
+(`step_ms` min / median), events around the two expert GEMM launches on their launch stream (`roofline`), events around
+every launch (`stages`) -- all live, inside this script, on the same tensors.
 
 `roofline`: the dominant kernel is the fc1 grouped GEMM.  N = 1 (128 rows per expert):
 expert_gemm_glds_kernel<bf16,k-major,relu>, HBM-bound; achieved = algorithmic bytes per launch
@@ -122,7 +122,7 @@ def cpu_baseline(T, M, H, E, k, max_seconds=20.0):
                                    "source": "BASELINE.md section 2: the reference's own helloworld --device=cpu --eval at this shape, survey container (8 x Xeon 2.1 GHz)"}}
 
 
-def run_timed(step, x, steps, world, timer_gate, mode=2):
+def run_timed(step, x, steps, world, timer_gate, mode=2, marks=True):
     """exactly `steps` steps between barrier + synchronize pairs; returns (elapsed_s, per-step ms list, stage report).
     mode 2: HIP events around the two expert GEMMs only (the timed region); mode 1: around every launch (breakdown pass)."""
     from tutel_amd import ops
@@ -132,13 +132,15 @@ def run_timed(step, x, steps, world, timer_gate, mode=2):
     torch.cuda.synchronize()
     ops.stage_timing(mode)
     timer_gate.on = mode == 1
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ops.marks_reserve(steps + 1)
     t0 = time.perf_counter()
-    marks[0].record()
+    if marks:
+        ops.mark()
     y = None
     for i in range(steps):
         y = step(x)
-        marks[i + 1].record()
+        if marks:
+            ops.mark()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -146,7 +148,7 @@ def run_timed(step, x, steps, world, timer_gate, mode=2):
     t1 = time.perf_counter()
     ops.stage_timing(0)
     timer_gate.on = False
-    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    per_step = ops.marks_report(steps)
     return t1 - t0, per_step, ops.stage_report(), y
 
 
@@ -220,20 +222,21 @@ def main():
     with torch.no_grad():
         for _ in range(args.settle):
             step(x)
-        # the event pools of the two timers are filled before the timed region (creating a HIP event costs host time the
-        # first timed step would otherwise pay: one 0.39 ms step among twenty 0.27 ms ones)
-        run_timed(step, x, 3, 1, gate_timer, mode=2)
-        run_timed((lambda t: layer(t, **fwd_kw)), x, 3, 1, gate_timer, mode=1)
-        gate_timer.events.clear()
         for _ in range(args.warmup):
             y = step(x)
-        elapsed, per_step, gemms, y = run_timed(step, x, args.steps, world, gate_timer, mode=2)
-        # the per-stage table comes from a separate, untimed pass with events around EVERY launch (a dozen event records
-        # per step perturb the step by ~10 %; the timed region carries only those of the two dominant kernels)
-        nb = 20
-        _, _, stages, _ = run_timed((lambda t: layer(t, **fwd_kw)), x, nb, world, gate_timer, mode=1)
-        if args.graph:  # events cannot be recorded inside a replayed graph: the GEMM times come from the eager pass as well
-            gemms = stages
+        # THE timed region: exactly K steps, nothing else on the stream.  HIP events are NOT free on this part: a record makes
+        # the queue drain and release before it takes its timestamp (measured, profiles/r02_event_overhead.txt: 0.2605 ms/step
+        # bare, 0.263 with one mark per step, 0.275 with events around the two GEMMs, 0.305 around every launch), so the
+        # event-based numbers come from three more passes of the same steps right after it, each bracketed the same way:
+        elapsed, _, _, y = run_timed(step, x, args.steps, world, gate_timer, mode=0, marks=False)
+        nb = args.steps
+        eager = (lambda t: layer(t, **fwd_kw))
+        _, per_step, _, _ = run_timed(step, x, nb, world, gate_timer, mode=0, marks=True)     # one mark per step: min / median
+        run_timed(eager, x, 3, 1, gate_timer, mode=2, marks=False)                            # (fills the event pool)
+        _, _, gemms, _ = run_timed(eager, x, nb, world, gate_timer, mode=2, marks=False)      # events around fc1 / fc2: roofline
+        run_timed(eager, x, 3, 1, gate_timer, mode=1, marks=False)
+        gate_timer.events.clear()
+        _, _, stages, _ = run_timed(eager, x, nb, world, gate_timer, mode=1, marks=False)     # events around every launch: stages
     if world > 1:
         tt = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -289,7 +292,14 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dname, "data": "synthetic" if not share else "synthetic; TEST HOOK: all ranks share one GPU, host-staged all-to-all -- not a measurement",
             "step_ms": {"mean_wall": round(ms, 4), "min": round(srt[0], 4), "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4),
-                        "note": "min / median / max from one HIP event per step (rank 0); mean_wall = the timed region / steps"},
+                        "per_step": [round(v, 4) for v in per_step],
+                        "note": "mean_wall = the timed region / steps (no events inside it); min / median / max / per_step from a second pass "
+                                "of the same steps with one device-scope HIP event per step (rank 0); the first step after the "
+                                "synchronize is host-bound (Python + first launches on an idle queue)"},
+            "timing_passes": "1: K steps, wall clock only (value). 2: K steps + one mark per step (step_ms). 3: K steps + HIP events "
+                             "around the two expert GEMM launches on their launch stream (roofline). 4: K steps + events around every "
+                             "launch (stages). Each pass is bracketed by synchronize (+ barrier) like the first; events cost 5-15 % "
+                             "of a step on this GPU, which is why the timed region carries none.",
             "config": {"workload": "BASELINE.json configs[1]: tutel.moe.moe_layer forward (eval), per GPU 4096 tokens "
                                    "(batch 16 x 256) x model_dim 2048, hidden 2048, 64 global experts, top-2, "
                                    f"capacity_factor {args.capacity_factor}, ReLU, {dname}, random-init weights",
@@ -303,8 +313,8 @@ def main():
             "stages": {"avg_us_per_step": stage_us, "launches_timed": launches,
                        "sum_us": round(sum(stage_us.values()), 2),
                        "steps": nb,
-                       "note": "separate untimed pass after the timed region, HIP events around EVERY launch (tutel_amd_stage_timing(1)); "
-                               "the timed region itself carries events around the two expert GEMMs only (roofline object)"},
+                       "note": "pass 4: HIP events around EVERY launch (tutel_amd_stage_timing(1)); the sum exceeds a bare step because "
+                               "every event record drains the queue"},
             "layer_roofline": {"algorithmic_bytes_per_step": layer_bytes, "achieved_GBs": round(layer_bytes / (ms * 1e-3) * 1e-9, 1),
                                "frac_of_hbm_peak": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
                                "frac_of_hbm_achievable": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_ACHIEVABLE_GBS, 4)},
@@ -317,7 +327,8 @@ def main():
             with torch.no_grad():
                 for _ in range(30):
                     lay2(x, megablocks_size=4)
-                el2, ps2, st2, _ = run_timed(lambda t: lay2(t, megablocks_size=4), x, 30, 1, gt2, mode=2)
+                el2, _, _, _ = run_timed(lambda t: lay2(t, megablocks_size=4), x, 30, 1, gt2, mode=0, marks=False)
+                _, _, st2, _ = run_timed(lambda t: lay2(t, megablocks_size=4), x, 30, 1, gt2, mode=2, marks=False)
             ms2 = el2 / 30 * 1e3
             out["extra"] = {"dropless_configs2": {
                 "workload": "BASELINE.json configs[2]: same shape, capacity_factor 0 (capacity = max expert load, read back each step), megablocks_size 4",

@@ -327,6 +327,13 @@ enum {
 };
 int tutel_amd_stage_timing(int enable);
 int tutel_amd_stage_report(double *total_us, int *counts, int n_stages /* >= TUTEL_STAGE_COUNT */);
+/* step marks: tutel_amd_mark records one event on `stream` (device-scope release: a default HIP event writes the L2 back to
+ * system scope before it takes its timestamp, ~5 us of idle GPU per record); tutel_amd_marks_report waits, returns the
+ * deltas between consecutive marks in microseconds (at most n; return value = how many) and clears the list;
+ * tutel_amd_marks_reserve(n) creates the events ahead of a timed region. */
+int tutel_amd_mark(tutel_stream_t stream);
+int tutel_amd_marks_reserve(int n);
+int tutel_amd_marks_report(double *delta_us, int n);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG

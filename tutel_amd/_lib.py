@@ -74,6 +74,9 @@ SIGNATURES.update({
     "tutel_amd_ep_all_to_all": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tutel_amd_ep_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(EpPlan)]),
     "tutel_amd_ep_forward": (_i, [_vp, ctypes.POINTER(EpArgs), _vp]),
+    "tutel_amd_mark": (_i, [_vp]),
+    "tutel_amd_marks_reserve": (_i, [_i]),
+    "tutel_amd_marks_report": (_i, [ctypes.POINTER(ctypes.c_double), _i]),
     "tutel_amd_stage_timing": (_i, [_i]),
     "tutel_amd_stage_report": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), _i]),
     "tutel_amd_range_push": (_i, [ctypes.c_char_p]),

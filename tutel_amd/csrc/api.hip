@@ -96,7 +96,10 @@ int tutel_stage_begin(int stage, hipStream_t st) {
     r.a = g_free.back().first;
     r.b = g_free.back().second;
     g_free.pop_back();
-  } else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+  } else if (hipEventCreateWithFlags(&r.a, hipEventReleaseToDevice) != hipSuccess ||
+             hipEventCreateWithFlags(&r.b, hipEventReleaseToDevice) != hipSuccess) {
+    // device-scope release: a default event makes the queue write the L2 back to system scope before it takes its
+    // timestamp (5-6 us of idle GPU per record behind a GEMM that just wrote 33 MB, measured in a kernel trace)
     return -1;
   }
   (void)hipEventRecord(r.a, st);
@@ -105,6 +108,42 @@ int tutel_stage_begin(int stage, hipStream_t st) {
 }
 void tutel_stage_end(int token, hipStream_t st) {
   if (token >= 0 && token < (int)g_recs.size()) (void)hipEventRecord(g_recs[token].b, st);
+}
+
+// step marks: one event per call; tutel_amd_stage_report returns nothing about them, tutel_amd_marks_report the deltas
+static std::vector<hipEvent_t> g_marks;
+static std::vector<hipEvent_t> g_marks_free;
+extern "C" int tutel_amd_mark(tutel_stream_t stream) {
+  hipEvent_t ev;
+  if (!g_marks_free.empty()) {
+    ev = g_marks_free.back();
+    g_marks_free.pop_back();
+  } else {
+    TUTEL_REQUIRE(hipEventCreateWithFlags(&ev, hipEventReleaseToDevice) == hipSuccess, "tutel_amd_mark: cannot create an event");
+  }
+  TUTEL_REQUIRE(hipEventRecord(ev, (hipStream_t)stream) == hipSuccess, "tutel_amd_mark: hipEventRecord failed");
+  g_marks.push_back(ev);
+  return 0;
+}
+extern "C" int tutel_amd_marks_reserve(int n) {
+  while ((int)g_marks_free.size() < n) {
+    hipEvent_t ev;
+    TUTEL_REQUIRE(hipEventCreateWithFlags(&ev, hipEventReleaseToDevice) == hipSuccess, "tutel_amd_marks_reserve: cannot create an event");
+    g_marks_free.push_back(ev);
+  }
+  return 0;
+}
+extern "C" int tutel_amd_marks_report(double *delta_us, int n) {
+  const int have = (int)g_marks.size();
+  int m = 0;
+  for (int i = 0; i + 1 < have; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_marks[i + 1]) == hipSuccess && hipEventElapsedTime(&ms, g_marks[i], g_marks[i + 1]) == hipSuccess && m < n && delta_us)
+      delta_us[m++] = 1e3 * ms;
+  }
+  for (auto ev : g_marks) g_marks_free.push_back(ev);
+  g_marks.clear();
+  return m;
 }
 
 extern "C" int tutel_amd_stage_timing(int enable) {

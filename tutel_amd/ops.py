@@ -282,3 +282,20 @@ def stage_report():
     _lib.check(_lib.lib().tutel_amd_stage_report(tot, cnt, n), "tutel_amd_stage_report")
     return {name: (float(tot[i]), int(cnt[i])) for i, name in enumerate(_lib.STAGES)}
 
+
+
+def mark():
+    """record a step mark on the current stream (see tutel_amd_mark)"""
+    _lib.check(_lib.lib().tutel_amd_mark(_stream()), "tutel_amd_mark")
+
+
+def marks_reserve(n):
+    _lib.check(_lib.lib().tutel_amd_marks_reserve(int(n)), "tutel_amd_marks_reserve")
+
+
+def marks_report(n):
+    """milliseconds between consecutive marks recorded since the last report"""
+    import ctypes
+    buf = (ctypes.c_double * max(n, 1))()
+    m = _lib.lib().tutel_amd_marks_report(buf, int(n))
+    return [buf[i] * 1e-3 for i in range(m)]
