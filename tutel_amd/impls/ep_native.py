@@ -134,9 +134,11 @@ def usable(layer, x, crit, degree):
 
 
 class _Workspace:
-    def __init__(self, layer, x, crit, degree, comm):
+    """the buffers of one pipeline configuration + its argument struct (pointers that never change filled in once)"""
+
+    def __init__(self, layer, x, E, C, k, degree, comm):
         ex = layer.experts
-        W, E, C, k = layer.world_size, crit[0], crit[4], crit.idx2d.shape[0]
+        W = layer.world_size
         T, M = x.shape
         H, Mo = ex.batched_fc1_w.size(1), ex.output_dim
         dev, dt = x.device, x.dtype
@@ -186,7 +188,7 @@ def forward(layer, x, crit, degree):
     if ws is None:
         if len(cache) > 8:
             cache.clear()
-        ws = cache[key] = _Workspace(layer, x, crit, degree, comm)
+        ws = cache[key] = _Workspace(layer, x, crit[0], crit[4], crit.idx2d.shape[0], degree, comm)
     a = ws.args
     w1, b1, w2, b2, kmajor = ex.fused_params(x.dtype)
     gates = crit.gates2d
@@ -218,22 +220,17 @@ class _MoeWorkspace(_Workspace):
     def __init__(self, layer, x, logits, k, capacity, degree, comm):
         E, T = logits.shape[1], logits.shape[0]
         dev = x.device
-
-        class _Crit(tuple):   # what _Workspace reads from a RoutingPlan
-            pass
-        crit = _Crit((E, None, None, None, capacity, None))
-        crit.idx2d = torch.empty([k, T], dtype=torch.int32, device=dev)
-        crit.loc2d = torch.empty([k, T], dtype=torch.int32, device=dev)
-        crit.gates2d = torch.empty([k, T], dtype=logits.dtype, device=dev)
-        crit.slot_map = torch.empty([E * capacity], dtype=torch.int32, device=dev)
-        super().__init__(layer, x, crit, degree, comm)
-        self.crit = crit
+        super().__init__(layer, x, E, capacity, k, degree, comm)
+        self.idx = torch.empty([k, T], dtype=torch.int32, device=dev)
+        self.loc = torch.empty([k, T], dtype=torch.int32, device=dev)
+        self.gates = torch.empty([k, T], dtype=logits.dtype, device=dev)
+        self.slot_map = torch.empty([E * capacity], dtype=torch.int32, device=dev)
         self.ws = ops.routing_workspace(T, E, k, dev)
         self.stats = torch.empty([1], dtype=torch.int32, device=dev)
         m = _lib.MoeArgs()
         m.ep = self.args
-        m.ep.slot_map, m.ep.idx, m.ep.loc, m.ep.gates = (crit.slot_map.data_ptr(), crit.idx2d.data_ptr(), crit.loc2d.data_ptr(),
-                                                          crit.gates2d.data_ptr())
+        m.ep.slot_map, m.ep.idx, m.ep.loc, m.ep.gates = (self.slot_map.data_ptr(), self.idx.data_ptr(), self.loc.data_ptr(),
+                                                          self.gates.data_ptr())
         m.logits_dtype = ops._DT[logits.dtype]
         m.ws, m.ws_bytes, m.stats = self.ws.data_ptr(), self.ws.numel(), self.stats.data_ptr()
         self.margs = m
