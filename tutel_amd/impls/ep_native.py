@@ -67,11 +67,25 @@ def _create(group, device):
     t = idbuf.to(device) if on_dev else idbuf
     dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     idbytes = bytes(t.cpu().tolist())
+
+    def agree(v):  # all ranks continue only if every rank is fine (a rank that skipped a collective would hang the others)
+        f = torch.tensor([v], dtype=torch.int32, device=device if on_dev else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+        return int(f)
+    comm = None
+    ok = agree(ok)     # every rank resolved RCCL and rank 0 drew an id: only then is ncclCommInitRank (collective) entered
     if ok:
         try:
             with torch.cuda.device(device):
                 _lib.check(L.tutel_amd_ep_comm_create(idbytes, len(idbytes), W, rank, ctypes.byref(handle)), "tutel_amd_ep_comm_create")
             comm = EpComm(handle, W, rank)
+        except Exception as ex:
+            logging.warning("tutel_amd: native expert-parallel communicator could not be created on rank %d (%s)", rank, ex)
+            ok = 0
+
+    ok = agree(ok)
+    if ok:
+        try:
             # self-check: block p of my send buffer carries (my rank, p); after the exchange block r must carry (r, my rank)
             n = 1024
             send = (torch.arange(W, device=device, dtype=torch.int32).view(W, 1) + 1000 * rank).repeat(1, n).contiguous()
@@ -84,9 +98,8 @@ def _create(group, device):
         except Exception as ex:
             logging.warning("tutel_amd: native expert-parallel communicator failed its self-check on rank %d (%s)", rank, ex)
             ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=device if on_dev else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag) == 0:
+        ok = agree(ok)
+    if not ok:
         if handle:
             L.tutel_amd_ep_comm_destroy(handle)
         if rank == 0:
