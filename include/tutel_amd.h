@@ -224,6 +224,13 @@ int tutel_amd_ep_load_rccl(const char *path_hint /* may be NULL */);
 int tutel_amd_ep_unique_id(void *out, size_t bytes /* >= TUTEL_AMD_EP_ID_BYTES */);
 int tutel_amd_ep_comm_create(const void *id, size_t bytes, int world, int rank, tutel_amd_ep_comm_t **out);
 int tutel_amd_ep_comm_destroy(tutel_amd_ep_comm_t *comm);
+/* Bring-up / test communicator: the equal-split exchange is performed by a HOST callback instead of RCCL (e.g. staged
+ * through host memory over a gloo process group, which is how several ranks can share one GPU).  The callback is invoked
+ * synchronously from tutel_amd_ep_forward / tutel_amd_ep_all_to_all on the calling thread; it must order itself after the
+ * work already enqueued on the caller's current stream and return only when `recv` may be read by work enqueued after it.
+ * Everything else -- stage layouts, buffers, both streams, events -- is the production path. */
+typedef int (*tutel_amd_exchange_fn)(void *user, const void *send, void *recv, size_t bytes_per_peer, int world);
+int tutel_amd_ep_comm_create_hosted(int world, int rank, tutel_amd_exchange_fn fn, void *user, tutel_amd_ep_comm_t **out);
 int tutel_amd_ep_comm_info(const tutel_amd_ep_comm_t *comm, int *world, int *rank);
 
 /* all_to_all_single with equal splits (simple_all_to_all, communicate.py:181-192): block r of `send`

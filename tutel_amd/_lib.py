@@ -70,6 +70,7 @@ SIGNATURES.update({
     "tutel_amd_ep_unique_id": (_i, [_vp, _sz]),
     "tutel_amd_ep_comm_create": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(_vp)]),
     "tutel_amd_ep_comm_destroy": (_i, [_vp]),
+    "tutel_amd_ep_comm_create_hosted": (_i, [_i, _i, _vp, _vp, ctypes.POINTER(_vp)]),
     "tutel_amd_ep_comm_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "tutel_amd_ep_all_to_all": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tutel_amd_ep_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(EpPlan)]),
@@ -82,6 +83,7 @@ SIGNATURES.update({
     "tutel_amd_range_push": (_i, [ctypes.c_char_p]),
     "tutel_amd_range_pop": (_i, []),
 })
+EXCHANGE_FN = ctypes.CFUNCTYPE(_i, _vp, _vp, _vp, _sz, _i)
 EP_ID_BYTES = 128
 EAGAIN = 1000
 STAGES = ("gate_topk", "location", "fast_encode", "expert_fc1", "expert_fc2", "fast_decode", "all_to_all_dispatch", "all_to_all_combine", "other")

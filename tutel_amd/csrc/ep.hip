@@ -92,6 +92,8 @@ struct Range {
 struct tutel_amd_ep_comm {
   ncclComm_t comm;
   int world, rank, device;
+  tutel_amd_exchange_fn hosted;  // bring-up / test communicator: the exchange is a host callback (comm == nullptr then)
+  void *hosted_user;
   hipStream_t side_stream;  // the GEMMs of the overlapped pipeline (the collectives run on the caller's stream)
   hipEvent_t recv_ev[EP_MAX_SPLIT], done_ev[EP_MAX_SPLIT];
 };
@@ -142,6 +144,27 @@ extern "C" int tutel_amd_ep_comm_create(const void *id, size_t bytes, int world,
   return 0;
 }
 
+extern "C" int tutel_amd_ep_comm_create_hosted(int world, int rank, tutel_amd_exchange_fn fn, void *user, tutel_amd_ep_comm_t **out) {
+  TUTEL_REQUIRE(out != nullptr && fn != nullptr && world >= 1 && rank >= 0 && rank < world, "tutel_amd_ep_comm_create_hosted: bad arguments");
+  tutel_amd_ep_comm *c = (tutel_amd_ep_comm *)calloc(1, sizeof(tutel_amd_ep_comm));
+  TUTEL_REQUIRE(c != nullptr, "tutel_amd_ep_comm_create_hosted: out of memory");
+  c->world = world;
+  c->rank = rank;
+  c->hosted = fn;
+  c->hosted_user = user;
+  bool ok = hipGetDevice(&c->device) == hipSuccess && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < EP_MAX_SPLIT; ++i)
+    ok = hipEventCreateWithFlags(&c->recv_ev[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->done_ev[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    tutel_set_error("tutel_amd_ep_comm_create_hosted: cannot create the side stream / event table");
+    (void)tutel_amd_ep_comm_destroy(c);
+    return -1;
+  }
+  *out = c;
+  return 0;
+}
+
 extern "C" int tutel_amd_ep_comm_destroy(tutel_amd_ep_comm_t *c) {
   if (c == nullptr) return 0;
   if (c->side_stream != nullptr) (void)hipStreamSynchronize(c->side_stream);
@@ -170,6 +193,11 @@ static int exchange(tutel_amd_ep_comm *c, const void *send, void *recv, size_t b
   StageScope scope(stage, st);
   if (c == nullptr) {  // single rank without a communicator: the exchange is a copy
     HIP_CHECK(hipMemcpyAsync(recv, send, bytes_per_peer * (size_t)world, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+    return 0;
+  }
+  if (c->hosted != nullptr) {  // bring-up / test communicator
+    const int rc = c->hosted(c->hosted_user, send, recv, bytes_per_peer, world);
+    TUTEL_REQUIRE(rc == 0, "tutel_amd_ep_forward: the host exchange callback failed (%d)", rc);
     return 0;
   }
   if ((bytes_per_peer & 1) == 0)

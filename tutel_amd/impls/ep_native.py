@@ -26,6 +26,7 @@ from .. import _lib, ops
 
 ENABLED = int(os.environ.get("TUTEL_AMD_NATIVE_EP", "1")) != 0
 FAST_PATH = int(os.environ.get("TUTEL_AMD_FAST_PATH", "1")) != 0  # routing + pipeline in one call (tutel_amd_moe_forward)
+HOSTED = int(os.environ.get("TUTEL_AMD_NATIVE_HOSTED", "0")) != 0  # bring-up / tests: native pipeline over a gloo group, exchange staged by the host
 _FORCE_COMM = False  # test hook: run a single rank through a real 1-rank RCCL communicator (staged pipeline, both streams)
 _comms = {}      # id(group) / "world" -> EpComm | False (creation failed: do not retry)
 _zero_rows = {}
@@ -108,12 +109,46 @@ def _create(group, device):
     return comm
 
 
+def _create_hosted(group, device):
+    """communicator whose exchange is done by the host over `group` (gloo): the native pipeline with ranks that share a GPU"""
+    from . import communicate as C
+    L = _lib.lib()
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    bufs = []   # (base, nbytes, uint8 view) of the tensors exchanges may address -- registered by the workspaces
+
+    def find(ptr, nbytes):
+        for base, size, view in bufs:
+            if base <= ptr and ptr + nbytes <= base + size:
+                return view[ptr - base:ptr - base + nbytes]
+        raise _lib.TutelAmdError("hosted exchange: pointer outside the registered workspace")
+
+    def cb(_user, send, recv, per_peer, world):
+        try:
+            n = int(per_peer) * int(world)
+            C.exchange_equal_split(find(int(recv), n), find(int(send), n), group)   # device -> host -> gloo -> device, on the current stream
+            return 0
+        except Exception as ex:  # noqa: BLE001
+            logging.error("tutel_amd: hosted exchange failed: %s", ex)
+            return 1
+    fn = _lib.EXCHANGE_FN(cb)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _lib.check(L.tutel_amd_ep_comm_create_hosted(W, rank, ctypes.cast(fn, ctypes.c_void_p), None, ctypes.byref(handle)),
+                   "tutel_amd_ep_comm_create_hosted")
+    comm = EpComm(handle, W, rank)
+    comm._keep, comm.register = fn, lambda t: bufs.append((t.data_ptr(), t.numel() * t.element_size(), t.view(-1).view(torch.uint8)))
+    return comm
+
+
 def communicator(group, device):
     """EpComm of `group` (created on first use; collective), or None when the native path is unavailable."""
     key = id(group) if group is not None else "world"
     c = _comms.get(key)
     if c is None:
-        c = _create(group, device) or False
+        if HOSTED and dist.get_backend(group) != "nccl":
+            c = _create_hosted(group, device)
+        else:
+            c = _create(group, device) or False
         _comms[key] = c
     return c or None
 
@@ -141,7 +176,7 @@ def usable(layer, x, crit, degree):
     if getattr(layer, "megablocks_size", 0) > 0 and (W > 1 or not layer.is_postscore):
         return False  # row counts ride on the single-rank fused-encode route only
     if W > 1:
-        if not dist.is_initialized() or dist.get_backend(layer.group) != "nccl":
+        if not dist.is_initialized() or (dist.get_backend(layer.group) != "nccl" and not HOSTED):
             return False  # gloo rendezvous (ranks sharing a GPU in the tests): host-staged exchange in impls/overlap.py
     return crit[4] % max(degree, 1) == 0 and degree <= 32
 
@@ -180,6 +215,9 @@ class _Workspace:
             self.bufs["zero_row"] = z
             a.zero_row = z.data_ptr()
         self.args, self.comm = a, comm
+        if comm is not None and hasattr(comm, "register"):
+            for t in self.bufs.values():
+                comm.register(t)
 
 
 def forward(layer, x, crit, degree):

@@ -241,7 +241,7 @@ class MOELayer(torch.nn.Module):
                 or (degree > 1 and self.use_2dh) or degree > 32 or (self.training and gate.gate_noise > 0)
                 or not self.experts.can_fuse(x, self)):
             return None
-        if self.world_size > 1 and not (dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
+        if self.world_size > 1 and not (dist.is_initialized() and (dist.get_backend(self.group) == "nccl" or ep_native.HOSTED)):
             return None
         with torch.autocast("cuda", enabled=False):
             logits = gate(x)
