@@ -10,17 +10,17 @@ import test_ep_ranks_one_gpu as T  # noqa: E402
 
 
 def main():
-    for degree, E_loc in ((2, 2), (1, 1), (2, 1)):
+    for degree, E_loc, native in ((2, 2, True), (1, 1, True), (2, 1, True), (2, 8, True), (2, 2, False)):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = T._free_port()
-        procs = [ctx.Process(target=T._worker, args=(r, 8, port, degree, E_loc, q)) for r in range(8)]
+        procs = [ctx.Process(target=T._worker, args=(r, 8, port, degree, E_loc, q, None, native)) for r in range(8)]
         for p in procs:
             p.start()
         res = [q.get(timeout=600) for _ in procs]
         for p in procs:
             p.join(timeout=60)
-        print("world 8, degree", degree, "E_loc", E_loc, "->", all(r[1] for r in res), sorted(set(r[2][:60] for r in res))[:2], flush=True)
+        print("world 8, degree", degree, "E_loc", E_loc, "native one-call pipeline" if native else "python-orchestrated", "->", all(r[1] for r in res), sorted(set(r[2][:60] for r in res))[:2], flush=True)
 
 
 if __name__ == "__main__":
