@@ -234,9 +234,11 @@ def _free_port():
     return p
 
 
-def _ep_worker(rank, world, port, degree, use_2dh, q):
+def _ep_worker(rank, world, port, degree, use_2dh, q, local_size=0):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        if local_size:
+            os.environ["LOCAL_SIZE"] = str(local_size)   # "nodes" of local_size ranks: the 2DH exchange runs its two phases
         import sys
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -294,6 +296,22 @@ def test_expert_parallel_world2_gloo(degree, use_2dh):
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, info in res:
+        assert ok, f"rank {rank}: {info}"
+
+
+def test_hierarchical_all_to_all_world4_two_nodes_of_two_gloo():
+    """use_2dh with LOCAL_SIZE=2 on 4 ranks: the intra-node then inter-node exchange (communicate.py:412-430) must equal the
+    flat all-to-all (the reference's test_a2a_algos, test_tutel.py:178-209) -- as a collective and through the layer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ep_worker, args=(r, 4, port, 1, True, q, 2)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, ok, info in res:
