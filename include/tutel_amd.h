@@ -351,7 +351,6 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *                        (automatic: > 128 rows per expert and enough tiles to cover the chip) */
 #define TUTEL_OPT_GEMM_IMPL 0
 #define TUTEL_OPT_GEMM_TILE 1
-#define TUTEL_OPT_GEMM_ABL 2 /* dev only: ablation variant of the ping-pong kernel (timing experiments; results invalid) */
 int tutel_amd_set_option(int key, int value);
 
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------

@@ -11,65 +11,7 @@ from tutel_amd import ops, _lib  # noqa: E402
 VARIANTS = (("256x256", 1), ("pingpong", 4), ("256x128", 3), ("128", 0))
 
 
-def ablation():
-    """time the ping-pong kernel with parts removed (results are garbage; only the durations mean something)"""
-    g = torch.Generator().manual_seed(0)
-    for El, R, N, K in [(8, 1024, 2048, 2048), (8, 1024, 4096, 4096)]:
-        a = torch.randn([El, R, K], generator=g).bfloat16().cuda()
-        w = (torch.randn([El, N, K], generator=g) / K ** 0.5).bfloat16().cuda()
-        b = torch.randn([El, N], generator=g).bfloat16().cuda()
-        ops.set_option(_lib.OPT_GEMM_TILE, 4)
-        res = {}
-        names = {0: "full", 1: "no DMA", 2: "no frag reads", 3: "no DMA, no reads", 4: "no epilogue", 7: "MFMA + barriers only",
-                 8: "no setprio", 16: "no stagger", 256: "direct-store epilogue"}
-        for rep in range(3):
-            for abl, name in names.items():
-                ops.set_option(_lib.OPT_GEMM_ABL, abl)
-                fn = lambda: ops.expert_gemm(a, w, b, True, act="relu")  # noqa: E731
-                for _ in range(10):
-                    fn()
-                torch.cuda.synchronize()
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                for _ in range(50):
-                    fn()
-                e.record()
-                torch.cuda.synchronize()
-                res.setdefault(name, []).append(round(s.elapsed_time(e) * 20, 1))
-        ops.set_option(_lib.OPT_GEMM_ABL, 0)
-        ops.set_option(_lib.OPT_GEMM_TILE, -1)
-        print(f"{El}x{R}x{N}x{K} ablation (us):", res, flush=True)
-
-
-def timeline():
-    """per-wave cycle sums of the phase segments (s_memtime instrumentation, ABL 128)"""
-    g = torch.Generator().manual_seed(0)
-    El, R, N, K = 8, 1024, 2048, 2048
-    a = torch.randn([El, R, K], generator=g).bfloat16().cuda()
-    w = (torch.randn([El, N, K], generator=g) / K ** 0.5).bfloat16().cuda()
-    b = torch.randn([El, N], generator=g).bfloat16().cuda()
-    ops.set_option(_lib.OPT_GEMM_TILE, 4)
-    for abl in (128, 144):
-        ops.set_option(_lib.OPT_GEMM_ABL, abl)
-        dbg = torch.zeros([16 * 8], dtype=torch.int32, device="cuda")
-        out = torch.empty([El, R, N], dtype=torch.bfloat16, device="cuda")
-        for _ in range(3):
-            ops.expert_gemm(a, w, b, True, act="relu", out=out, d_layout=(R * N, 0, R, N), mul=dbg.view(torch.bfloat16))
-        torch.cuda.synchronize()
-        d = dbg.view(16, 8).cpu().tolist()
-        nph = (K // 64) * 4
-        print("ABL", abl, "(144 = no stagger): per phase cycles [DMA issue, reads+vmcnt+barrier1+lgkm, 8 MFMA issue, barrier2] | phase-0 seg1 | total")
-        for i, row in enumerate(d):
-            print("  block", 0 if i < 8 else 100, "wave", i % 8, [round(v / nph, 1) for v in row[:4]], round(row[4] / (K // 64), 1), row[5], flush=True)
-    ops.set_option(_lib.OPT_GEMM_ABL, 0)
-    ops.set_option(_lib.OPT_GEMM_TILE, -1)
-
-
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "abl":
-        return ablation()
-    if len(sys.argv) > 1 and sys.argv[1] == "timeline":
-        return timeline()
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     g = torch.Generator().manual_seed(0)
     shapes = [(8, 1024, 2048, 2048), (8, 1024, 4096, 4096), (32, 256, 2048, 2048), (16, 512, 2048, 2048), (64, 160, 2048, 2048),

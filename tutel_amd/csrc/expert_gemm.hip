@@ -894,9 +894,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
 // -------------------------------------------------------------------------------------------
 #define PP_BUF (4 * GL_STAGE)   // elements per LDS K-tile buffer: [256][64] tokens + [256][64] weights = 64 KB
 
-// ABL: ablation bits for on-hardware timing experiments (tools/pp_probe.py abl); 0 in the product.
-//   1 no LDS-DMA in the loop   2 no fragment reads   4 no epilogue   8 no s_setprio   16 no stagger (groups in lockstep)
-template <typename T, int ACT, bool W_ONCE, int ABL = 0, bool RAGGED = false>
+template <typename T, int ACT, bool W_ONCE, bool RAGGED = false>
 __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t *lds = reinterpret_cast<uint16_t *>(smem);  // [2][ tokens 2*GL_STAGE | weights 2*GL_STAGE ]
@@ -1016,32 +1014,12 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     bdma16<W_ONCE>(rs_w, w_off[2 * (HALF) + 1], ko_, d_ + 512);                          \
   } while (0)
 
-#define PP_NOW(T)                                                                         \
-  unsigned long long T = 0;                                                              \
-  if (ABL & 128) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T)::"memory")
-  unsigned seg[5] = {0, 0, 0, 0, 0};
-  PP_NOW(tstart);
   u32x4 fa[4][2], fw[4];
-  if (ABL & 2) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      fw[kk] = u32x4{0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-      fa[kk][0] = fw[kk]; fa[kk][1] = fw[kk];
-    }
-  }
   // one phase: [DMA issue] [fragment reads] [counted DMA wait] barrier [8 MFMAs at raised priority] barrier
 #define PP_PHASE(MODE, Q, BUF, STEADY, ISSUE)                                                  \
   do {                                                                                   \
-    PP_NOW(t0_);                                                                         \
-    if (!(ABL & 1)) { ISSUE; }                                                           \
-    PP_NOW(t1_);                                                                         \
+    { ISSUE; }                                                                           \
     const uint16_t *cb_ = lds + (BUF) * PP_BUF;                                          \
-    if (ABL & 2) {                                                                       \
-      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                 \
-        asm volatile("" : "+v"(fw[kk]));                                                 \
-        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) asm volatile("" : "+v"(fa[kk][mi])); \
-      }                                                                                  \
-    } else {                                                                             \
     if ((Q) == 0) {                                                                      \
       _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                   \
         _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
@@ -1049,15 +1027,13 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     }                                                                                    \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                     \
       fw[kk] = *reinterpret_cast<const u32x4 *>(cb_ + w_row + (Q) * 64 * GL_BK + frag_k[kk]); \
-    }                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                   \
-    if ((STEADY) && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         \
+    if (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                         \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
     __builtin_amdgcn_s_barrier();                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
-    PP_NOW(t2_);                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                   \
-    if (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);                                       \
+    __builtin_amdgcn_s_setprio(1);                                                       \
     if ((MODE) == 2) {                                                                   \
       _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                   \
         _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                 \
@@ -1066,16 +1042,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
       _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                   \
         acc[Q][0] = Mma<T>::run(fw[kk], fa[kk][0], acc[Q][0]);                           \
     }                                                                                    \
-    if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);                                       \
+    __builtin_amdgcn_s_setprio(0);                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                   \
-    PP_NOW(t3_);                                                                         \
     __builtin_amdgcn_s_barrier();                                                        \
-    PP_NOW(t4_);                                                                         \
-    if (ABL & 128) {                                                                     \
-      seg[0] += (unsigned)(t1_ - t0_); seg[1] += (unsigned)(t2_ - t1_);                  \
-      seg[2] += (unsigned)(t3_ - t2_); seg[3] += (unsigned)(t4_ - t3_);                  \
-      if ((Q) == 0) seg[4] += (unsigned)(t2_ - t1_);                                     \
-    }                                                                                    \
   } while (0)
 
   // ---- prologue: tiles 0 (tokens + weights) and 1 (tokens) in flight; wait for tile 0 only
@@ -1088,7 +1057,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  if (wid >= 4 && !(ABL & 16)) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier interval behind group 0
+  if (wid >= 4) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier interval behind group 0
 
   // the K loop, as a macro over MODE = number of live 32-row groups of this wave (2: both, 1: the first, 0: none)
 #define PP_MAINLOOP(MODE)                                                                \
@@ -1122,43 +1091,14 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   else if (mi_on[0]) PP_MAINLOOP(1);
   else PP_MAINLOOP(0);
 #undef PP_MAINLOOP
-  if (wid < 4 && !(ABL & 16)) __builtin_amdgcn_s_barrier();  // group 0 catches up: equal barrier counts for all waves
+  if (wid < 4) __builtin_amdgcn_s_barrier();  // group 0 catches up: equal barrier counts for all waves
 #undef PP_PHASE
 #undef PP_ISSUE_A
 #undef PP_ISSUE_W
 #undef PP_KOFF
 
-  if (ABL & 128) {  // timing instrumentation: per-wave segment sums (cycles) -> debug buffer passed in p.mul
-    PP_NOW(tend);
-    if (lane == 0 && p.mul != nullptr && (blockIdx.x == 0 || blockIdx.x == 100)) {
-      unsigned *dbg = reinterpret_cast<unsigned *>(const_cast<void *>(p.mul)) + ((blockIdx.x ? 8 : 0) + wid) * 8;
-      for (int i = 0; i < 5; ++i) dbg[i] = seg[i];
-      dbg[5] = (unsigned)(tend - tstart);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += acc[i][jj][r];
-    if (sum == 12345.678f) reinterpret_cast<uint16_t *>(p.D)[tid] = 1;
-    return;
-  }
-#undef PP_NOW
-  if (ABL & 4) {  // keep the accumulators alive, store one element per lane
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += acc[i][jj][r];
-    if (sum == 12345.678f) reinterpret_cast<uint16_t *>(p.D)[tid] = 1;
-    return;
-  }
   GM_PRELOAD_BIAS_N(4);
-  if ((ABL & 256) || (p.ldd & 7) || (p.d_stride_e & 7) || (p.d_stride_w & 7) || (reinterpret_cast<uintptr_t>(p.D) & 15)) {
+  if ((p.ldd & 7) || (p.d_stride_e & 7) || (p.d_stride_w & 7) || (reinterpret_cast<uintptr_t>(p.D) & 15)) {
     gemm_epilogue<T, ACT, 4>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);  // rows not 16-byte aligned
     return;
   }
@@ -1166,11 +1106,11 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   gemm_epilogue_lds<T, ACT>(p, acc, bias_r, smem + wid * (64 * EP_PITCH), e, m0, n0, wm, wn, lane, row_limit);
 }
 
-template <typename T, int ACT, bool W_ONCE, int ABL = 0, bool RAGGED = false>
+template <typename T, int ACT, bool W_ONCE, bool RAGGED = false>
 static int launch_pp_cfg(const GemmArgs &b, hipStream_t st) {
   const size_t lds = (size_t)8 * 64 * EP_PITCH;  // 136 KB: the epilogue staging (8 waves x 64 rows x 272 B) > the two K-tile buffers (128 KB)
   static_assert((size_t)8 * 64 * EP_PITCH >= (size_t)2 * PP_BUF * 2, "LDS request must cover the K-tile buffers");
-  auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, ABL, RAGGED>;
+  auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, RAGGED>;
   static bool optin = false;
   if (!optin) {
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1187,27 +1127,12 @@ static int launch_pp(const GemmArgs &a, hipStream_t st) {
   GemmArgs b = a;
   b.ntm = (a.R + GB_BM - 1) / GB_BM;
   b.ntn = (a.N + 255) / 256;
-  if (ACT == TUTEL_ACT_RELU && sizeof(T) == 2) {  // ablation variants (dev only): bf16/fp16 + relu
-    switch (tutel_get_option(TUTEL_OPT_GEMM_ABL)) {
-      case 1: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 1>(b, st);
-      case 2: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 2>(b, st);
-      case 3: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 3>(b, st);
-      case 4: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 4>(b, st);
-      case 7: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 7>(b, st);
-      case 8: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 8>(b, st);
-      case 16: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 16>(b, st);
-      case 128: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 128>(b, st);
-      case 144: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 144>(b, st);
-      case 256: return launch_pp_cfg<T, TUTEL_ACT_RELU, false, 256>(b, st);
-      default: break;
-    }
-  }
   // a last M-tile with >= 32 padding rows, or per-expert row counts: the variant that skips padded 32-row groups
   const int tail_rows = b.R % GB_BM;
   const bool ragged = b.row_counts != nullptr || (tail_rows != 0 && tail_rows <= GB_BM - 32);
   if (b.ntm == 1 && (long long)b.E_loc * b.ntn >= 256)
-    return ragged ? launch_pp_cfg<T, ACT, true, 0, true>(b, st) : launch_pp_cfg<T, ACT, true>(b, st);
-  return ragged ? launch_pp_cfg<T, ACT, false, 0, true>(b, st) : launch_pp_cfg<T, ACT, false>(b, st);
+    return ragged ? launch_pp_cfg<T, ACT, true, true>(b, st) : launch_pp_cfg<T, ACT, true>(b, st);
+  return ragged ? launch_pp_cfg<T, ACT, false, true>(b, st) : launch_pp_cfg<T, ACT, false>(b, st);
 }
 
 template <typename T, bool KM, int ACT, int NI, int NS = 2, bool BUF = false>
