@@ -381,6 +381,21 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
   const int t0 = b * tile, t1 = min(Tn, t0 + tile);
   const int kE = k * E;
 
+  // 0. loads that depend on nothing computed here go out first, so that their round trip overlaps the one of step 1
+  //    instead of following it: this wave's first 64 expert ids (step 3) and, in block 0, a thread's share of the
+  //    per-tile score column sums (step 4).  Same values, same summation order as loading them in place.
+  int e_first = -1;
+  if (wid < k && t0 + lane < t1) e_first = idx[(size_t)wid * Tn + t0 + lane];
+  const int cs_parts = (E >= RT_THREADS) ? 1 : (RT_THREADS / E);
+  const int cs_per = (ntiles + cs_parts - 1) / cs_parts;
+  const bool cs_early = b == 0 && l_aux != nullptr && cs_parts * E <= RT_THREADS;  // one (expert, part) per thread
+  float cs_first[16];
+  if (cs_early && tid < cs_parts * E) {
+    const int e = tid % E, a = (tid / E) * cs_per, z = min(ntiles, a + cs_per);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) cs_first[u] = (a + u < z) ? ws_colsum[(size_t)(a + u) * E + e] : 0.f;
+  }
+
   // 1. base[j][e] = sum over earlier tiles, tot[j][e] = sum over all tiles.  The tile axis is
   //    split over the waves and unrolled so the (<=128) dependent-free L2 loads overlap.
   for (int i = tid; i < kE; i += RT_THREADS) { s_cur[i] = 0; s_tot[i] = 0; }
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
     int32_t *cur = s_cur + j * E;
     for (int c0 = t0; c0 < t1; c0 += 64) {
       int t = c0 + lane;
-      int e = (t < t1) ? idx[(size_t)j * Tn + t] : -1;
+      int e = (j == wid && c0 == t0) ? e_first : ((t < t1) ? idx[(size_t)j * Tn + t] : -1);
       bool valid = (e >= 0) && (e < E);
       // lanes holding the same expert: AND over the bits of the expert id of (ballot of that bit,
       // complemented where my bit is 0) -- ceil(log2 E) ballots instead of one loop iteration per
@@ -459,8 +474,7 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
     if (l_aux != nullptr) {
       float *s_me = reinterpret_cast<float *>(s_cur);  // s_cur is dead after step 3 (k*E >= E floats)
       __syncthreads();
-      const int parts = (E >= RT_THREADS) ? 1 : (RT_THREADS / E);
-      const int per = (ntiles + parts - 1) / parts;
+      const int parts = cs_parts, per = cs_per;
       float *s_parts = reinterpret_cast<float *>(smem) + (size_t)2 * kE;  // [parts][E], see launch
       for (int w = tid; w < parts * E; w += RT_THREADS) {
         const int e = w % E, pt = w / E;
@@ -469,7 +483,8 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
         for (int tl0 = a; tl0 < z; tl0 += 16) {
           float cs[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) cs[u] = (tl0 + u < z) ? ws_colsum[(size_t)(tl0 + u) * E + e] : 0.f;
+          for (int u = 0; u < 16; ++u)
+            cs[u] = (cs_early && tl0 == a) ? cs_first[u] : ((tl0 + u < z) ? ws_colsum[(size_t)(tl0 + u) * E + e] : 0.f);
 #pragma unroll
           for (int u = 0; u < 16; ++u) me += cs[u];
         }
