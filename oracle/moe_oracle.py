@@ -15,7 +15,10 @@ How it is pinned (so that "parity" means parity with the reference, not with our
     package from /root/reference + its C++ CPU kernels compiled into oracle/_ref/ by
     oracle/Makefile) and checks every function below against it on seeded inputs;
   * tests/golden/*.npz are outputs of that reference (generator tests/golden/make_golden.py)
-    and are replayed against this oracle on any box (tests/test_oracle_golden.py).
+    and are replayed against this oracle on any box (tests/test_oracle_golden.py);
+  * the reference's own golden-loss file tests/test_baseline.json (head committed as
+    tests/golden/reference_baseline_losses.json): losses[0] of its 9 entries, a forward-only quantity,
+    is reproduced from helloworld's seeds by helloworld_problem() + moe_forward() below.
 
 Arithmetic split: integer/index work and the scatter/gather loops are plain C
 (oracle/moe_oracle.c via ctypes); softmax / matmul / dtype rounding use torch-CPU ATen ops,
@@ -346,6 +349,39 @@ def make_problem(T, M, H, E, dtype=torch.float32, seed=0, out_dim=None):
     w2 = uni([E, H, out_dim], 1 / math.sqrt(H))
     b2 = uni([E, out_dim], 1 / math.sqrt(H))
     return [t.to(dtype) for t in (x, wg, w1, b1, w2, b2)]
+
+
+def helloworld_problem(batch, tokens, M, H, E_loc, dtype=torch.float32, rank=0, world=1):
+    """The inputs tutel/examples/helloworld.py builds for rank `rank`: x [batch, tokens, M], wg [E, M], w1 [E_loc, H, M],
+    b1 [E_loc, H], w2 [E_loc, H, M], b2 [E_loc, M] -- the seeds the script passes (`seeds=(1, rank + 1, 1)`, helloworld.py:81),
+    consumed as MOELayer.__init__ does (expert weights under seeds[1], moe_layer.py:157-158; gate under seeds[0], :211-212),
+    the per-expert nn.Linear draws of FusedExpertsNetwork.reset_parameters (ffn.py:39-49), the default dtype the script
+    sets (helloworld.py:60-67) and its tokens (manual_seed(0), fp32 randn on the CPU cast to dtype, :112-113).
+    This is what makes the losses of the reference's own tests/test_baseline.json (test_tutel.py:94-152) reproducible."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        torch.manual_seed(rank + 1)
+        w1, b1, w2, b2 = [], [], [], []
+        for _ in range(E_loc):
+            fc1, fc2 = torch.nn.Linear(M, H), torch.nn.Linear(H, M)
+            w1.append(fc1.weight.detach())
+            b1.append(fc1.bias.detach())
+            w2.append(fc2.weight.detach().t())
+            b2.append(fc2.bias.detach())
+        torch.manual_seed(1)
+        wg = torch.nn.Linear(M, E_loc * world, bias=False).weight.detach()
+        torch.manual_seed(0)
+        x = torch.randn([batch, tokens, M], dtype=torch.float32).to(dtype)
+    finally:
+        torch.set_default_dtype(old)
+    return x, wg, torch.stack(w1), torch.stack(b1), torch.stack(w2), torch.stack(b2)
+
+
+def helloworld_loss(y):
+    """helloworld.py:97,114,132: nll_loss(log_softmax(sum over the model dim), target 0)"""
+    out = torch.log_softmax(torch.sum(y, dim=2), dim=1)
+    return torch.nn.functional.nll_loss(out, torch.zeros(y.shape[0], dtype=torch.long))
 
 
 def make_problem_ext(T, M, H, E, P=32, dtype=torch.float32, seed=0):

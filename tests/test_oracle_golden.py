@@ -104,3 +104,32 @@ def test_oracle_cosine_gate_llama_expert_matches_reference_fixture(oracle, path)
     assert torch.equal(torch.stack(crit[3]), _t(z["gates"], gdt)) and crit[4] == int(z["capacity"][0])
     assert float(l_aux) == float(z["l_aux"][0])
     assert torch.equal(y, _t(z["y"], dtype))
+
+
+# ---- the reference's OWN golden file: tests/test_baseline.json (head committed as reference_baseline_losses.json) ----
+def _baseline_cases():
+    import json
+    return json.load(open(os.path.join(GOLD, "reference_baseline_losses.json")))["cases"]
+
+
+def _ref_round(v, dtype):
+    return round(float(v), 3 if "32" in dtype else 1)   # test_tutel.py:52-63,79-83
+
+
+@pytest.mark.parametrize("case", _baseline_cases(), ids=lambda c: "top%d_%s_e%d" % (c["top"], c["dtype"], c["num_local_experts"]))
+def test_oracle_reproduces_first_loss_of_reference_baseline(oracle, case):
+    """losses[0] of each of the 9 entries is a pure FORWARD quantity of the untrained layer: helloworld's seeded weights and
+    tokens through the oracle's forward, helloworld's loss, compared at the reference test's own rounding (and to 2e-5
+    relative for fp32 / 1e-12 for fp64 -- the file was written by GPUs, this runs on CPU BLAS)."""
+    dtype = DT[case["dtype"]]
+    x, wg, w1, b1, w2, b2 = oracle.helloworld_problem(case["batch_size"], case["num_tokens"], case["model_dim"], case["hidden_size"],
+                                                      case["num_local_experts"], dtype)
+    with torch.no_grad():
+        y, _, crit, _ = oracle.moe_forward(x, wg, w1, b1, w2, b2, top_k=case["top"], capacity_factor=1.0)
+        loss = float(oracle.helloworld_loss(y))
+    want = float(case["losses"][0])
+    assert _ref_round(loss, case["dtype"]) == _ref_round(want, case["dtype"]), (loss, want)
+    if case["dtype"] == "float32":
+        assert abs(loss - want) <= 2e-5 * abs(want), (loss, want)
+    elif case["dtype"] == "float64":
+        assert abs(loss - want) <= 1e-12 * abs(want), (loss, want)
