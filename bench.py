@@ -126,13 +126,13 @@ def run_timed(step, x, steps, world, timer_gate, mode=2, marks=True):
     """exactly `steps` steps between barrier + synchronize pairs; returns (elapsed_s, per-step ms list, stage report).
     mode 2: HIP events around the two expert GEMMs only (the timed region); mode 1: around every launch (breakdown pass)."""
     from tutel_amd import ops
+    ops.stage_timing(mode)          # (host-side setup first: nothing but the clock read stands between the synchronize
+    timer_gate.on = mode == 1       #  that closes the bracket and the first step -- event creation takes ~0.2 ms, long
+    ops.marks_reserve(steps + 1)    #  enough for an idle GPU to drop its clocks)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.stage_timing(mode)
-    timer_gate.on = mode == 1
-    ops.marks_reserve(steps + 1)
     t0 = time.perf_counter()
     if marks:
         ops.mark()
