@@ -186,6 +186,7 @@ def main():
     share = os.environ.get("TUTEL_AMD_BENCH_SHARE_GPU", "0") == "1"
     if share:
         local_rank = 0
+    local_rank %= max(1, torch.cuda.device_count())   # a launcher that hands every rank ONE visible device numbers it 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
