@@ -1,0 +1,53 @@
+"""Which clock moves with the operand data?  Runs the headline grouped GEMM in a loop for ~2 s with random and with zero tokens
+while sampling `rocm-smi --showclocks --showpower` (read-only).  python tools/clock_watch_probe.py"""
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tutel_amd import ops  # noqa: E402
+
+
+def sample(stop, out):
+    while not stop.is_set():
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True)
+        keep = [l.strip() for l in r.stdout.splitlines() if any(k in l for k in ("sclk", "mclk", "fclk", "socclk", "Power"))]
+        out.append(" | ".join(k.split(":", 1)[-1].strip() if "GPU[" in k else k for k in keep))
+        time.sleep(0.25)
+
+
+def main():
+    E, R, N, K = 64, 128, 2048, 2048
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn([E, N, K], generator=g) / K ** 0.5).bfloat16().cuda()
+    b = torch.zeros([E, N], dtype=torch.bfloat16, device="cuda")
+    for name, t in (("random tokens", torch.randn([E, R, K], generator=g).bfloat16().cuda()),
+                    ("zero tokens", torch.zeros([E, R, K], dtype=torch.bfloat16, device="cuda")),
+                    ("random tokens", torch.randn([E, R, K], generator=g).bfloat16().cuda())):
+        stop, out = threading.Event(), []
+        th = threading.Thread(target=sample, args=(stop, out))
+        th.start()
+        t0 = time.time()
+        n = 0
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        while time.time() - t0 < 2.5:
+            for _ in range(200):
+                ops.expert_gemm(t, w, b, True, act="relu")
+            n += 200
+            torch.cuda.synchronize()
+        e.record()
+        torch.cuda.synchronize()
+        stop.set()
+        th.join()
+        print(f"== {name}: {s.elapsed_time(e) * 1e3 / n:.2f} us per launch (incl. sync gaps), {n} launches", flush=True)
+        for l in out[2:8]:
+            print("   ", l, flush=True)
+
+
+if __name__ == "__main__":
+    main()
