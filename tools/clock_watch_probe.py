@@ -20,7 +20,45 @@ def sample(stop, out):
         time.sleep(0.25)
 
 
+def watch(name, fn, seconds=2.5, per=200):
+    stop, out = threading.Event(), []
+    th = threading.Thread(target=sample, args=(stop, out))
+    th.start()
+    t0 = time.time()
+    n = 0
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    while time.time() - t0 < seconds:
+        for _ in range(per):
+            fn()
+        n += per
+        torch.cuda.synchronize()
+    e.record()
+    torch.cuda.synchronize()
+    stop.set()
+    th.join()
+    print(f"== {name}: {s.elapsed_time(e) * 1e3 / n:.2f} us per launch (incl. sync gaps), {n} launches", flush=True)
+    for l in out[2:6]:
+        print("   ", l, flush=True)
+
+
+def big():
+    """the MFMA-bound per-rank shape of an 8-way expert-parallel run: the ping-pong kernel vs torch.bmm (hipBLASLt)"""
+    E, R, N, K = 8, 1024, 2048, 2048
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn([E, R, K], generator=g).bfloat16().cuda()
+    w = (torch.randn([E, N, K], generator=g) / K ** 0.5).bfloat16().cuda()
+    wt = w.transpose(1, 2).contiguous()
+    b = torch.zeros([E, N], dtype=torch.bfloat16, device="cuda")
+    for name, fn in (("expert_gemm_pp_kernel 8x1024x2048x2048", lambda: ops.expert_gemm(a, w, b, True, act="relu")),
+                     ("torch.bmm (hipBLASLt), same shape", lambda: torch.matmul(a, wt)),
+                     ("expert_gemm_pp_kernel again", lambda: ops.expert_gemm(a, w, b, True, act="relu"))):
+        watch(name, fn)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        return big()
     E, R, N, K = 64, 128, 2048, 2048
     g = torch.Generator().manual_seed(0)
     w = (torch.randn([E, N, K], generator=g) / K ** 0.5).bfloat16().cuda()
