@@ -56,9 +56,27 @@ def big():
         watch(name, fn)
 
 
+def impls():
+    """the headline shape on the two 128-tile kernels (register-staged vs LDS-DMA), sustained"""
+    from tutel_amd import _lib
+    E, R, N, K = 64, 128, 2048, 2048
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn([E, R, K], generator=g).bfloat16().cuda()
+    w = (torch.randn([E, N, K], generator=g) / K ** 0.5).bfloat16().cuda()
+    b = torch.zeros([E, N], dtype=torch.bfloat16, device="cuda")
+    wt = w.transpose(1, 2).contiguous()
+    for name, impl in (("LDS-DMA kernel", 1), ("register-staged kernel", 0), ("LDS-DMA kernel again", 1)):
+        ops.set_option(_lib.OPT_GEMM_IMPL, impl)
+        watch(name, lambda: ops.expert_gemm(a, w, b, True, act="relu"))
+    ops.set_option(_lib.OPT_GEMM_IMPL, -1)
+    watch("torch.bmm (hipBLASLt, no bias / relu)", lambda: torch.matmul(a, wt))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "big":
         return big()
+    if len(sys.argv) > 1 and sys.argv[1] == "impls":
+        return impls()
     E, R, N, K = 64, 128, 2048, 2048
     g = torch.Generator().manual_seed(0)
     w = (torch.randn([E, N, K], generator=g) / K ** 0.5).bfloat16().cuda()
