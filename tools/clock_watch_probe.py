@@ -72,7 +72,23 @@ def impls():
     watch("torch.bmm (hipBLASLt, no bias / relu)", lambda: torch.matmul(a, wt))
 
 
+def tiles():
+    """8 x 1024 x 2048 x 2048 on each 256-row kernel, sustained"""
+    from tutel_amd import _lib
+    E, R, N, K = 8, 1024, 2048, 2048
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn([E, R, K], generator=g).bfloat16().cuda()
+    w = (torch.randn([E, N, K], generator=g) / K ** 0.5).bfloat16().cuda()
+    b = torch.zeros([E, N], dtype=torch.bfloat16, device="cuda")
+    for name, t in (("256x256 ping-pong", 4), ("256x256 round-1 kernel", 1), ("256x128 ring of 3", 3), ("128x128 LDS-DMA", 0), ("256x256 ping-pong again", 4)):
+        ops.set_option(_lib.OPT_GEMM_TILE, t)
+        watch(name, lambda: ops.expert_gemm(a, w, b, True, act="relu"), seconds=2.0)
+    ops.set_option(_lib.OPT_GEMM_TILE, -1)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "tiles":
+        return tiles()
     if len(sys.argv) > 1 and sys.argv[1] == "big":
         return big()
     if len(sys.argv) > 1 and sys.argv[1] == "impls":
