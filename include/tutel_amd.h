@@ -238,6 +238,23 @@ int tutel_amd_ep_comm_info(const tutel_amd_ep_comm_t *comm, int *world, int *ran
 int tutel_amd_ep_all_to_all(tutel_amd_ep_comm_t *comm, const void *send, void *recv, size_t bytes_per_peer,
                             tutel_stream_t stream);
 
+/* Variable-size exchanges on the same communicator (tutel.net.batch_all_to_all_v / batch_all_gather_v; reference:
+ * custom_kernel.cpp:463-491 and :493-518, one grouped ncclSend / ncclRecv loop per tensor on the shared communicator).
+ *   all_to_all_v: send_bytes[r] bytes, taken from `send` at the running offset, go to rank r; recv_bytes[r] bytes from rank
+ *                 r land in `recv` at the running offset.  The caller has exchanged the sizes (the one host sync the
+ *                 reference API implies, communicate.py:225-241).
+ *   all_gather_v: my recv_bytes[<my rank>] bytes at `send` go to every rank; rank r's recv_bytes[r] bytes land in `recv`
+ *                 at the running offset (rank order).
+ * Byte counts are host arrays of `world` entries; zero-byte pairs are skipped on both sides.  Enqueued on `stream`.
+ * A hosted communicator performs them with the callback registered by tutel_amd_ep_comm_set_hosted_v. */
+typedef int (*tutel_amd_exchange_v_fn)(void *user, const void *send, void *recv, const uint64_t *send_bytes,
+                                       const uint64_t *send_offsets, const uint64_t *recv_bytes, int world);
+int tutel_amd_ep_comm_set_hosted_v(tutel_amd_ep_comm_t *comm, tutel_amd_exchange_v_fn fn);
+int tutel_amd_ep_all_to_all_v(tutel_amd_ep_comm_t *comm, const void *send, void *recv, const uint64_t *send_bytes,
+                              const uint64_t *recv_bytes, tutel_stream_t stream);
+int tutel_amd_ep_all_gather_v(tutel_amd_ep_comm_t *comm, const void *send, void *recv, const uint64_t *recv_bytes,
+                              tutel_stream_t stream);
+
 /* Stage layouts of the pipeline (identical to tutel_amd/impls/overlap.py::OverlapPlan; a CPU test pins it):
  *   sliced  (allow_sliced && E_loc % degree == 0): stages = groups of E_loc/degree local experts, buckets
  *           laid out [degree, W, s, C]; every expert's weights are streamed once per forward;

@@ -96,6 +96,22 @@ def gshard_loss(scores, idx0):
     return torch.sum(me * ce) / T
 
 
+def load_importance_loss(scores_wo_noise, topk_logits, E, gate_noise):
+    """Reference: losses.py:21-42.  l = (cv2(importance) + cv2(load)) / 2 with cv2(v) = var(v) / (mean(v)^2 + 1e-10)
+    (unbiased variance), importance[e] = sum_t scores[t,e], load[e] = sum_t Phi((scores[t,e] - thr[t]) / (gate_noise / E)),
+    thr[t] = the k-th (last) of the token's top-k NOISY LOGITS.  (The reference really does subtract a logit from a
+    probability -- restated as written.)  All in fp32; Phi through erf, as torch's Normal.cdf evaluates it."""
+    assert gate_noise > 0
+    s = scores_wo_noise.float()
+
+    def cv2(v):
+        return v.var() / (v.mean() ** 2 + 1e-10)
+    thr = topk_logits[:, -1].reshape(-1, 1).float()
+    sigma = torch.tensor([gate_noise / E], dtype=torch.float32)
+    load = (0.5 * (1 + torch.erf((s - thr) * sigma.reciprocal() / math.sqrt(2)))).sum(0)
+    return (cv2(s.sum(0)) + cv2(load)) / 2.0
+
+
 def capacity_of(T, E, k, capacity_factor, dispatch_count, alignment=1):
     """Reference: fast_dispatch.py:188-199 (single rank: the all-reduce MAX is the identity)."""
     spe = (T + E - 1) // E
@@ -112,11 +128,12 @@ def capacity_of(T, E, k, capacity_factor, dispatch_count, alignment=1):
 
 
 def extract_critical(scores, top_k, capacity_factor=1.0, normalize_gate=True, alignment=1,
-                     with_loss=True, topk_override=None):
+                     with_loss=True, topk_override=None, num_samples=None):
     """Reference: fast_dispatch.py:143-204 (batch_prioritized_routing=False).
     Returns ((E, idx_list, loc_list, gate_list, capacity, dispatch_count), l_aux).
     `topk_override`: inject the reference's own topk indices (used to compare everything
-    downstream of a tie independently of the tie rule)."""
+    downstream of a tie independently of the tie rule).  `num_samples`: the all-reduced MAX token count
+    of `inequivalent_tokens=True` (fast_dispatch.py:181-186) -- the capacity follows it, not the local T."""
     T, E = scores.shape
     k = min(top_k, E)
     idx_list = topk_override if topk_override is not None else topk_indices(scores, k)
@@ -127,7 +144,7 @@ def extract_critical(scores, top_k, capacity_factor=1.0, normalize_gate=True, al
     if k > 1 and normalize_gate:  # :173-175 -- python sum(): ((0 + g0) + g1) ... in scores dtype
         denom = torch.clamp(sum(gates), min=torch.finfo(gates[0].dtype).eps)
         gates = [g / denom for g in gates]
-    cap = capacity_of(T, E, k, capacity_factor, cnt, alignment)
+    cap = capacity_of(T if num_samples is None else num_samples, E, k, capacity_factor, cnt, alignment)
     return (E, idx_list, loc_list, gates, cap, cnt), l_aux
 
 
@@ -281,21 +298,30 @@ def a2a_combine(per_rank, C):
 # ---------------------------------------------------------------------------------------------
 def moe_forward(x, wg, w1, b1, w2, b2, top_k=2, capacity_factor=1.0, fp32_gate=False,
                 normalize_gate=True, is_postscore=True, act=torch.relu, alignment=1,
-                accum_fp32=False, topk_override=None, logits_fn=None, expert_fn=None):
+                accum_fp32=False, topk_override=None, logits_fn=None, expert_fn=None, noise=None,
+                gate_noise=0.0, is_gshard_loss=True):
     """Single-rank MOELayer.forward.  Reference: moe_layer.py:255-363 (dtype chain :264-270,
     :327, :359-361).  x [..., M] -> (y [..., M_out], l_aux, crit, stages dict).
     logits_fn(x[T,M]) -> logits replaces the linear gate (custom / cosine gates, moe_layer.py:283);
-    expert_fn(enc[E,C,M]) -> [E,C,M_out] replaces the ReLU FFN (custom / llama experts, :251)."""
+    expert_fn(enc[E,C,M]) -> [E,C,M_out] replaces the ReLU FFN (custom / llama experts, :251).
+    noise [T,E]: the randn_like draw of a TRAINING forward with gate_noise > 0 (:285-288; routed on
+    logits + gate_noise * noise / E); is_gshard_loss=False: the load-importance loss (:291-296)."""
     orig_shape, orig_dtype = x.shape, x.dtype
     M = orig_shape[-1]
     xr = x.reshape(-1, M).to(w1.dtype)
     if logits_fn is not None:
         logits = logits_fn(xr)
-        scores, logits_dtype = torch.softmax(logits, dim=1), logits.dtype
     else:
-        scores, logits_dtype = gate_scores(xr, wg, fp32_gate)
+        w = wg.float() if fp32_gate else wg
+        logits = torch.nn.functional.linear(xr.to(w.dtype), w)   # gates/top.py:20-22
+    logits_dtype = logits.dtype
+    noisy = logits if noise is None else logits + gate_noise * noise.to(logits.dtype) / logits.shape[1]
+    scores = torch.softmax(noisy, dim=1)
     crit, l_aux = extract_critical(scores, top_k, capacity_factor, normalize_gate, alignment,
                                    topk_override=topk_override)
+    if not is_gshard_loss:
+        ids = torch.stack(crit[1], dim=1).long()
+        l_aux = load_importance_loss(torch.softmax(logits, dim=1), noisy.gather(1, ids), logits.shape[1], gate_noise)
     enc = fast_encode(xr.to(logits_dtype), crit, is_postscore).to(xr.dtype)
     if expert_fn is not None:
         ffn = expert_fn(enc)
@@ -308,16 +334,19 @@ def moe_forward(x, wg, w1, b1, w2, b2, top_k=2, capacity_factor=1.0, fp32_gate=F
 
 def moe_forward_ep(xs, wg, w1s, b1s, w2s, b2s, top_k=2, capacity_factor=1.0, fp32_gate=False,
                    normalize_gate=True, is_postscore=True, act=torch.relu, alignment=1,
-                   accum_fp32=False):
+                   accum_fp32=False, inequivalent_tokens=False):
     """Expert-parallel forward with W ranks simulated in-process: xs[r] is rank r's [T,M]
     tokens, w1s[r] etc. rank r's local expert weights.  Reference: moe_layer.py:344-351 with
-    num_local_experts > 0 (E = E_loc*W, moe_layer.py:46-55)."""
+    num_local_experts > 0 (E = E_loc*W, moe_layer.py:46-55).  inequivalent_tokens: the ranks hold
+    different numbers of tokens and size their buckets from the largest (fast_dispatch.py:181-186)."""
     W = len(xs)
     crits, encs, ldt = [], [], None
+    n_max = max(int(x.shape[0]) for x in xs) if inequivalent_tokens else None
     for r in range(W):
         xr = xs[r].to(w1s[r].dtype)
         scores, ldt = gate_scores(xr, wg, fp32_gate)
-        crit, _ = extract_critical(scores, top_k, capacity_factor, normalize_gate, alignment)
+        crit, _ = extract_critical(scores, top_k, capacity_factor, normalize_gate, alignment, with_loss=xr.shape[0] > 0,
+                                   num_samples=n_max)
         crits.append(crit)
         encs.append(fast_encode(xr.to(ldt), crit, is_postscore).to(xr.dtype))
     C = crits[0][4]

@@ -198,6 +198,55 @@ def train_losses_case(E_loc=2, k=2, steps=4, T=1024, M=256, H=256, seed=5):
     return dict(losses=np.array(losses), meta=np.array([T, M, H, E_loc, k, steps, seed], dtype=np.int64))
 
 
+# gate noise + load-importance loss (moe_layer.py:285-296, losses.py:21-42):
+# (name, T, M, H, E, k, dtype, fp32_gate, gate_noise, training)
+NOISY_CASES = [
+    ("f32_noise1_loadimp_train", 512, 64, 32, 16, 2, "float32", False, 1.0, True),
+    ("f32_noise1_loadimp_eval", 512, 64, 32, 16, 2, "float32", False, 1.0, False),   # eval: no draw, the loss still uses gate_noise
+    ("bf16_noise2_loadimp_train_fp32gate", 384, 64, 64, 8, 2, "bfloat16", True, 2.0, True),
+]
+NOISE_SEED = 99
+
+
+def run_noisy_case(case, seed=2468):
+    """the reference layer with is_gshard_loss=False and gate_noise > 0; the draw of torch.randn_like(logits) is reproduced
+    from the seed set right before the forward and stored, so that any implementation can be fed the same noise"""
+    name, T, M, H, E, k, dts, fp32_gate, gate_noise, training = case
+    x, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=DT[dts], seed=seed)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(DT[dts])
+    try:
+        layer = ref_moe.moe_layer(
+            gate_type={"type": "top", "k": k, "fp32_gate": fp32_gate, "gate_noise": gate_noise},
+            experts={"type": "ffn", "num_experts_per_device": E, "hidden_size_per_expert": H,
+                     "activation_fn": lambda t: torch.nn.functional.relu(t)},
+            model_dim=M, is_gshard_loss=False)
+    finally:
+        torch.set_default_dtype(old)
+    with torch.no_grad():
+        layer.gates[0].wg.weight.copy_(wg.to(layer.gates[0].wg.weight.dtype))
+        layer.experts.batched_fc1_w.copy_(w1); layer.experts.batched_fc1_bias.copy_(b1)
+        layer.experts.batched_fc2_w.copy_(w2); layer.experts.batched_fc2_bias.copy_(b2)
+    layer.train(training)
+    with torch.no_grad():
+        logits = layer.gates[0](x)
+        torch.manual_seed(NOISE_SEED)
+        noise = torch.randn_like(logits)
+        torch.manual_seed(NOISE_SEED)
+        y = layer(x)
+    out = dict(meta=np.array([T, M, H, E, k, int(fp32_gate), int(training), seed], dtype=np.int64), dtype=np.array([dts]),
+               gate_noise=np.array([gate_noise]), in_checksum=np.array([checksum([x, wg, w1, b1, w2, b2])]),
+               noise=np_(noise), y=np_(y), l_aux=np.array([float(y.l_aux)]), dispatch_count=np_(layer.dispatch_count.to(torch.int32)))
+    return name, out, (layer, x, noise)
+
+
+def oracle_noisy_forward(case, noise, seed=2468):
+    name, T, M, H, E, k, dts, fp32_gate, gate_noise, training = case
+    x, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=DT[dts], seed=seed)
+    return O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k, fp32_gate=fp32_gate, noise=noise if training else None,
+                         gate_noise=gate_noise, is_gshard_loss=False)
+
+
 def check_oracle_against_reference():
     """Function-by-function comparison of oracle/ against the live reference."""
     bad = []
@@ -258,6 +307,13 @@ def check_oracle_against_reference():
             yr = layer(x)
         expect(torch.equal(yr, yo), f"cosine+llama layer output {name} maxdiff={(yr.double() - yo.double()).abs().max():.3e}")
         expect(float(yr.l_aux) == float(lo), f"cosine+llama l_aux {name}")
+    for case in NOISY_CASES:
+        name, out, (layer, x, noise) = run_noisy_case(case)
+        yo, lo, co, _ = oracle_noisy_forward(case, noise)
+        expect(torch.equal(torch.from_numpy(out["dispatch_count"]), co[5]), f"noisy-gate routing {name}")
+        yr = torch.from_numpy(out["y"]).view(torch.bfloat16) if case[6] == "bfloat16" else torch.from_numpy(out["y"])
+        expect(torch.equal(yr, yo), f"noisy-gate layer output {name} maxdiff={(yr.double() - yo.double()).abs().max():.3e}")
+        expect(abs(float(out["l_aux"][0]) - float(lo)) <= 1e-6 * max(1.0, abs(float(lo))), f"load_importance l_aux {name}: {float(out['l_aux'][0])} vs {float(lo)}")
     # gate gradient kernel (backward-only row)
     from tutel.impls.jit_compiler import tutel_custom_kernel as ck  # noqa
     g = torch.Generator().manual_seed(9)
@@ -300,6 +356,10 @@ def main():
         name, out, _ = run_ext_case(case)
         np.savez_compressed(os.path.join(HERE, f"ext_{name}.npz"), **out)
         print("wrote ext", name)
+    for case in NOISY_CASES:
+        name, out, _ = run_noisy_case(case)
+        np.savez_compressed(os.path.join(HERE, f"noisy_{name}.npz"), **out)
+        print("wrote noisy", name, float(out["l_aux"][0]))
     np.savez_compressed(os.path.join(HERE, "headline_integers.npz"), **headline_integer_case())
     # batch-prioritised routing (fast_dispatch.py:138-141,155-157): tokens ranked by -max score get buckets first
     g = torch.Generator().manual_seed(31)

@@ -55,6 +55,28 @@ def test_layer_host_logic_matches_oracle(oracle, monkeypatch, k, cf, post, norm)
     assert torch.equal(layer.dispatch_count.cpu(), crit[5])
 
 
+@pytest.mark.parametrize("name", ["f32_noise1_loadimp_train", "f32_noise1_loadimp_eval"])
+def test_noisy_gate_load_importance_host_logic(oracle, monkeypatch, name):
+    """moe_layer.py:285-296 on the host side: is_gshard_loss=False and (training) gate_noise > 0, fed the REFERENCE's stored
+    noise draw, must reproduce the reference's own fixture (kernels replaced by the oracle shim)."""
+    import numpy as np
+    _cpu_ops.install(monkeypatch)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"noisy_{name}.npz"))
+    T, M, H, E, k, fp32_gate, training, seed = [int(v) for v in z["meta"]]
+    gate_noise = float(z["gate_noise"][0])
+    x, wg, w1, b1, w2, b2 = oracle.make_problem(T, M, H, E, seed=seed)
+    layer = _make_layer(M, H, E, k, 1.0, is_gshard_loss=False, gate={"gate_noise": gate_noise})
+    _load(layer, wg, w1, b1, w2, b2)
+    layer.train(bool(training))
+    noise = torch.from_numpy(z["noise"])
+    monkeypatch.setattr(torch, "randn_like", lambda t, **kw: noise.to(t.dtype))
+    with torch.no_grad():
+        y = layer(x)
+    assert torch.equal(layer.dispatch_count, torch.from_numpy(z["dispatch_count"]))
+    assert torch.equal(y, torch.from_numpy(z["y"]))
+    assert abs(float(y.l_aux) - float(z["l_aux"][0])) <= 1e-6
+
+
 def test_cosine_gate_and_llama_expert_host_logic(oracle, monkeypatch):
     """`gate_type={'type': 'cosine_top'}` + `experts={'type': 'llama_ffn'}` modules
     (parameter names/shapes of the reference, its RNG order, and the layer wiring) against the

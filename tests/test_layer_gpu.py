@@ -95,6 +95,42 @@ def test_layer_vs_reference_fixture(oracle, path):
     assert abs(float(y.l_aux) - float(z["l_aux"][0])) <= (1e-5 if dtype == torch.float32 or fp32_gate else 1e-2)
 
 
+NOISY = sorted(glob.glob(os.path.join(GOLD, "noisy_*.npz")))
+
+
+@pytest.mark.parametrize("path", NOISY, ids=lambda p: os.path.basename(p)[6:-4])
+def test_noisy_gate_load_importance_layer_vs_reference_fixture(oracle, monkeypatch, path):
+    """The layer path of moe_layer.py:285-296 -- is_gshard_loss=False (load-importance loss, losses.py:21-42) and, in
+    training, gate_noise > 0 -- against the REFERENCE's own output: the fixture stores the reference's randn_like draw,
+    which is fed to this layer in place of its own (grad enabled, as in training).  Routing bit-exact; y at the dtype's bar."""
+    z = np.load(path)
+    assert len(NOISY) >= 3
+    T, M, H, E, k, fp32_gate, training, seed = [int(v) for v in z["meta"]]
+    dtype, gate_noise = DT[str(z["dtype"][0])], float(z["gate_noise"][0])
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed)
+    layer = make_layer(M, H, E, k, 1.0, dtype, weights, is_gshard_loss=False, gate={"fp32_gate": bool(fp32_gate), "gate_noise": gate_noise})
+    layer.train(bool(training))
+    assert layer.gates[0].gate_noise == gate_noise
+    noise = torch.from_numpy(z["noise"])
+    draws = []
+    monkeypatch.setattr(torch, "randn_like", lambda t, **kw: draws.append(1) or noise.to(device=t.device, dtype=t.dtype))
+    if training:
+        y = layer(x.cuda())          # grad enabled: the configuration this branch exists for
+        assert y.requires_grad and y.l_aux.requires_grad
+    else:
+        with torch.no_grad():
+            y = layer(x.cuda())
+    assert len(draws) == (1 if training else 0), "the noise is drawn once per training forward, never in eval"
+    assert torch.equal(layer.dispatch_count.cpu(), torch.from_numpy(z["dispatch_count"]))
+    _close(y.detach(), _t(z["y"], dtype), dtype, vs_lowprec_reference=True)
+    want = float(z["l_aux"][0])
+    assert abs(float(y.l_aux) - want) <= 2e-4 * max(1.0, abs(want)), (float(y.l_aux), want)
+    if training:   # and the loss reaches the router: d l_aux / d wg is non-zero and finite
+        y.l_aux.backward()
+        g = layer.gates[0].wg.weight.grad
+        assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
 @pytest.mark.parametrize("path", [p for p in CASES if "c0_" not in p], ids=lambda p: os.path.basename(p)[6:-4])
 def test_low_level_api_vs_reference_fixture(oracle, path):
     """tutel.moe.top_k_routing / fast_encode / fast_decode on the fixture's scores."""
@@ -400,6 +436,13 @@ with torch.no_grad():
             torch.cuda.synchronize()
             assert torch.equal(chunked if degree == 3 else plain, over), degree
     assert ep_native._comms and all(ep_native._comms.values()), "the native communicator must have been created"
+# the variable-size exchanges on the same REAL communicator: one grouped ncclSend / ncclRecv loop (to self at world size 1)
+comm = ep_native.communicator(None, x.device)
+t = torch.arange(100003, device="cuda", dtype=torch.int32)
+assert torch.equal(comm.all_to_all_v(t, [t.numel()], [t.numel()]), t)
+assert torch.equal(comm.all_gather_v(t.to(torch.bfloat16), [t.numel()]), t.to(torch.bfloat16))
+assert comm.all_to_all_v(t[:0], [0], [0]).numel() == 0
+torch.cuda.synchronize()
 ep_native.destroy_all()
 dist.destroy_process_group()
 print("NATIVE_RCCL_OK")

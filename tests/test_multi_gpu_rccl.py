@@ -76,7 +76,26 @@ def _worker(rank, world, port, E_loc, q):
         tol = 2 ** -7 * want[rank].double().abs() + 2e-3
         ok = bool((err <= tol).all()) and torch.equal(layer.dispatch_count.cpu(), crits[rank][5])
         same = all(torch.equal(y, o) for d in outs for o in outs[d])
-        q.put((rank, ok and same, f"max err {float(err.max()):.3e}; degree 1 == degree 2 bitwise: {same}"))
+        # variable-size collectives (net.batch_all_to_all_v / batch_all_gather_v, custom_kernel.cpp:463-518) on the library's
+        # communicator: ragged seeded splits incl. an empty pair
+        from tutel import net
+        gen = torch.Generator().manual_seed(5)
+        split = torch.randint(0, 4000, [world, world], generator=gen)
+        split[0, world - 1] = 0
+        datas = [(torch.randn(int(split[s].sum()), generator=gen) * 100).to(dtype) for s in range(world)]
+        (got,), rs = net.batch_all_to_all_v([datas[rank].to(dev)], split[rank].tolist())
+        offs = [[int(split[s, :d].sum()) for d in range(world)] for s in range(world)]
+        exp = torch.cat([datas[s][offs[s][rank]:offs[s][rank] + int(split[s, rank])] for s in range(world)])
+        vok = torch.equal(got.cpu(), exp) and rs.cpu().tolist() == split[:, rank].tolist()
+        (gg,), _ = net.batch_all_gather_v([datas[rank].to(dev)])
+        vok = vok and torch.equal(gg.cpu(), torch.cat(datas))
+        # a rank WITHOUT tokens must not hang its peers (inequivalent_tokens)
+        with torch.no_grad():
+            xe = x if rank != world - 1 else x[:0]
+            ye = layer(xe, a2a_ffn_overlap_degree=2, inequivalent_tokens=True)
+        torch.cuda.synchronize()
+        vok = vok and ye.shape[0] == xe.shape[0] and bool(torch.isfinite(ye.float()).all())
+        q.put((rank, ok and same and vok, f"max err {float(err.max()):.3e}; degree 1 == degree 2 bitwise: {same}; v-collectives + empty rank: {vok}"))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:  # pragma: no cover

@@ -22,6 +22,7 @@ CASES = sorted(glob.glob(os.path.join(GOLD, "layer_*.npz")))
 
 def test_fixtures_present():
     assert len(CASES) >= 10 and len(glob.glob(os.path.join(GOLD, "ext_*.npz"))) >= 3 and os.path.exists(os.path.join(GOLD, "headline_integers.npz"))
+    assert len(NOISY) >= 3
 
 
 @pytest.mark.parametrize("path", CASES, ids=lambda p: os.path.basename(p)[6:-4])
@@ -48,6 +49,25 @@ def test_oracle_layer_matches_reference_fixture(oracle, path):
     if "encoded" in z.files:
         assert torch.equal(st["encoded"], _t(z["encoded"], dtype))
         assert torch.equal(st["expert_out"], _t(z["expert_out"], dtype))
+
+
+NOISY = sorted(glob.glob(os.path.join(GOLD, "noisy_*.npz")))
+
+
+@pytest.mark.parametrize("path", NOISY, ids=lambda p: os.path.basename(p)[6:-4])
+def test_oracle_noisy_gate_load_importance_matches_reference_fixture(oracle, path):
+    """moe_layer.py:285-296 (gate noise in training, load-importance loss): the reference's output with a stored noise draw."""
+    z = np.load(path)
+    T, M, H, E, k, fp32_gate, training, seed = [int(v) for v in z["meta"]]
+    dtype, gate_noise = DT[str(z["dtype"][0])], float(z["gate_noise"][0])
+    x, wg, w1, b1, w2, b2 = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed)
+    assert float(sum(t.double().abs().sum() for t in (x, wg, w1, b1, w2, b2))) == float(z["in_checksum"][0])
+    noise = torch.from_numpy(z["noise"]) if training else None
+    y, l_aux, crit, _ = oracle.moe_forward(x, wg, w1, b1, w2, b2, top_k=k, fp32_gate=bool(fp32_gate), noise=noise,
+                                           gate_noise=gate_noise, is_gshard_loss=False)
+    assert torch.equal(crit[5], torch.from_numpy(z["dispatch_count"]))
+    assert torch.equal(y, _t(z["y"], dtype))
+    assert abs(float(l_aux) - float(z["l_aux"][0])) <= 1e-6 * max(1.0, abs(float(l_aux)))
 
 
 def test_headline_integer_fixture(oracle):

@@ -73,6 +73,9 @@ SIGNATURES.update({
     "tutel_amd_ep_comm_create_hosted": (_i, [_i, _i, _vp, _vp, ctypes.POINTER(_vp)]),
     "tutel_amd_ep_comm_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "tutel_amd_ep_all_to_all": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "tutel_amd_ep_comm_set_hosted_v": (_i, [_vp, _vp]),
+    "tutel_amd_ep_all_to_all_v": (_i, [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), _vp]),
+    "tutel_amd_ep_all_gather_v": (_i, [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint64), _vp]),
     "tutel_amd_ep_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(EpPlan)]),
     "tutel_amd_ep_forward": (_i, [_vp, ctypes.POINTER(EpArgs), _vp]),
     "tutel_amd_mark": (_i, [_vp]),
@@ -84,6 +87,8 @@ SIGNATURES.update({
     "tutel_amd_range_pop": (_i, []),
 })
 EXCHANGE_FN = ctypes.CFUNCTYPE(_i, _vp, _vp, _vp, _sz, _i)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+EXCHANGE_V_FN = ctypes.CFUNCTYPE(_i, _vp, _vp, _vp, _u64p, _u64p, _u64p, _i)
 EP_ID_BYTES = 128
 EAGAIN = 1000
 STAGES = ("gate_topk", "location", "fast_encode", "expert_fc1", "expert_fc2", "fast_decode", "all_to_all_dispatch", "all_to_all_combine", "other")

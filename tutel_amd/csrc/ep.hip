@@ -36,8 +36,12 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t);
   ncclResult_t (*AllToAll)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
   const char *(*GetErrorString)(ncclResult_t);
+  ncclResult_t (*GroupStart)();
+  ncclResult_t (*GroupEnd)();
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
 };
-static RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static RcclApi g_rccl = {};
 
 extern "C" int tutel_amd_ep_load_rccl(const char *path) {
   if (g_rccl.handle != nullptr) return 0;
@@ -57,8 +61,12 @@ extern "C" int tutel_amd_ep_load_rccl(const char *path) {
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
   a.AllToAll = (decltype(a.AllToAll))dlsym(h, "ncclAllToAll");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
-  TUTEL_REQUIRE(a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllToAll && a.GetErrorString,
-                "tutel_amd_ep_load_rccl: librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllToAll");
+  a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+  a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+  a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
+  a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
+  TUTEL_REQUIRE(a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllToAll && a.GetErrorString && a.GroupStart && a.GroupEnd && a.Send && a.Recv,
+                "tutel_amd_ep_load_rccl: librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllToAll / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
   g_rccl = a;
   return 0;
 }
@@ -93,7 +101,9 @@ struct tutel_amd_ep_comm {
   ncclComm_t comm;
   int world, rank, device;
   tutel_amd_exchange_fn hosted;  // bring-up / test communicator: the exchange is a host callback (comm == nullptr then)
+  tutel_amd_exchange_v_fn hosted_v;
   void *hosted_user;
+
   hipStream_t side_stream;  // the GEMMs of the overlapped pipeline (the collectives run on the caller's stream)
   hipEvent_t recv_ev[EP_MAX_SPLIT], done_ev[EP_MAX_SPLIT];
 };
@@ -213,6 +223,67 @@ extern "C" int tutel_amd_ep_all_to_all(tutel_amd_ep_comm_t *c, const void *send,
   return exchange(c, send, recv, bytes_per_peer, c->world, (hipStream_t)stream);
 }
 
+// ---- variable-size exchanges (tutel.net.batch_all_to_all_v / batch_all_gather_v; custom_kernel.cpp:463-518) -----------
+extern "C" int tutel_amd_ep_comm_set_hosted_v(tutel_amd_ep_comm_t *c, tutel_amd_exchange_v_fn fn) {
+  TUTEL_REQUIRE(c != nullptr && c->hosted != nullptr, "tutel_amd_ep_comm_set_hosted_v: need a hosted communicator");
+  c->hosted_v = fn;
+  return 0;
+}
+
+// one grouped send / recv loop: to rank r `sb[r]` bytes from send + so[r], from rank r `rb[r]` bytes into the running offset
+static int exchange_v(tutel_amd_ep_comm *c, const void *send, void *recv, const uint64_t *sb, const uint64_t *so, const uint64_t *rb,
+                      hipStream_t st, const char *what) {
+  StageScope scope(TUTEL_STAGE_OTHER, st);
+  if (c->hosted != nullptr) {
+    TUTEL_REQUIRE(c->hosted_v != nullptr, "%s: the hosted communicator has no variable-size callback (tutel_amd_ep_comm_set_hosted_v)", what);
+    const int rc = c->hosted_v(c->hosted_user, send, recv, sb, so, rb, c->world);
+    TUTEL_REQUIRE(rc == 0, "%s: the host exchange callback failed (%d)", what, rc);
+    return 0;
+  }
+  RCCL_CHECK(g_rccl.GroupStart(), "ncclGroupStart");
+  uint64_t ro = 0;
+  ncclResult_t bad = ncclSuccess;
+  for (int r = 0; r < c->world && bad == ncclSuccess; ++r) {
+    if (sb[r]) bad = g_rccl.Send((const char *)send + so[r], (size_t)sb[r], ncclInt8, r, c->comm, st);
+    if (rb[r] && bad == ncclSuccess) bad = g_rccl.Recv((char *)recv + ro, (size_t)rb[r], ncclInt8, r, c->comm, st);
+    ro += rb[r];
+  }
+  const ncclResult_t end = g_rccl.GroupEnd();  // always closed, also after a failed send / recv
+  RCCL_CHECK(bad, what);
+  RCCL_CHECK(end, "ncclGroupEnd");
+  return 0;
+}
+
+extern "C" int tutel_amd_ep_all_to_all_v(tutel_amd_ep_comm_t *c, const void *send, void *recv, const uint64_t *send_bytes,
+                                         const uint64_t *recv_bytes, tutel_stream_t stream) {
+  TUTEL_REQUIRE(c != nullptr && send_bytes != nullptr && recv_bytes != nullptr, "tutel_amd_ep_all_to_all_v: need a communicator and both size arrays");
+  TUTEL_REQUIRE(c->world <= 4096, "tutel_amd_ep_all_to_all_v: world size %d", c->world);
+  uint64_t so[4096], tot_s = 0, tot_r = 0;
+  for (int r = 0; r < c->world; ++r) {
+    so[r] = tot_s;
+    tot_s += send_bytes[r];
+    tot_r += recv_bytes[r];
+  }
+  TUTEL_REQUIRE((send != nullptr || tot_s == 0) && (recv != nullptr || tot_r == 0) && (send != recv || tot_s + tot_r == 0),
+                "tutel_amd_ep_all_to_all_v: null or aliased buffers");
+  return exchange_v(c, send, recv, send_bytes, so, recv_bytes, (hipStream_t)stream, "tutel_amd_ep_all_to_all_v");
+}
+
+extern "C" int tutel_amd_ep_all_gather_v(tutel_amd_ep_comm_t *c, const void *send, void *recv, const uint64_t *recv_bytes,
+                                         tutel_stream_t stream) {
+  TUTEL_REQUIRE(c != nullptr && recv_bytes != nullptr, "tutel_amd_ep_all_gather_v: need a communicator and the size array");
+  TUTEL_REQUIRE(c->world <= 4096, "tutel_amd_ep_all_gather_v: world size %d", c->world);
+  uint64_t sb[4096], so[4096], tot_r = 0;
+  for (int r = 0; r < c->world; ++r) {
+    sb[r] = recv_bytes[c->rank];  // the same bytes to everybody
+    so[r] = 0;
+    tot_r += recv_bytes[r];
+  }
+  TUTEL_REQUIRE((send != nullptr || recv_bytes[c->rank] == 0) && (recv != nullptr || tot_r == 0) && (send != recv || tot_r == 0),
+                "tutel_amd_ep_all_gather_v: null or aliased buffers");
+  return exchange_v(c, send, recv, sb, so, recv_bytes, (hipStream_t)stream, "tutel_amd_ep_all_gather_v");
+}
+
 // ---- stage layouts (== tutel_amd/impls/overlap.py::OverlapPlan) ------------------------------------------------
 extern "C" int tutel_amd_ep_plan(int E, int W, int capacity, int degree, int allow_sliced, tutel_amd_ep_plan_t *out) {
   TUTEL_REQUIRE(out != nullptr && E >= 1 && W >= 1 && E % W == 0 && degree >= 1 && degree <= EP_MAX_SPLIT && capacity >= 0,
@@ -240,19 +311,22 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
                 "tutel_amd_ep_forward: bad sizes");
   TUTEL_REQUIRE(c == nullptr ? W == 1 : c->world == W, "tutel_amd_ep_forward: communicator world size does not match (%d)", W);
   TUTEL_REQUIRE(a->dtype == TUTEL_BF16 || a->dtype == TUTEL_F16, "tutel_amd_ep_forward: bf16 / fp16 experts only (got dtype %d)", a->dtype);
-  TUTEL_REQUIRE(a->x && a->slot_map && a->idx && a->loc && a->w1 && a->w2 && a->y, "tutel_amd_ep_forward: null pointer");
-  if (T == 0) return 0;
+  TUTEL_REQUIRE((T == 0 || (a->x && a->idx && a->loc && a->y)) && (a->slot_map || C == 0) && a->w1 && a->w2, "tutel_amd_ep_forward: null pointer");
+  // a rank without tokens still owes its peers every collective of the pipeline (they block in ncclAllToAll otherwise):
+  // only a single rank without a communicator may leave here.  With a communicator the empty rank encodes all-zero
+  // buckets, runs its experts on what the others send and skips nothing but its own (empty) decode.
+  if (T == 0 && c == nullptr) return 0;
   const int E_loc = E / W, es = 2;
   hipStream_t cur = (hipStream_t)stream;
   const void *enc_gates = a->is_postscore ? nullptr : a->gates;  // fast_dispatch.py:125,131: gates on one side only
   const void *dec_gates = a->is_postscore ? a->gates : nullptr;
-  TUTEL_REQUIRE(a->gates != nullptr, "tutel_amd_ep_forward: null gates");
+  TUTEL_REQUIRE(a->gates != nullptr || T == 0, "tutel_amd_ep_forward: null gates");
   TUTEL_REQUIRE(a->row_counts == nullptr || (W == 1 && c == nullptr && a->degree <= 1), "tutel_amd_ep_forward: row counts (megablocks) need a single rank");
   const int32_t *rcnt = a->row_counts;
   const int ralign = a->row_counts != nullptr && a->row_align >= 1 ? a->row_align : 1;
 
-  if (C == 0) {  // nothing is dispatched: every token's output is the zero vector
-    HIP_CHECK(hipMemsetAsync(a->y, 0, (size_t)T * Mo * es, cur), "hipMemsetAsync");
+  if (C == 0) {  // nothing is dispatched (on any rank: the capacity is agreed): every token's output is the zero vector
+    if (T > 0) HIP_CHECK(hipMemsetAsync(a->y, 0, (size_t)T * Mo * es, cur), "hipMemsetAsync");
     return 0;
   }
 
@@ -363,10 +437,10 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
 extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe_args_t *m, tutel_stream_t stream) {
   TUTEL_REQUIRE(m != nullptr, "tutel_amd_moe_forward: null arguments");
   const tutel_amd_ep_args_t &a = m->ep;
-  TUTEL_REQUIRE(m->logits != nullptr && m->ws != nullptr && m->dispatch_count != nullptr, "tutel_amd_moe_forward: null pointer");
-  TUTEL_REQUIRE(a.slot_map && a.idx && a.loc && a.gates, "tutel_amd_moe_forward: null routing buffers");
   const int T = a.T, E = a.num_experts, k = a.k;
-  if (T == 0) return 0;
+  TUTEL_REQUIRE((m->logits != nullptr || T == 0) && m->ws != nullptr && m->dispatch_count != nullptr, "tutel_amd_moe_forward: null pointer");
+  TUTEL_REQUIRE(a.slot_map && (T == 0 || (a.idx && a.loc && a.gates)), "tutel_amd_moe_forward: null routing buffers");
+  if (T == 0 && c == nullptr) return 0;  // (with a communicator an empty rank still takes part in every exchange, see tutel_amd_ep_forward)
   const bool dropless = a.capacity <= 0;
   TUTEL_REQUIRE(!dropless || (c == nullptr && a.world == 1 && m->stats != nullptr && m->capacity_out != nullptr && m->max_capacity >= 1),
                 "tutel_amd_moe_forward: dropless routing needs a single rank, stats, capacity_out and max_capacity");
@@ -382,12 +456,13 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
   if (dropless) {
     // the one host synchronisation of the dropless API (fast_dispatch.py:192-193), taken here so that nothing but this
     // function stands between the read-back and the next launch
-    static int *h_cap = nullptr;  // pinned
-    if (h_cap == nullptr) HIP_CHECK(hipHostMalloc((void **)&h_cap, sizeof(int), hipHostMallocDefault), "hipHostMalloc");
+    // the read-back lands in the caller's own slot (m->capacity_out: any host memory; pinned memory makes the copy
+    // asynchronous, pageable memory makes the runtime stage it) -- no process-global state, so callers on different
+    // threads / streams / devices cannot read each other's capacity
     hipStream_t st = (hipStream_t)stream;
-    HIP_CHECK(hipMemcpyAsync(h_cap, m->stats, sizeof(int), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+    HIP_CHECK(hipMemcpyAsync(m->capacity_out, m->stats, sizeof(int), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
     HIP_CHECK(hipStreamSynchronize(st), "hipStreamSynchronize");
-    int cap = *h_cap;
+    int cap = *m->capacity_out;
     if (m->capacity_limit > 0 && cap > m->capacity_limit) cap = m->capacity_limit;
     const int al = m->alignment >= 1 ? m->alignment : 1;
     cap = (cap + al - 1) / al * al;

@@ -242,6 +242,18 @@ def _staged(t, group):
     return t.cpu() if t.is_cuda and dist.get_backend(group) == "gloo" else t
 
 
+def _native_comm(t, group):
+    """the library's own communicator for device tensors (RCCL; or host-staged when the ranks share a GPU in tests):
+    the variable-size collectives then run as ONE grouped ncclSend / ncclRecv loop per tensor inside libtutel_amd.so, as the
+    reference's do inside its extension (custom_kernel.cpp:463-518).  None -> torch.distributed's all_to_all_single."""
+    if not t.is_cuda:
+        return None
+    from . import ep_native
+    if not ep_native.ENABLED or not (dist.get_backend(group) == "nccl" or ep_native.HOSTED):
+        return None
+    return ep_native.communicator(group, t.device)   # collective on first use; every rank of the group is in this call
+
+
 def batch_all_to_all_v(datas, partition_sizes, group=None):
     """Variable-size all-to-all of a batch of flat tensors sharing one split (reference:
     communicate.py:225-241 over custom_kernel.cpp:463-491, a grouped ncclSend/ncclRecv loop):
@@ -259,10 +271,14 @@ def batch_all_to_all_v(datas, partition_sizes, group=None):
         return list(datas), in_sizes
     out_sizes = simple_all_to_all(in_sizes, group=group)
     send, recv = [int(v) for v in in_sizes.tolist()], [int(v) for v in out_sizes.tolist()]  # the one sync the API implies
+    comm = _native_comm(datas[0], group)
     outputs = []
     for data in datas:
         flat = data.contiguous().view(-1)
         assert flat.numel() == sum(send), "Tensor instances within batch_all_to_all_v are supposed to share same length."
+        if comm is not None:
+            outputs.append(comm.all_to_all_v(flat, send, recv))
+            continue
         src = _staged(flat, group)
         out = torch.empty([sum(recv)], dtype=flat.dtype, device=src.device)
         dist.all_to_all_single(out, src, output_split_sizes=recv, input_split_sizes=send, group=group)
@@ -282,9 +298,13 @@ def batch_all_gather_v(datas, group=None):
         return list(datas), input_size
     output_sizes = simple_all_gather(input_size, group=group)
     recv = [int(v) for v in output_sizes.tolist()]
+    comm = _native_comm(datas[0], group)
     outputs = []
     for flat in datas:
         assert flat.numel() == int(input_size), "Tensor instances within batch_all_gather_v are supposed to share same length."
+        if comm is not None:
+            outputs.append(comm.all_gather_v(flat, recv))
+            continue
         src = _staged(flat, group)
         # my tensor to every rank, every rank's tensor to me: an all-to-all whose input is W copies of the tensor
         out = torch.empty([sum(recv)], dtype=flat.dtype, device=src.device)

@@ -42,6 +42,46 @@ class EpComm:
         _lib.check(_lib.lib().tutel_amd_ep_all_to_all(self.handle, inp.data_ptr(), out.data_ptr(), per_peer, ops._stream()),
                    "tutel_amd_ep_all_to_all")
 
+    def _scoped(self, *tensors):
+        """hosted communicators resolve device pointers through registered tensors: register for one call"""
+        reg = getattr(self, "register", None)
+        if reg is None:
+            return lambda: None
+        n = len(tensors)
+        for t in tensors:
+            reg(t)
+        return lambda: self.unregister(n)
+
+    def all_to_all_v(self, inp, send_counts, recv_counts):
+        """flat `inp` split by send_counts (elements per destination rank) -> flat tensor of sum(recv_counts) elements
+        (tutel_amd_ep_all_to_all_v: one grouped ncclSend / ncclRecv loop on the library's communicator)"""
+        assert inp.is_contiguous() and inp.dim() == 1 and len(send_counts) == self.world == len(recv_counts)
+        es = inp.element_size()
+        out = torch.empty([int(sum(recv_counts))], dtype=inp.dtype, device=inp.device)
+        arr = ctypes.c_uint64 * self.world
+        sb, rb = arr(*[int(c) * es for c in send_counts]), arr(*[int(c) * es for c in recv_counts])
+        done = self._scoped(inp, out)
+        try:
+            _lib.check(_lib.lib().tutel_amd_ep_all_to_all_v(self.handle, inp.data_ptr() or None, out.data_ptr() or None, sb, rb, ops._stream()),
+                       "tutel_amd_ep_all_to_all_v")
+        finally:
+            done()
+        return out
+
+    def all_gather_v(self, inp, counts):
+        """flat `inp` (counts[rank] elements) -> the concatenation of every rank's tensor, in rank order"""
+        assert inp.is_contiguous() and inp.dim() == 1 and len(counts) == self.world and int(counts[self.rank]) == inp.numel()
+        es = inp.element_size()
+        out = torch.empty([int(sum(counts))], dtype=inp.dtype, device=inp.device)
+        rb = (ctypes.c_uint64 * self.world)(*[int(c) * es for c in counts])
+        done = self._scoped(inp, out)
+        try:
+            _lib.check(_lib.lib().tutel_amd_ep_all_gather_v(self.handle, inp.data_ptr() or None, out.data_ptr() or None, rb, ops._stream()),
+                       "tutel_amd_ep_all_gather_v")
+        finally:
+            done()
+        return out
+
 
 def _rccl_hint():
     return os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
@@ -130,13 +170,30 @@ def _create_hosted(group, device):
         except Exception as ex:  # noqa: BLE001
             logging.error("tutel_amd: hosted exchange failed: %s", ex)
             return 1
-    fn = _lib.EXCHANGE_FN(cb)
+    def cb_v(_user, send, recv, sb, so, rb, world):
+        try:
+            sb, so, rb = ([int(a[i]) for i in range(world)] for a in (sb, so, rb))
+            span = max([o + b for o, b in zip(so, sb)] + [0])
+            src = find(int(send or 0), span) if span else None
+            host = torch.cat([src[o:o + b] for o, b in zip(so, sb)]).cpu() if span else torch.empty([0], dtype=torch.uint8)
+            out = torch.empty([sum(rb)], dtype=torch.uint8)
+            dist.all_to_all_single(out, host, output_split_sizes=rb, input_split_sizes=sb, group=group)
+            if sum(rb):
+                find(int(recv), sum(rb)).copy_(out)
+            return 0
+        except Exception as ex:  # noqa: BLE001
+            logging.error("tutel_amd: hosted variable-size exchange failed: %s", ex)
+            return 1
+    fn, fn_v = _lib.EXCHANGE_FN(cb), _lib.EXCHANGE_V_FN(cb_v)
     handle = ctypes.c_void_p()
     with torch.cuda.device(device):
         _lib.check(L.tutel_amd_ep_comm_create_hosted(W, rank, ctypes.cast(fn, ctypes.c_void_p), None, ctypes.byref(handle)),
                    "tutel_amd_ep_comm_create_hosted")
+        _lib.check(L.tutel_amd_ep_comm_set_hosted_v(handle, ctypes.cast(fn_v, ctypes.c_void_p)), "tutel_amd_ep_comm_set_hosted_v")
     comm = EpComm(handle, W, rank)
-    comm._keep, comm.register = fn, lambda t: bufs.append((t.data_ptr(), t.numel() * t.element_size(), t.view(-1).view(torch.uint8)))
+    comm._keep = (fn, fn_v)
+    comm.register = lambda t: bufs.append((t.data_ptr(), t.numel() * t.element_size(), t.view(-1).view(torch.uint8)))
+    comm.unregister = lambda n: bufs.__delitem__(slice(len(bufs) - n, len(bufs)))
     return comm
 
 
@@ -278,12 +335,16 @@ class _MoeWorkspace(_Workspace):
         self.slot_map = torch.empty([E * capacity], dtype=torch.int32, device=dev)
         self.ws = ops.routing_workspace(T, E, k, dev)
         self.stats = torch.empty([1], dtype=torch.int32, device=dev)
+        # the dropless capacity is read back into this workspace's own pinned word (no process-global slot: ADVICE r2)
+        self.cap_host = torch.zeros([1], dtype=torch.int32).pin_memory()
+        self.cap_c = ctypes.c_int.from_address(self.cap_host.data_ptr())
         m = _lib.MoeArgs()
         m.ep = self.args
         m.ep.slot_map, m.ep.idx, m.ep.loc, m.ep.gates = (self.slot_map.data_ptr(), self.idx.data_ptr(), self.loc.data_ptr(),
                                                           self.gates.data_ptr())
         m.logits_dtype = ops._DT[logits.dtype]
         m.ws, m.ws_bytes, m.stats = self.ws.data_ptr(), self.ws.numel(), self.stats.data_ptr()
+        m.capacity_out = ctypes.pointer(self.cap_c)
         self.margs = m
 
 
@@ -306,7 +367,6 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
     skey = (tuple(x.shape), logits.shape[1], k)
     if dropless is not None:
         capacity = max(capacity, sizes.get(skey, 0))
-    cap_out = ctypes.c_int(0)
     for attempt in range(4):
         key = ("moe", tuple(x.shape), x.dtype, x.device, tuple(logits.shape), logits.dtype, k, capacity, degree, bool(layer.is_postscore),
                ex.fused_activation(), ops._stream(), with_comm)
@@ -335,7 +395,7 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
         m.logits, m.normalize_gate = logits.data_ptr(), int(bool(normalize_gate))
         m.dispatch_count = cnt.data_ptr()
         m.l_aux = l_aux.data_ptr() if l_aux is not None else None
-        m.capacity_out = ctypes.pointer(cap_out)
+        cap_out = ws.cap_c
         if dropless is not None:
             a.capacity = 0
             m.capacity_limit, m.alignment, m.max_capacity = int(dropless[0]), int(dropless[1]), int(capacity)
