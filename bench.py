@@ -28,6 +28,15 @@ expert_gemm_glds_kernel<bf16,k-major,relu>, HBM-bound; achieved = algorithmic by
 (E_loc*H*M weights + E_loc*R*M tokens + E_loc*R*H hidden out, x2 bytes) / its average duration.
 256 rows or more per expert and launch (N > 1, --tokens 65536): expert_gemm_pp_kernel, MFMA-bound; achieved = flop
 per launch / its average duration.
+`roofline.traffic` / `roofline.frac_rocprof` come from profiles/traffic.json (PMC FETCH_SIZE / WRITE_SIZE passes and the rocprofv3
+kernel-trace average of the same command, written by tools/profile_r03.sh) and are emitted only while the sha256 of
+csrc/expert_gemm.hip equals the one stamped there -- otherwise null with the reason.  `decode` and `extra.ep8_rank_gemms` are
+roofline objects of the second / third kernels of interest (fast_decode; the grouped GEMM at the per-rank shapes of an 8-way
+expert-parallel run: one pipeline stage, and the whole rank).
+Launch mode: with capacity_factor > 0 the forward never talks to the host, so the default is to capture it once in a HIP graph
+(tutel_amd.impls.graph.GraphedForward -- kernels, and with N > 1 the RCCL collectives of the library's communicator) and REPLAY
+it per step; `--eager` measures the Python-enqueued forward instead, and the line always carries the other mode beside it
+(`launch_modes`).  If capture fails the script says so on stderr and in the line and runs eager.
 `cpu_baseline`: the CPU oracle (a port of the reference CPU path, oracle/moe_oracle.py) timed on this box's host
 cores on a bounded sample, rank 0, N=1 only, next to the figure BASELINE.md measured with the reference itself.
 Checker code is used here ONLY as that reported baseline; it is never part of the measured GPU path.
@@ -82,6 +91,39 @@ class GateTimer:
 
     def avg_us(self):
         return sum(s.elapsed_time(e) for s, e in self.events) * 1e3 / max(1, len(self.events))
+
+
+def source_sha():
+    """sha256 of the grouped-GEMM kernel source the library is built from (stamps profiles/traffic.json)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("expert_gemm.hip", "common.h"):
+        h.update(open(os.path.join(ROOT, "tutel_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def gemm_probe(E_loc, R, M, H, dtype, iters=30):
+    """the fc1 grouped GEMM (bias + ReLU fused) on random operands at one shape, alternating two weight sets so that the weights
+    come from HBM: average launch in us between HIP events around `iters` back-to-back launches"""
+    from tutel_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(11)
+    a = torch.randn([E_loc, R, M], device=dev, generator=g).to(dtype)
+    ws = [(torch.randn([E_loc, H, M], device=dev, generator=g) * 0.03).to(dtype) for _ in range(2)]
+    b = torch.randn([E_loc, H], device=dev, generator=g).to(dtype)
+    for i in range(6):
+        ops.expert_gemm(a, ws[i & 1], b, True, act="relu")
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for i in range(iters):
+        ops.expert_gemm(a, ws[i & 1], b, True, act="relu")
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / iters
+    flops = 2.0 * E_loc * R * M * H
+    return {"shape": f"{E_loc} experts x {R} rows, K = {M}, N = {H}", "avg_launch_us": round(us, 2), "tflops": round(flops / us * 1e-6, 1),
+            "frac_of_mfma_peak": round(flops / us * 1e-6 / MFMA_PEAK_TFLOPS, 4), "launches_timed": iters, "bound": "mfma"}
 
 
 def physical_cores():
@@ -173,7 +215,8 @@ def main():
     ap.add_argument("--megablocks_size", type=int, default=0, help="configs[2]: row granularity of the dropless expert GEMMs")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_extra", action="store_true", help="skip the short BASELINE configs[2] (dropless) measurement appended at N=1")
-    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured HIP graph")
+    ap.add_argument("--graph", action="store_true", help="(default when capacity_factor > 0) replay the forward from a captured HIP graph")
+    ap.add_argument("--eager", action="store_true", help="time the Python-enqueued forward instead of the HIP-graph replay")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -214,11 +257,32 @@ def main():
     gate_timer = GateTimer(layer.gates[0])
     fwd_kw = dict(megablocks_size=args.megablocks_size) if args.megablocks_size else {}
     step = (lambda t: layer(t, **fwd_kw)) if fwd_kw else layer
-    launch = "eager"
-    if args.graph:
+    eager_step = step
+    launch, graph_note, graphed = "eager", None, None
+    want_graph = (args.graph or not args.eager) and args.capacity_factor > 0 and not share
+    if want_graph:
+        # same kernels (and, N > 1, the same RCCL collectives on the caller's stream), enqueued by ONE hipGraphLaunch per step:
+        # the host cost of a forward drops from ~0.09 (N = 1) / ~0.16 ms (N > 1, degree 2) to one launch, so the step is
+        # GPU-paced from the first one after the synchronize.  All ranks agree on the outcome (a rank that fell back alone would
+        # still match its peers' collectives -- the graph replays the same calls -- but the line should say what ran).
         from tutel_amd.impls.graph import GraphedForward
-        step = GraphedForward(layer, x, **fwd_kw)  # same kernels (and collectives), enqueued by one hipGraphLaunch per step
-        launch = "hip-graph replay"
+        ok = 1
+        try:
+            with torch.no_grad():
+                graphed = GraphedForward(layer, x, **fwd_kw)
+        except Exception as ex:   # noqa: BLE001 -- loud, not silent
+            ok, graph_note = 0, f"HIP-graph capture failed ({type(ex).__name__}: {str(ex)[:200]}); timed eager instead"
+            print("bench.py: " + graph_note, file=sys.stderr, flush=True)
+        if world > 1:
+            f = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            if int(f) == 0 and ok:
+                ok, graph_note = 0, "HIP-graph capture failed on another rank; timed eager instead"
+        if ok:
+            x = graphed.static_in   # the tokens live where the captured forward reads them: no per-step copy
+            step, launch = graphed, "hip-graph replay"
+    elif args.capacity_factor <= 0:
+        graph_note = "dropless routing reads the capacity back to the host every step: not capturable, eager"
 
     with torch.no_grad():
         for _ in range(args.settle):
@@ -231,7 +295,12 @@ def main():
         # event-based numbers come from three more passes of the same steps right after it, each bracketed the same way:
         elapsed, _, _, y = run_timed(step, x, args.steps, world, gate_timer, mode=0, marks=False)
         nb = args.steps
-        eager = (lambda t: layer(t, **fwd_kw))
+        eager = eager_step
+        other = None
+        if launch != "eager":      # the same K steps, eager, bracketed the same way: reported beside the value
+            for _ in range(max(3, args.warmup)):
+                eager(x)
+            other, _, _, _ = run_timed(eager, x, args.steps, world, gate_timer, mode=0, marks=False)
         _, per_step, _, _ = run_timed(step, x, nb, world, gate_timer, mode=0, marks=True)     # one mark per step: min / median
         run_timed(eager, x, 3, 1, gate_timer, mode=2, marks=False)                            # (fills the event pool)
         _, _, gemms, _ = run_timed(eager, x, nb, world, gate_timer, mode=2, marks=False)      # events around fc1 / fc2: roofline
@@ -239,9 +308,9 @@ def main():
         gate_timer.events.clear()
         _, _, stages, _ = run_timed(eager, x, nb, world, gate_timer, mode=1, marks=False)     # events around every launch: stages
     if world > 1:
-        tt = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed, other or 0.0], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
+        elapsed, other = float(tt[0]), (float(tt[1]) if other is not None else None)
     assert torch.isfinite(y.float()).all()
 
     C = int(layer.protected_shape[1]) // world  # capacity the layer actually used (dropless: max expert load)
@@ -258,10 +327,26 @@ def main():
         rows_per_launch, experts_per_launch = pl["gemm_rows"], pl["experts_per_stage"]
     gemm_bytes = (experts_per_launch * H * M + experts_per_launch * rows_per_launch * (M + H)) * es
     gemm_flops = 2 * experts_per_launch * rows_per_launch * M * H
-    traffic = None
+    # counter traffic and the profiler's own average of the dominant kernel are NOT measured in this run: they are read from
+    # profiles/traffic.json, which tools/profile_r03.sh writes together with the sha256 of the kernel source they were measured
+    # on -- a different source means a different kernel, and then both are reported as null with the reason
+    traffic, rocprof_us, traffic_note = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and world == 1 and (T, M, H, E, k) == (4096, 2048, 2048, 64, 2) and args.capacity_factor == 1.0:
-        traffic = json.load(open(tpath)).get("expert_gemm_fc1_hbm_bytes_per_launch")
+    headline = world == 1 and (T, M, H, E, k) == (4096, 2048, 2048, 64, 2) and args.capacity_factor == 1.0 and dtype == torch.bfloat16
+    if not headline:
+        traffic_note = "profiles/traffic.json holds the headline configuration only"
+    elif not os.path.exists(tpath):
+        traffic_note = "profiles/traffic.json is missing"
+    else:
+        tj = json.load(open(tpath))
+        have = source_sha()
+        if tj.get("expert_gemm_hip_sha256") != have:
+            traffic_note = (f"stale: profiles/traffic.json was measured on csrc/expert_gemm.hip sha256 {str(tj.get('expert_gemm_hip_sha256'))[:12]}, "
+                            f"the library was built from {have[:12]} -- re-run tools/profile_r03.sh")
+        else:
+            traffic = tj.get("expert_gemm_fc1_hbm_bytes_per_launch")
+            rocprof_us = tj.get("expert_gemm_fc1_avg_us_rocprofv3")
+            traffic_note = f"{tj.get('source')}; kernel {tj.get('kernel')}; measured at git {tj.get('git_head')}"
 
     fc2_obj = {"avg_launch_us": round(fc2_us, 2), "achieved_GBs": round(gemm_bytes / max(fc2_us, 1e-9) * 1e-3, 1),
                "tflops": round(gemm_flops / max(fc2_us, 1e-9) * 1e-6, 1), "launches_timed": fc2_n}
@@ -276,9 +361,24 @@ def main():
         roofline = {"bound": "hbm", "kernel": f"expert_gemm_glds_kernel<{dname},k-major,relu> (fc1 grouped GEMM, LDS-DMA)",
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_GBs": HBM_ACHIEVABLE_GBS, "traffic": traffic,
+                    "traffic_over_algorithmic": round(traffic / gemm_bytes, 4) if traffic else None, "traffic_note": traffic_note,
+                    "avg_launch_us_rocprofv3": rocprof_us,
+                    "frac_rocprof": round(gemm_bytes / rocprof_us * 1e-3 / HBM_PEAK_GBS, 4) if rocprof_us else None,
                     "algorithmic_bytes_per_launch": gemm_bytes, "avg_launch_us": round(fc1_us, 2), "launches_timed": fc1_n,
                     "fc2_gemm": fc2_obj, "mfma_tflops_fc1": round(gemm_flops / fc1_us * 1e-6, 1)}
 
+    # second kernel of interest: fast_decode (HBM-bound permutation).  Algorithmic bytes: the kept bucket rows it
+    # gathers + the token rows it writes; kept rows from the layer's own dispatch counts.
+    n_kept = int(torch.clamp(layer.dispatch_count.to(torch.int64), max=C).sum()) if C > 0 else 0
+    dec_bytes = (n_kept + T) * int(layer.protected_shape[-1]) * es
+    dec_tot, dec_n = stages.get("fast_decode", (0.0, 0))
+    dec_us = dec_tot / max(1, dec_n)
+    decode_obj = {"bound": "hbm", "kernel": f"decode_kernel<{dname}, k={k}> (fast_decode)", "algorithmic_bytes_per_launch": dec_bytes,
+                  "kept_rows": n_kept, "avg_launch_us": round(dec_us, 2), "launches_timed": dec_n,
+                  "achieved": round(dec_bytes / max(dec_us, 1e-9) * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(dec_bytes / max(dec_us, 1e-9) * 1e-3 / HBM_PEAK_GBS, 4),
+                  "frac_of_achievable": round(dec_bytes / max(dec_us, 1e-9) * 1e-3 / HBM_ACHIEVABLE_GBS, 4),
+                  "note": "from timing pass 4 (events around every launch)"}
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * T / (elapsed / args.steps)
@@ -316,13 +416,16 @@ def main():
                        "steps": nb,
                        "note": "pass 4: HIP events around EVERY launch (tutel_amd_stage_timing(1)); the sum exceeds a bare step because "
                                "every event record drains the queue"},
+            "decode": decode_obj,
+            "launch_modes": {"timed": launch, "note": graph_note,
+                             "other": (None if other is None else {"launch": "eager", "ms_per_step": round(other / args.steps * 1e3, 4),
+                                                                   "value": round(world * T / (other / args.steps), 1)})},
             "layer_roofline": {"algorithmic_bytes_per_step": layer_bytes, "achieved_GBs": round(layer_bytes / (ms * 1e-3) * 1e-9, 1),
                                "frac_of_hbm_peak": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
                                "frac_of_hbm_achievable": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_ACHIEVABLE_GBS, 4)},
         }
-        if world == 1 and not args.no_extra and args.capacity_factor == 1.0 and not args.graph and (T, M, H, E, k) == (4096, 2048, 2048, 64, 2):
+        if world == 1 and not args.no_extra and headline:
             # BASELINE configs[2] (same shape, dropless + megablocks): a short secondary measurement, recorded next to the headline one
-            del layer, step
             lay2 = build_layer(M, H, E_loc, k, rank, 1, dtype, args.fp32_gate, 0.0).to(dev).eval()
             gt2 = GateTimer(lay2.gates[0])
             with torch.no_grad():
@@ -337,6 +440,12 @@ def main():
                 "capacity": int(lay2.protected_shape[1]),
                 "fc1_avg_us": round(st2["expert_fc1"][0] / max(1, st2["expert_fc1"][1]), 2),
                 "fc2_avg_us": round(st2["expert_fc2"][0] / max(1, st2["expert_fc2"][1]), 2)}}
+        if world == 1 and not args.no_extra and headline:
+            # third kernel of interest: the grouped GEMM at the per-rank shapes of the 8-GPU point of this metric (E_loc = 8, rows =
+            # 8 ranks x capacity 128): one pipeline stage of a2a_ffn_overlap_degree 2 (4 experts) and the whole rank (8 experts)
+            out.setdefault("extra", {})["ep8_rank_gemms"] = {
+                "stage_gemm": gemm_probe(4, 1024, M, H, dtype), "full_rank_gemm": gemm_probe(8, 1024, M, H, dtype),
+                "note": "expert_gemm (fc1: bias + ReLU fused) launched alone on one GPU at the shapes an 8-way expert-parallel rank runs; MFMA-bound"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, M, H, E, k)
         print(json.dumps(out), flush=True)
