@@ -76,6 +76,16 @@ int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax, int T, int
                         int normalize_gate, void *scores_out, int32_t *idx, void *gates, void *ws,
                         size_t ws_bytes, int32_t *clear_map, int clear_n, tutel_stream_t stream);
 
+/* tutel_amd_gate_topk (on logits, softmax applied) + tutel_amd_compute_location in ONE launch: the blocks meet at a grid-wide
+ * barrier between the two halves (<= 128 blocks, all resident).  Same outputs, bit for bit, as the two calls; l_aux in the
+ * logits' dtype.  `sync`: two uint32 words in device memory, ZERO before the first call -- the kernel leaves them zero (so a
+ * HIP graph can replay it).  Applies to E <= 128 (and k * tile <= 4096 ids); otherwise returns TUTEL_AMD_ENOTSUP and launches
+ * nothing -- the caller then issues the two calls.  Replaces fast_dispatch.py:143-178 in one launch. */
+#define TUTEL_AMD_ENOTSUP 1001
+int tutel_amd_route(const void *logits, int dtype, int T, int E, int k, int normalize_gate, int32_t *idx, void *gates, void *ws,
+                    size_t ws_bytes, int32_t *loc, int32_t *dispatch_count, int32_t *stats, void *l_aux, int capacity,
+                    int32_t *slot_map, uint32_t *sync, tutel_stream_t stream);
+
 /* idx[k,T] -> loc[k,T] (stable rank of token t among tokens with the same k-th choice, queued
  * after ALL tokens' earlier choices -- fast_dispatch.py:159-171), dispatch_count[E] (:177-178),
  * stats[0] = max_e dispatch_count[e] (the dropless capacity before the all-reduce, :192),
@@ -328,7 +338,10 @@ typedef struct {
    * the rest with that capacity.  The workspace must hold max_capacity rows per expert; if the capacity exceeds it nothing
    * further is enqueued and the call returns TUTEL_AMD_EAGAIN with the needed value in *capacity_out (grow and call again). */
   int capacity_limit, alignment, max_capacity;
-  int *capacity_out;         /* host pointer, out: the capacity used (may be NULL when ep.capacity > 0) */
+  int *capacity_out;         /* host pointer, out: the capacity used (may be NULL when ep.capacity > 0); dropless: the read-back
+                              * lands here (pinned memory keeps the copy asynchronous) */
+  uint32_t *route_sync;      /* NULL, or the two zero-initialised words of tutel_amd_route: top-k and locations then run as ONE
+                              * launch where that kernel applies (capacity known up front, E <= 128) */
 } tutel_amd_moe_args_t;
 #define TUTEL_AMD_EAGAIN 1000
 int tutel_amd_moe_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_moe_args_t *args, tutel_stream_t stream);
@@ -360,14 +373,22 @@ int tutel_amd_marks_reserve(int n);
 int tutel_amd_marks_report(double *delta_us, int n);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
- * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG
- * seed it once), 0 / 1 = force.  Every choice computes bit-identical results.
+ * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG / TUTEL_AMD_DECODE /
+ * TUTEL_AMD_ROUTING / TUTEL_AMD_GEMM_PERSIST seed it once), >= 0 = force.  Every choice computes bit-identical results.
  *   TUTEL_OPT_GEMM_IMPL  128-tile kernels: 0 register-staged, 1 LDS-DMA
  *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
  *                        with a two- / three-slot LDS ring (k-major weights), 4 always the 256 x 256 ping-pong kernel
- *                        (automatic: > 128 rows per expert and enough tiles to cover the chip) */
+ *                        (automatic: > 128 rows per expert and enough tiles to cover the chip)
+ *   TUTEL_OPT_DECODE     fast_decode launch shape: bit 0 = two waves per token, bit 1 = non-temporal stores of the output
+ *   TUTEL_OPT_ROUTING    tutel_amd_moe_forward: 0 = top-k and location as two launches, 1 = the fused routing kernel
+ *   TUTEL_OPT_GEMM_PERSIST  256 x 256 ping-pong kernel: 0 = one tile per workgroup, 1 = persistent workgroups looping over tiles
+ *                        (automatic: persistent when a launch has more tiles than the GPU has compute units) */
 #define TUTEL_OPT_GEMM_IMPL 0
 #define TUTEL_OPT_GEMM_TILE 1
+#define TUTEL_OPT_DECODE 2
+#define TUTEL_OPT_ROUTING 3
+#define TUTEL_OPT_GEMM_PERSIST 4
+#define TUTEL_OPT_COUNT 5
 int tutel_amd_set_option(int key, int value);
 
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------

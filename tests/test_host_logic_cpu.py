@@ -514,3 +514,36 @@ def test_native_plan_equals_python_plan(W, E_loc, Cap, degree):
         assert py.row_layout(64) == (c["chunk"] * 64, c["rows"] * 64, c["chunk"], 64)
         want = dict(num_experts=E, expert_slice=py.s, ep_world=W) if py.sliced else dict(num_experts=E, chunk_rows=py.c)
         assert py.decode_kwargs == want
+
+
+def test_workspace_cache_is_lru_over_size_buckets():
+    """impls/ep_native.py::_workspace: a hit is any cached workspace of the same configuration that is large enough; misses
+    allocate for a size BUCKET; at most WS_MAX entries, least recently used first out (the cache used to be keyed on
+    the exact token count and cleared wholesale)."""
+    import random
+    from tutel_amd.impls import ep_native as N
+
+    class Layer:
+        pass
+
+    class WS:
+        def __init__(self, T_cap, C_cap):
+            self.T_cap, self.C_cap = T_cap, C_cap
+    lay = Layer()
+    made = []
+    make = lambda Tc, Cc: made.append((Tc, Cc)) or WS(Tc, Cc)
+    rnd = random.Random(1)
+    counts = rnd.sample(range(1000, 4097), 20)            # 20 different token counts
+    for T in counts:
+        C = 2 * ((T + 63) // 64)
+        ws = N._workspace(lay, ("cfg",), T, C, make)
+        assert ws.T_cap >= T and ws.C_cap >= C
+    assert len(made) <= 3 and lay._ep_workspace_allocations == len(made), made
+    for T in (1, 255, 256, 257, 4096, 4097, 65536, 100000):
+        b = N._bucket_tokens(T)
+        assert T <= b < T + max(256, T // 4 + 1), (T, b)
+    # another configuration does not hit; the cache holds at most WS_MAX workspaces and drops the least recently used
+    for i in range(6):
+        N._workspace(lay, ("other", i), 512, 32, make)
+    assert len(lay._ep_workspaces) == N.WS_MAX
+    assert all(key[0] != ("cfg",) for key in lay._ep_workspaces)

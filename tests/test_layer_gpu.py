@@ -814,3 +814,54 @@ def test_inference_mode_equals_no_grad(oracle):
         y1 = layer(x.cuda())
         crit, _ = __import__("tutel").moe.top_k_routing(torch.softmax(torch.randn(64, 8, device="cuda"), 1), 2)
     assert torch.equal(y0, y1) and float(y0.l_aux) == float(y1.l_aux)
+
+
+def test_variable_token_counts_reuse_workspaces(oracle):
+    """20 forwards with 20 different token counts (serving): at most 3 workspace allocations (LRU over size buckets), and
+    every output equals the one a fresh layer computes for that batch alone."""
+    import random
+    M, H, E, k = 256, 256, 16, 2
+    x, *weights = oracle.make_problem(4096, M, H, E, dtype=torch.bfloat16, seed=31)
+    layer = make_layer(M, H, E, k, 1.0, torch.bfloat16, weights).eval()
+    counts = random.Random(2).sample(range(1000, 4097), 20)
+    xd = x.cuda()
+    outs = {}
+    with torch.no_grad():
+        for T in counts:
+            outs[T] = layer(xd[:T]).clone()
+    assert layer._ep_workspace_allocations <= 3, layer._ep_workspace_allocations
+    for T in counts[:4] + [max(counts), min(counts)]:
+        fresh = make_layer(M, H, E, k, 1.0, torch.bfloat16, weights).eval()
+        with torch.no_grad():
+            assert torch.equal(fresh(xd[:T]), outs[T]), T
+    yo, *_ = oracle.moe_forward(x[:counts[0]], *weights, top_k=k, accum_fp32=True)
+    _close(outs[counts[0]], yo, torch.bfloat16)
+
+
+def test_gate_is_projected_once_per_forward(oracle):
+    """the one-call path used to run gate(x) before its last eligibility checks, and the general path ran it
+    again on a bail-out (hooks fired twice, the projection ran twice).  One projection per forward on every path."""
+    M, H, E, k = 256, 256, 8, 2
+    x, *weights = oracle.make_problem(1024, M, H, E, dtype=torch.bfloat16, seed=32)
+    xd = x.cuda()
+    for cfg in ("inference", "trainable_router_frozen_experts", "bpr", "load_importance", "training"):
+        kw = {}
+        if cfg == "bpr":
+            kw["batch_prioritized_routing"] = True
+        if cfg == "load_importance":
+            kw.update(is_gshard_loss=False, gate={"gate_noise": 1.0})
+        layer = make_layer(M, H, E, k, 1.0, torch.bfloat16, weights, **kw)
+        layer.train(cfg == "training")
+        calls = []
+        layer.gates[0].register_forward_hook(lambda *a: calls.append(1))
+        if cfg == "trainable_router_frozen_experts":
+            for p in layer.experts.parameters():
+                p.requires_grad_(False)
+            y = layer(xd)               # grad enabled: logits require grad -> the one-call path does not apply
+            assert y.requires_grad
+        elif cfg == "training":
+            y = layer(xd)
+        else:
+            with torch.no_grad():
+                y = layer(xd)
+        assert calls == [1], (cfg, calls)

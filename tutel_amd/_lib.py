@@ -14,7 +14,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
-OPT_GEMM_IMPL, OPT_GEMM_TILE = 0, 1
+OPT_GEMM_IMPL, OPT_GEMM_TILE, OPT_DECODE, OPT_ROUTING, OPT_GEMM_PERSIST = 0, 1, 2, 3, 4
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -27,6 +27,7 @@ SIGNATURES = {
     "tutel_amd_gate_topk": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
     "tutel_amd_compute_location": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "tutel_amd_slot_map": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "tutel_amd_route": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "tutel_amd_cumsum_sub_one": (_i, [_vp, _vp, _i, _i, _vp]),
     "tutel_amd_fast_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "tutel_amd_fast_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -61,7 +62,8 @@ class MoeArgs(ctypes.Structure):
     """tutel_amd_moe_args_t"""
     _fields_ = [("ep", EpArgs), ("logits", _vp), ("logits_dtype", _i), ("normalize_gate", _i), ("ws", _vp), ("ws_bytes", _sz),
                 ("dispatch_count", _vp), ("stats", _vp), ("l_aux", _vp),
-                ("capacity_limit", _i), ("alignment", _i), ("max_capacity", _i), ("capacity_out", ctypes.POINTER(_i))]
+                ("capacity_limit", _i), ("alignment", _i), ("max_capacity", _i), ("capacity_out", ctypes.POINTER(_i)),
+                ("route_sync", _vp)]
 
 
 SIGNATURES.update({
@@ -90,7 +92,7 @@ EXCHANGE_FN = ctypes.CFUNCTYPE(_i, _vp, _vp, _vp, _sz, _i)
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 EXCHANGE_V_FN = ctypes.CFUNCTYPE(_i, _vp, _vp, _vp, _u64p, _u64p, _u64p, _i)
 EP_ID_BYTES = 128
-EAGAIN = 1000
+EAGAIN, ENOTSUP = 1000, 1001
 STAGES = ("gate_topk", "location", "fast_encode", "expert_fc1", "expert_fc2", "fast_decode", "all_to_all_dispatch", "all_to_all_combine", "other")
 
 _lib = None

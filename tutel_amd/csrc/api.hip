@@ -18,11 +18,12 @@ extern "C" const char *tutel_amd_target_arch(void) { return "gfx950"; }
 extern "C" const char *tutel_amd_last_error(void) { return g_err; }
 
 // ---- tuning knobs (A/B runs and tests; defaults come from the environment once) -----------------
-static int g_opt[2] = {-2, -2};  // TUTEL_OPT_GEMM_IMPL, TUTEL_OPT_GEMM_TILE; -2 = not initialised, -1 = automatic
-static const char *const g_opt_env[2] = {"TUTEL_AMD_GEMM_IMPL", "TUTEL_AMD_GEMM_BIG"};
+static int g_opt[TUTEL_OPT_COUNT] = {-2, -2, -2, -2, -2};  // indexed by TUTEL_OPT_*; -2 = not initialised, -1 = automatic
+static const char *const g_opt_env[TUTEL_OPT_COUNT] = {"TUTEL_AMD_GEMM_IMPL", "TUTEL_AMD_GEMM_BIG", "TUTEL_AMD_DECODE", "TUTEL_AMD_ROUTING",
+                                                       "TUTEL_AMD_GEMM_PERSIST"};
 
 int tutel_get_option(int key) {
-  if (key < 0 || key > 1) return -1;
+  if (key < 0 || key >= TUTEL_OPT_COUNT) return -1;
   if (g_opt[key] == -2) {
     const char *s = getenv(g_opt_env[key]);
     g_opt[key] = s ? atoi(s) : -1;
@@ -31,8 +32,8 @@ int tutel_get_option(int key) {
 }
 
 extern "C" int tutel_amd_set_option(int key, int value) {
-  TUTEL_REQUIRE(key >= 0 && key <= 1, "tutel_amd_set_option: unknown key %d", key);
-  TUTEL_REQUIRE(value >= -1 && value <= 4, "tutel_amd_set_option: value %d out of range", value);
+  TUTEL_REQUIRE(key >= 0 && key < TUTEL_OPT_COUNT, "tutel_amd_set_option: unknown key %d", key);
+  TUTEL_REQUIRE(value >= -1 && value <= 7, "tutel_amd_set_option: value %d out of range", value);
   g_opt[key] = value;
   return 0;
 }
@@ -76,7 +77,11 @@ void tutel_stage_range_pop() {
 // the launch stream (timing events; ~2 us of host time each, nothing on the device between kernels of one stream).
 // bench.py turns it on for the timed steps and reads back per-stage totals: the HIP-event durations the roofline
 // object is computed from, for every stage of the forward, with no Python between the launches.
+#include <mutex>
 #include <vector>
+// one lock for the measurement state below (records, event pools, marks): launches may come from several host threads
+// (one per GPU / stream); the lock is only ever taken while timing is switched on or a report is read
+static std::mutex g_meas_mu;
 struct StageRec { hipEvent_t a, b; int stage; };
 static std::vector<StageRec> g_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free;
@@ -90,6 +95,7 @@ int tutel_stage_begin(int stage, hipStream_t st) {
   if (g_timing == 2 && stage != TUTEL_STAGE_FC1 && stage != TUTEL_STAGE_FC2) return -1;  // mode 2: the two expert GEMMs only
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;  // never inside a graph capture
+  std::lock_guard<std::mutex> lock(g_meas_mu);
   StageRec r;
   r.stage = stage;
   if (!g_free.empty()) {
@@ -107,13 +113,16 @@ int tutel_stage_begin(int stage, hipStream_t st) {
   return (int)g_recs.size() - 1;
 }
 void tutel_stage_end(int token, hipStream_t st) {
-  if (token >= 0 && token < (int)g_recs.size()) (void)hipEventRecord(g_recs[token].b, st);
+  if (token < 0) return;
+  std::lock_guard<std::mutex> lock(g_meas_mu);
+  if (token < (int)g_recs.size()) (void)hipEventRecord(g_recs[token].b, st);
 }
 
 // step marks: one event per call; tutel_amd_stage_report returns nothing about them, tutel_amd_marks_report the deltas
 static std::vector<hipEvent_t> g_marks;
 static std::vector<hipEvent_t> g_marks_free;
 extern "C" int tutel_amd_mark(tutel_stream_t stream) {
+  std::lock_guard<std::mutex> lock(g_meas_mu);
   hipEvent_t ev;
   if (!g_marks_free.empty()) {
     ev = g_marks_free.back();
@@ -126,6 +135,7 @@ extern "C" int tutel_amd_mark(tutel_stream_t stream) {
   return 0;
 }
 extern "C" int tutel_amd_marks_reserve(int n) {
+  std::lock_guard<std::mutex> lock(g_meas_mu);
   while ((int)g_marks_free.size() < n) {
     hipEvent_t ev;
     TUTEL_REQUIRE(hipEventCreateWithFlags(&ev, hipEventReleaseToDevice) == hipSuccess, "tutel_amd_marks_reserve: cannot create an event");
@@ -134,6 +144,7 @@ extern "C" int tutel_amd_marks_reserve(int n) {
   return 0;
 }
 extern "C" int tutel_amd_marks_report(double *delta_us, int n) {
+  std::lock_guard<std::mutex> lock(g_meas_mu);
   const int have = (int)g_marks.size();
   int m = 0;
   for (int i = 0; i + 1 < have; ++i) {
@@ -154,6 +165,7 @@ extern "C" int tutel_amd_stage_timing(int enable) {
 extern "C" int tutel_amd_stage_report(double *total_us, int *counts, int n_stages) {
   TUTEL_REQUIRE(total_us != nullptr && counts != nullptr && n_stages >= TUTEL_STAGE_COUNT, "tutel_amd_stage_report: need arrays of %d entries", TUTEL_STAGE_COUNT);
   for (int i = 0; i < n_stages; ++i) { total_us[i] = 0.0; counts[i] = 0; }
+  std::lock_guard<std::mutex> lock(g_meas_mu);
   for (auto &r : g_recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.stage >= 0 && r.stage < n_stages) {

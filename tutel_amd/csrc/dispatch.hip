@@ -16,6 +16,7 @@
 
 #define DP_THREADS 256
 #define DP_WAVES 4
+#define TUTEL_DECODE_DEFAULT 0   // see launch_decode
 
 
 __device__ __forceinline__ float load_gate(const void *g, int gate_dtype, size_t i) {
@@ -106,7 +107,10 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
 // -------------------------------------------------------------------------------------------
 // decode
 // -------------------------------------------------------------------------------------------
-template <typename T, int KMAX>
+// SPLIT waves share one token (each takes 1/SPLIT of the row): more, shorter waves -- the whole grid is resident at once at the
+// headline shape, so the kernel is one dependent chain (index loads -> row loads -> stores) and shorter per-wave chains overlap
+// better.  NTS: the combined rows are written with non-temporal stores (they are not re-read by this layer).
+template <typename T, int KMAX, int SPLIT, bool NTS>
 __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict__ buf,
                                                            const int32_t *__restrict__ idx,
                                                            const int32_t *__restrict__ loc,
@@ -121,8 +125,10 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
   const int nwaves = gridDim.x * DP_WAVES;
   const int nvec = M / VN;
   const bool vec_ok = (M % VN) == 0;
+  const int per = SPLIT == 1 ? nvec : (((nvec + SPLIT - 1) / SPLIT + 63) / 64 * 64);  // vectors per wave of a token
 
-  for (int t = wave; t < Tn; t += nwaves) {
+  for (int wt = wave; wt < Tn * SPLIT; wt += nwaves) {
+    const int t = wt / SPLIT, part = wt % SPLIT;
     // per-choice row pointer (nullptr = dropped) and gate, wave-uniform
     const T *rows[KMAX];
     float g[KMAX];
@@ -151,9 +157,10 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
       vec16 *d = reinterpret_cast<vec16 *>(dst);
       // UNR vectors per lane per pass: all UNR * k loads are issued before the first use (8 x 16 B in flight per lane at
       // k = 2; two in flight left the kernel at 4.2 TB/s although its input was just written by fc2)
-      constexpr int UNR = KMAX >= 8 ? 1 : (8 / KMAX);
+      constexpr int UNR = KMAX * SPLIT >= 8 ? 1 : (8 / (KMAX * SPLIT));
       // loads are unconditional (a dropped choice reads bucket row 0 and its value is discarded): a branch around each
-      // load would make hipcc wait for every load separately
+      // load would make hipcc wait for every load separately.  KMAX is the exact k for k <= 8 (a KMAX of the
+      // next power of two issued up to 78 % of its loads for nothing)
       const T *src[KMAX];
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) src[j] = rows[j] ? rows[j] : buf;
@@ -183,8 +190,14 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
         }
         Vec<T>::pack(acc, o);
       };
-      int i = lane;
-      for (; i + 64 * (UNR - 1) < nvec; i += 64 * UNR) {
+      auto put = [&](int i, const vec16 &o) {
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+        if (NTS) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, o), reinterpret_cast<u32x4_t *>(d + i));
+        else d[i] = o;
+      };
+      const int hi = min(nvec, (part + 1) * per);
+      int i = part * per + lane;
+      for (; i + 64 * (UNR - 1) < hi; i += 64 * UNR) {
         vec16 v[UNR][KMAX];
 #pragma unroll
         for (int q = 0; q < UNR; ++q)
@@ -195,18 +208,18 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
         for (int q = 0; q < UNR; ++q) {
           vec16 o;
           combine(v[q], o);
-          d[i + 64 * q] = o;
+          put(i + 64 * q, o);
         }
       }
-      for (; i < nvec; i += 64) {
+      for (; i < hi; i += 64) {
         vec16 v[KMAX];
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) v[j] = reinterpret_cast<const vec16 *>(src[j])[i];
         vec16 o;
         combine(v, o);
-        d[i] = o;
+        put(i, o);
       }
-    } else {
+    } else if (part == 0) {
       for (int i = lane; i < M; i += 64) {
         float acc = 0.f;
         for (int j = 0; j < k && j < KMAX; ++j) {
@@ -303,18 +316,40 @@ extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *sl
   return 0;
 }
 
+template <typename T, int SPLIT, bool NTS>
+static void launch_decode_cfg(const void *buf, const int32_t *idx, const int32_t *loc, const void *gates,
+                              int gate_dtype, int Tn, int M, int k, int capacity, int num_experts, int chunk_rows, int expert_slice,
+                              int ep_world, void *out, hipStream_t st) {
+  int grid = dp_grid(Tn * SPLIT);
+#define DEC(KM) hipLaunchKernelGGL((decode_kernel<T, KM, SPLIT, NTS>), dim3(grid), dim3(DP_THREADS), 0, st, (const T *)buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, (T *)out)
+  switch (k) {
+    case 1: DEC(1); break;
+    case 2: DEC(2); break;
+    case 3: DEC(3); break;
+    case 4: DEC(4); break;
+    case 5: DEC(5); break;
+    case 6: DEC(6); break;
+    case 7: DEC(7); break;
+    case 8: DEC(8); break;
+    default:
+      if (k <= 12) DEC(12);
+      else DEC(16);
+  }
+#undef DEC
+}
+
+// TUTEL_OPT_DECODE (A/B on hardware, tools/decode_probe.py): -1 automatic; bit 0 = two waves per token, bit 1 = non-temporal stores
 template <typename T>
 static void launch_decode(const void *buf, const int32_t *idx, const int32_t *loc, const void *gates,
                           int gate_dtype, int Tn, int M, int k, int capacity, int num_experts, int chunk_rows, int expert_slice,
                           int ep_world, void *out, hipStream_t st) {
-  int grid = dp_grid(Tn);
-#define DEC(KM) hipLaunchKernelGGL((decode_kernel<T, KM>), dim3(grid), dim3(DP_THREADS), 0, st, (const T *)buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, (T *)out)
-  if (k <= 1) DEC(1);
-  else if (k <= 2) DEC(2);
-  else if (k <= 4) DEC(4);
-  else if (k <= 8) DEC(8);
-  else DEC(16);
-#undef DEC
+  int mode = tutel_get_option(TUTEL_OPT_DECODE);
+  if (mode < 0) mode = TUTEL_DECODE_DEFAULT;
+  const bool split = (mode & 1) && (size_t)M * sizeof(T) >= 2048;  // rows of at least two 1 KiB wave-loads
+#define GO(S, N) launch_decode_cfg<T, S, N>(buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st)
+  if (split) { if (mode & 2) GO(2, true); else GO(2, false); }
+  else { if (mode & 2) GO(1, true); else GO(1, false); }
+#undef GO
 }
 
 extern "C" int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *idx,

@@ -200,8 +200,11 @@ extern "C" int tutel_amd_ep_comm_info(const tutel_amd_ep_comm_t *c, int *world, 
 static int exchange(tutel_amd_ep_comm *c, const void *send, void *recv, size_t bytes_per_peer, int world, hipStream_t st,
                     int stage = TUTEL_STAGE_OTHER) {
   if (bytes_per_peer == 0) return 0;
+  // single rank without a communicator: the exchange is the identity -- nothing to do when the caller aliased the stage
+  // buffers (impls/ep_native.py does), a copy otherwise
+  if (c == nullptr && send == recv) return 0;
   StageScope scope(stage, st);
-  if (c == nullptr) {  // single rank without a communicator: the exchange is a copy
+  if (c == nullptr) {
     HIP_CHECK(hipMemcpyAsync(recv, send, bytes_per_peer * (size_t)world, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
     return 0;
   }
@@ -445,11 +448,19 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
   TUTEL_REQUIRE(!dropless || (c == nullptr && a.world == 1 && m->stats != nullptr && m->capacity_out != nullptr && m->max_capacity >= 1),
                 "tutel_amd_moe_forward: dropless routing needs a single rank, stats, capacity_out and max_capacity");
   int32_t *smap = const_cast<int32_t *>(a.slot_map);
-  int rc = tutel_amd_gate_topk(m->logits, m->logits_dtype, 1, T, E, k, m->normalize_gate, nullptr, const_cast<int32_t *>(a.idx),
-                               const_cast<void *>(a.gates), m->ws, m->ws_bytes, dropless ? nullptr : smap, dropless ? 0 : E * a.capacity, stream);
-  if (rc) return rc;
-  rc = tutel_amd_compute_location(a.idx, T, E, k, 1, m->ws, m->ws_bytes, const_cast<int32_t *>(a.loc), m->dispatch_count, m->stats,
-                                  m->l_aux, m->logits_dtype, dropless ? 0 : a.capacity, dropless ? nullptr : smap, dropless ? 0 : 1, stream);
+  int rc = TUTEL_AMD_ENOTSUP;
+  // top-k + locations in one launch where the fused kernel applies (tutel_amd_route) -- else, and always for T == 0, two launches
+  if (T > 0 && m->route_sync != nullptr && tutel_get_option(TUTEL_OPT_ROUTING) != 0 && m->logits_dtype != TUTEL_F64)
+    rc = tutel_amd_route(m->logits, m->logits_dtype, T, E, k, m->normalize_gate, const_cast<int32_t *>(a.idx), const_cast<void *>(a.gates),
+                         m->ws, m->ws_bytes, const_cast<int32_t *>(a.loc), m->dispatch_count, m->stats, m->l_aux,
+                         dropless ? 0 : a.capacity, dropless ? nullptr : smap, m->route_sync, stream);
+  if (rc == TUTEL_AMD_ENOTSUP) {
+    rc = tutel_amd_gate_topk(m->logits, m->logits_dtype, 1, T, E, k, m->normalize_gate, nullptr, const_cast<int32_t *>(a.idx),
+                             const_cast<void *>(a.gates), m->ws, m->ws_bytes, dropless ? nullptr : smap, dropless ? 0 : E * a.capacity, stream);
+    if (rc) return rc;
+    rc = tutel_amd_compute_location(a.idx, T, E, k, 1, m->ws, m->ws_bytes, const_cast<int32_t *>(a.loc), m->dispatch_count, m->stats,
+                                    m->l_aux, m->logits_dtype, dropless ? 0 : a.capacity, dropless ? nullptr : smap, dropless ? 0 : 1, stream);
+  }
   if (rc) return rc;
   tutel_amd_ep_args_t e = a;
   e.gate_dtype = m->logits_dtype;

@@ -211,6 +211,216 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
 }
 
 // -------------------------------------------------------------------------------------------
+// tile histograms from an externally supplied idx[k,T] (hist_ready == 0 path)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RT_THREADS) void tile_hist_kernel(const int32_t *__restrict__ idx,
+                                                              int Tn, int E, int k, int tile,
+                                                              int32_t *__restrict__ ws_hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t *s_hist = reinterpret_cast<int32_t *>(smem);
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int t0 = b * tile, t1 = min(Tn, t0 + tile);
+  for (int i = tid; i < k * E; i += RT_THREADS) s_hist[i] = 0;
+  __syncthreads();
+  for (int j = 0; j < k; ++j)
+    for (int t = t0 + tid; t < t1; t += RT_THREADS) {
+      int e = idx[(size_t)j * Tn + t];
+      if (e >= 0 && e < E) atomicAdd(&s_hist[j * E + e], 1);
+    }
+  __syncthreads();
+  for (int i = tid; i < k * E; i += RT_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
+}
+
+// -------------------------------------------------------------------------------------------
+// K2: locations.  The three phases are device functions over NW waves so that the stand-alone kernel (4 waves) and the fused
+// routing kernel below (16 waves, after its grid-wide barrier) run the same code.
+// -------------------------------------------------------------------------------------------
+// phases 1 + 2: s_cur[j][e] = absolute location of the tile's first token that picks (choice j, expert e); s_tot[j][e] = totals
+template <int NW>
+__device__ __forceinline__ void loc_prefix(int tid, int b, int E, int k, int ntiles, const int32_t *__restrict__ ws_hist,
+                                           int32_t *s_cur, int32_t *s_tot, int32_t *__restrict__ dispatch_count) {
+  const int lane = tid & 63, wid = tid >> 6, kE = k * E;
+  // base[j][e] = sum over earlier tiles, tot[j][e] = sum over all tiles.  The tile axis is
+  // split over the waves and unrolled so the (<=128) dependent-free L2 loads overlap.
+  for (int i = tid; i < kE; i += NW * 64) { s_cur[i] = 0; s_tot[i] = 0; }
+  __syncthreads();
+  for (int i = lane; i < kE; i += 64) {
+    int base = 0, tot = 0;
+    for (int tl0 = wid; tl0 < ntiles; tl0 += NW * 16) {
+      int h[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        int tl = tl0 + u * NW;
+        h[u] = (tl < ntiles) ? ws_hist[(size_t)tl * kE + i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        int tl = tl0 + u * NW;
+        tot += h[u];
+        if (tl < b) base += h[u];
+      }
+    }
+    if (wid < ntiles) {   // (waves past the tile count hold zeros)
+      atomicAdd(&s_cur[i], base);
+      atomicAdd(&s_tot[i], tot);
+    }
+  }
+  __syncthreads();
+  // choice j is queued after ALL tokens' choices < j (fast_dispatch.py:165-169)
+  for (int e = tid; e < E; e += NW * 64) {
+    int acc = 0;
+    for (int j = 0; j < k; ++j) {
+      s_cur[j * E + e] += acc;
+      acc += s_tot[j * E + e];
+    }
+    if (b == 0) dispatch_count[e] = acc;
+  }
+  __syncthreads();
+}
+
+// phase 3: stable rank inside the tile: a wave handles one choice, 64 tokens per step.  `lidx` (optional): the tile's expert
+// ids in LDS, [k][t1 - t0 rounded up to the tile]; `e_first`: the wave's first 64 ids when the caller loaded them early.
+template <int NW>
+__device__ __forceinline__ void loc_rank(int tid, int t0, int t1, int Tn, int E, int k, const int32_t *__restrict__ idx,
+                                         const int32_t *lidx, int lidx_stride, int e_first, bool have_first, int32_t *s_cur,
+                                         int32_t *__restrict__ loc, int capacity, int32_t *__restrict__ slot_map) {
+  const int lane = tid & 63, wid = tid >> 6;
+  int ebits = 0;
+  while ((1 << ebits) < E) ++ebits;
+  for (int j = wid; j < k; j += NW) {
+    int32_t *cur = s_cur + j * E;
+    for (int c0 = t0; c0 < t1; c0 += 64) {
+      int t = c0 + lane;
+      int e;
+      if (have_first && j == wid && c0 == t0) e = e_first;
+      else if (t >= t1) e = -1;
+      else e = lidx != nullptr ? lidx[j * lidx_stride + (t - t0)] : idx[(size_t)j * Tn + t];
+      bool valid = (e >= 0) && (e < E);
+      // lanes holding the same expert: AND over the bits of the expert id of (ballot of that bit,
+      // complemented where my bit is 0) -- ceil(log2 E) ballots instead of one loop iteration per
+      // distinct expert present in the wave.
+      unsigned long long same = __ballot(valid);
+      for (int bit = 0; bit < ebits; ++bit) {
+        const unsigned long long bb = __ballot(valid && ((e >> bit) & 1));
+        same &= ((e >> bit) & 1) ? bb : ~bb;
+      }
+      const int rank = __popcll(same & ((1ull << lane) - 1ull));
+      const int cnt = __popcll(same);
+      const bool leader = valid && (__ffsll((long long)same) - 1 == lane);
+      int base = valid ? cur[e] : 0;
+      int l = base + rank;
+      if (leader) cur[e] = base + cnt;
+      if (t < t1) {
+        loc[(size_t)j * Tn + t] = valid ? l : 0;
+        if (slot_map != nullptr && valid && l < capacity) slot_map[(size_t)e * capacity + l] = j * Tn + t;
+      }
+    }
+  }
+}
+
+// phase 4 (one block): max count and gshard loss.  Column sums: `parts` threads per expert, each a contiguous tile range in
+// fixed order, combined in fixed order.  The arithmetic is done by the block's first RT_THREADS threads in BOTH kernels, so the
+// loss does not depend on which kernel computed it (deterministic, bit for bit).
+template <int NW>
+__device__ __forceinline__ void loc_finish(int tid, int Tn, int E, int k, int ntiles, const float *__restrict__ ws_colsum,
+                                           const int32_t *s_tot, float *s_parts, float *s_red, int *s_redi, const float *cs_first,
+                                           bool cs_early, int32_t *__restrict__ stats, void *__restrict__ l_aux, int l_aux_dtype) {
+  const int lane = tid & 63, wid = tid >> 6;
+  const bool act = tid < RT_THREADS;
+  const int cs_parts = (E >= RT_THREADS) ? 1 : (RT_THREADS / E);
+  const int cs_per = (ntiles + cs_parts - 1) / cs_parts;
+  int mx = 0;
+  if (act)
+    for (int e = tid; e < E; e += RT_THREADS) {
+      int acc = 0;
+      for (int j = 0; j < k; ++j) acc += s_tot[j * E + e];
+      mx = max(mx, acc);
+    }
+  float part = 0.f;
+  if (l_aux != nullptr) {
+    __syncthreads();
+    const int parts = cs_parts, per = cs_per;
+    if (act)
+      for (int w = tid; w < parts * E; w += RT_THREADS) {
+        const int e = w % E, pt = w / E;
+        const int a = pt * per, z = min(ntiles, a + per);
+        float me = 0.f;
+        for (int tl0 = a; tl0 < z; tl0 += 16) {
+          float cs[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            cs[u] = (cs_early && tl0 == a) ? cs_first[u] : ((tl0 + u < z) ? ws_colsum[(size_t)(tl0 + u) * E + e] : 0.f);
+#pragma unroll
+          for (int u = 0; u < 16; ++u) me += cs[u];
+        }
+        s_parts[pt * E + e] = me;
+      }
+    __syncthreads();
+    if (act)
+      for (int e = tid; e < E; e += RT_THREADS) {
+        float me = 0.f;
+        for (int pt = 0; pt < parts; ++pt) me += s_parts[pt * E + e];
+        float ce = (float)s_tot[e] * ((float)E / (float)Tn);
+        part += me * ce;
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = max(mx, __shfl_xor(mx, o, 64));
+    part += __shfl_xor(part, o, 64);
+  }
+  if (act && lane == 0) { s_red[wid] = part; s_redi[wid] = mx; }
+  __syncthreads();
+  if (tid == 0) {
+    float p = 0.f;
+    int m2 = 0;
+    for (int w = 0; w < RT_WAVES; ++w) { p += s_red[w]; m2 = max(m2, s_redi[w]); }
+    if (stats != nullptr) stats[0] = m2;
+    if (l_aux != nullptr) {
+      const float la = p / (float)Tn;
+      if (l_aux_dtype == TUTEL_F32) reinterpret_cast<float *>(l_aux)[0] = la;
+      else if (l_aux_dtype == TUTEL_BF16) reinterpret_cast<uint16_t *>(l_aux)[0] = f32_to_bf16_bits(la);
+      else reinterpret_cast<_Float16 *>(l_aux)[0] = (_Float16)la;
+    }
+  }
+}
+
+__global__ __launch_bounds__(RT_THREADS) void location_kernel(
+    const int32_t *__restrict__ idx, int Tn, int E, int k, int tile, int ntiles,
+    const int32_t *__restrict__ ws_hist, const float *__restrict__ ws_colsum,
+    int32_t *__restrict__ loc, int32_t *__restrict__ dispatch_count, int32_t *__restrict__ stats,
+    void *__restrict__ l_aux, int l_aux_dtype, int capacity, int32_t *__restrict__ slot_map) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t *s_cur = reinterpret_cast<int32_t *>(smem);  // [k][E] running absolute location
+  int32_t *s_tot = s_cur + (size_t)k * E;              // [k][E] per-choice totals
+  float *s_parts = reinterpret_cast<float *>(smem) + (size_t)2 * k * E;  // [parts][E], see launch
+  __shared__ float s_red[RT_WAVES];
+  __shared__ int s_redi[RT_WAVES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.x;
+  const int t0 = b * tile, t1 = min(Tn, t0 + tile);
+
+  // 0. loads that depend on nothing computed here go out first, so that their round trip overlaps the one of step 1
+  //    instead of following it: this wave's first 64 expert ids (step 3) and, in block 0, a thread's share of the
+  //    per-tile score column sums (step 4).  Same values, same summation order as loading them in place.
+  int e_first = -1;
+  if (wid < k && t0 + lane < t1) e_first = idx[(size_t)wid * Tn + t0 + lane];
+  const int cs_parts = (E >= RT_THREADS) ? 1 : (RT_THREADS / E);
+  const int cs_per = (ntiles + cs_parts - 1) / cs_parts;
+  const bool cs_early = b == 0 && l_aux != nullptr && cs_parts * E <= RT_THREADS;  // one (expert, part) per thread
+  float cs_first[16];
+  if (cs_early && tid < cs_parts * E) {
+    const int e = tid % E, a = (tid / E) * cs_per, z = min(ntiles, a + cs_per);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) cs_first[u] = (a + u < z) ? ws_colsum[(size_t)(a + u) * E + e] : 0.f;
+  }
+  loc_prefix<RT_WAVES>(tid, b, E, k, ntiles, ws_hist, s_cur, s_tot, dispatch_count);
+  loc_rank<RT_WAVES>(tid, t0, t1, Tn, E, k, idx, nullptr, 0, e_first, true, s_cur, loc, capacity, slot_map);
+  if (b == 0) loc_finish<RT_WAVES>(tid, Tn, E, k, ntiles, ws_colsum, s_tot, s_parts, s_red, s_redi, cs_first, cs_early, stats, l_aux, l_aux_dtype);
+}
+
+// -------------------------------------------------------------------------------------------
 // K1, small-E variant (E <= 128): SIXTEEN lanes per token instead of a whole wave.  Lane q of a
 // 16-lane row owns the contiguous expert slice [q*EPQ, (q+1)*EPQ) in registers (EPQ = ceil(E/16)
 // <= 8), so softmax max/sum and the top-k arg-max need four row-local exchange steps (xor 1,2,4,8:
@@ -223,17 +433,33 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
 // -------------------------------------------------------------------------------------------
 #define GQ_LPT 16
 #define GQ_THREADS 1024
-template <typename T, int EPQ>
+// FUSED: the same block goes on to compute the locations (the whole of location_kernel) after a grid-wide barrier -- top-k,
+// compute_location, the slot map, dispatch counts and the loss in ONE launch.  The barrier needs every block of the grid
+// resident at once: the grid is at most RT_MAX_TILES = 128 blocks (one per CU on a 256-CU part; blocks are dispatched in index
+// order and a spinning block only ever waits for blocks that were dispatched before it or are about to be).  `sync` points to two
+// zero-initialised words: arrivals and departures; the last block to leave resets both, so the words are zero again when the
+// kernel ends (safe to replay from a HIP graph).  Cross-block visibility: tile histograms are published with a device-scope
+// release (fence + atomic add) and read after a device-scope acquire.
+struct FusedLoc {
+  int32_t *loc, *dispatch_count, *stats;
+  void *l_aux;
+  int l_aux_dtype, capacity, ntiles;
+  int32_t *slot_map;
+  unsigned int *sync;
+};
+
+template <typename T, int EPQ, bool FUSED>
 __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
-    int clear_n) {
+    int clear_n, FusedLoc fl) {
   using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ES = GQ_LPT * EPQ + 1;                                    // padded row of the score tile
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);                // [k][E]
   float *s_sc = reinterpret_cast<float *>(smem) + (size_t)k * E;      // [64][ES]
+  int32_t *s_idx = reinterpret_cast<int32_t *>(s_sc + 64 * ES);       // FUSED: [k][tile] expert ids of the tile
 
   const int tid = threadIdx.x, q = tid & (GQ_LPT - 1), tl = tid / GQ_LPT;  // tl = token slot 0..63
   const int b = blockIdx.x;
@@ -317,6 +543,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       if (c == q) myg = bv;                              // choice c parked on lane c of the row (k <= 16)
       if (q == 0 && live) {
         idx[(size_t)c * Tn + t] = be;
+        if (FUSED) s_idx[c * tile + (t - t0)] = be;
         atomicAdd(&s_hist[c * E + be], 1);
       }
     }
@@ -339,186 +566,37 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
   }
   for (int i = tid; i < k * E; i += GQ_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
   if (tid < E) ws_colsum[(size_t)b * E + tid] = colsum;
-}
+  if (!FUSED) return;
 
-// -------------------------------------------------------------------------------------------
-// tile histograms from an externally supplied idx[k,T] (hist_ready == 0 path)
-// -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RT_THREADS) void tile_hist_kernel(const int32_t *__restrict__ idx,
-                                                              int Tn, int E, int k, int tile,
-                                                              int32_t *__restrict__ ws_hist) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int32_t *s_hist = reinterpret_cast<int32_t *>(smem);
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int t0 = b * tile, t1 = min(Tn, t0 + tile);
-  for (int i = tid; i < k * E; i += RT_THREADS) s_hist[i] = 0;
+  // ---- grid-wide barrier: every tile's histogram (and column sums, and its slice of the cleared slot map) is published
+  const int ntiles = fl.ntiles;
+  __threadfence();   // release, device scope: this thread's stores above are visible before the arrival below
   __syncthreads();
-  for (int j = 0; j < k; ++j)
-    for (int t = t0 + tid; t < t1; t += RT_THREADS) {
-      int e = idx[(size_t)j * Tn + t];
-      if (e >= 0 && e < E) atomicAdd(&s_hist[j * E + e], 1);
+  if (tid == 0) {
+    __hip_atomic_fetch_add(&fl.sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(&fl.sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntiles) __builtin_amdgcn_s_sleep(2);
+    // departures: the last block out puts both words back to zero (no block can still be spinning on the arrivals then)
+    const unsigned left = __hip_atomic_fetch_add(&fl.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == (unsigned)ntiles - 1) {
+      __hip_atomic_store(&fl.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&fl.sync[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+  }
   __syncthreads();
-  for (int i = tid; i < k * E; i += RT_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
-}
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every thread: the other blocks' histograms are read from memory, not a stale line
 
-// -------------------------------------------------------------------------------------------
-// K2: locations
-// -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RT_THREADS) void location_kernel(
-    const int32_t *__restrict__ idx, int Tn, int E, int k, int tile, int ntiles,
-    const int32_t *__restrict__ ws_hist, const float *__restrict__ ws_colsum,
-    int32_t *__restrict__ loc, int32_t *__restrict__ dispatch_count, int32_t *__restrict__ stats,
-    void *__restrict__ l_aux, int l_aux_dtype, int capacity, int32_t *__restrict__ slot_map) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int32_t *s_cur = reinterpret_cast<int32_t *>(smem);  // [k][E] running absolute location
-  int32_t *s_tot = s_cur + (size_t)k * E;              // [k][E] per-choice totals
+  // ---- the location phases (== location_kernel), 16 waves.  LDS: s_cur / s_tot take over the score tile (dead now)
+  int32_t *s_cur = reinterpret_cast<int32_t *>(s_sc);                         // [k][E]
+  int32_t *s_tot = s_cur + (size_t)k * E;                                    // [k][E]
+  float *s_parts = reinterpret_cast<float *>(s_idx + (size_t)k * tile);       // [RT_THREADS] at least
   __shared__ float s_red[RT_WAVES];
   __shared__ int s_redi[RT_WAVES];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int b = blockIdx.x;
-  const int t0 = b * tile, t1 = min(Tn, t0 + tile);
-  const int kE = k * E;
-
-  // 0. loads that depend on nothing computed here go out first, so that their round trip overlaps the one of step 1
-  //    instead of following it: this wave's first 64 expert ids (step 3) and, in block 0, a thread's share of the
-  //    per-tile score column sums (step 4).  Same values, same summation order as loading them in place.
-  int e_first = -1;
-  if (wid < k && t0 + lane < t1) e_first = idx[(size_t)wid * Tn + t0 + lane];
-  const int cs_parts = (E >= RT_THREADS) ? 1 : (RT_THREADS / E);
-  const int cs_per = (ntiles + cs_parts - 1) / cs_parts;
-  const bool cs_early = b == 0 && l_aux != nullptr && cs_parts * E <= RT_THREADS;  // one (expert, part) per thread
-  float cs_first[16];
-  if (cs_early && tid < cs_parts * E) {
-    const int e = tid % E, a = (tid / E) * cs_per, z = min(ntiles, a + cs_per);
+  float cs_none[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) cs_first[u] = (a + u < z) ? ws_colsum[(size_t)(a + u) * E + e] : 0.f;
-  }
-
-  // 1. base[j][e] = sum over earlier tiles, tot[j][e] = sum over all tiles.  The tile axis is
-  //    split over the waves and unrolled so the (<=128) dependent-free L2 loads overlap.
-  for (int i = tid; i < kE; i += RT_THREADS) { s_cur[i] = 0; s_tot[i] = 0; }
-  __syncthreads();
-  for (int i = lane; i < kE; i += 64) {
-    int base = 0, tot = 0;
-    for (int tl0 = wid; tl0 < ntiles; tl0 += RT_WAVES * 16) {
-      int h[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        int tl = tl0 + u * RT_WAVES;
-        h[u] = (tl < ntiles) ? ws_hist[(size_t)tl * kE + i] : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        int tl = tl0 + u * RT_WAVES;
-        tot += h[u];
-        if (tl < b) base += h[u];
-      }
-    }
-    atomicAdd(&s_cur[i], base);
-    atomicAdd(&s_tot[i], tot);
-  }
-  __syncthreads();
-  // 2. choice j is queued after ALL tokens' choices < j (fast_dispatch.py:165-169)
-  for (int e = tid; e < E; e += RT_THREADS) {
-    int acc = 0;
-    for (int j = 0; j < k; ++j) {
-      s_cur[j * E + e] += acc;
-      acc += s_tot[j * E + e];
-    }
-    if (b == 0) dispatch_count[e] = acc;
-  }
-  __syncthreads();
-
-  // 3. stable rank inside the tile: wave handles one choice, 64 tokens per step
-  int ebits = 0;
-  while ((1 << ebits) < E) ++ebits;
-  for (int j = wid; j < k; j += RT_WAVES) {
-    int32_t *cur = s_cur + j * E;
-    for (int c0 = t0; c0 < t1; c0 += 64) {
-      int t = c0 + lane;
-      int e = (j == wid && c0 == t0) ? e_first : ((t < t1) ? idx[(size_t)j * Tn + t] : -1);
-      bool valid = (e >= 0) && (e < E);
-      // lanes holding the same expert: AND over the bits of the expert id of (ballot of that bit,
-      // complemented where my bit is 0) -- ceil(log2 E) ballots instead of one loop iteration per
-      // distinct expert present in the wave.
-      unsigned long long same = __ballot(valid);
-      for (int bit = 0; bit < ebits; ++bit) {
-        const unsigned long long bb = __ballot(valid && ((e >> bit) & 1));
-        same &= ((e >> bit) & 1) ? bb : ~bb;
-      }
-      const int rank = __popcll(same & ((1ull << lane) - 1ull));
-      const int cnt = __popcll(same);
-      const bool leader = valid && (__ffsll((long long)same) - 1 == lane);
-      int base = valid ? cur[e] : 0;
-      int l = base + rank;
-      if (leader) cur[e] = base + cnt;
-      if (t < t1) {
-        loc[(size_t)j * Tn + t] = valid ? l : 0;
-        if (slot_map != nullptr && valid && l < capacity) slot_map[(size_t)e * capacity + l] = j * Tn + t;
-      }
-    }
-  }
-
-  // 4. block 0: max count and gshard loss.  Column sums: `parts` threads per expert, each a
-  //    contiguous tile range in fixed order, combined in fixed order (deterministic).
-  if (b == 0) {
-    int mx = 0;
-    for (int e = tid; e < E; e += RT_THREADS) {
-      int acc = 0;
-      for (int j = 0; j < k; ++j) acc += s_tot[j * E + e];
-      mx = max(mx, acc);
-    }
-    float part = 0.f;
-    if (l_aux != nullptr) {
-      float *s_me = reinterpret_cast<float *>(s_cur);  // s_cur is dead after step 3 (k*E >= E floats)
-      __syncthreads();
-      const int parts = cs_parts, per = cs_per;
-      float *s_parts = reinterpret_cast<float *>(smem) + (size_t)2 * kE;  // [parts][E], see launch
-      for (int w = tid; w < parts * E; w += RT_THREADS) {
-        const int e = w % E, pt = w / E;
-        const int a = pt * per, z = min(ntiles, a + per);
-        float me = 0.f;
-        for (int tl0 = a; tl0 < z; tl0 += 16) {
-          float cs[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            cs[u] = (cs_early && tl0 == a) ? cs_first[u] : ((tl0 + u < z) ? ws_colsum[(size_t)(tl0 + u) * E + e] : 0.f);
-#pragma unroll
-          for (int u = 0; u < 16; ++u) me += cs[u];
-        }
-        s_parts[pt * E + e] = me;
-      }
-      __syncthreads();
-      for (int e = tid; e < E; e += RT_THREADS) {
-        float me = 0.f;
-        for (int pt = 0; pt < parts; ++pt) me += s_parts[pt * E + e];
-        float ce = (float)s_tot[e] * ((float)E / (float)Tn);
-        part += me * ce;
-      }
-      (void)s_me;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mx = max(mx, __shfl_xor(mx, o, 64));
-      part += __shfl_xor(part, o, 64);
-    }
-    if (lane == 0) { s_red[wid] = part; s_redi[wid] = mx; }
-    __syncthreads();
-    if (tid == 0) {
-      float p = 0.f;
-      int m2 = 0;
-      for (int w = 0; w < RT_WAVES; ++w) { p += s_red[w]; m2 = max(m2, s_redi[w]); }
-      if (stats != nullptr) stats[0] = m2;
-      if (l_aux != nullptr) {
-        const float la = p / (float)Tn;
-        if (l_aux_dtype == TUTEL_F32) reinterpret_cast<float *>(l_aux)[0] = la;
-        else if (l_aux_dtype == TUTEL_BF16) reinterpret_cast<uint16_t *>(l_aux)[0] = f32_to_bf16_bits(la);
-        else reinterpret_cast<_Float16 *>(l_aux)[0] = (_Float16)la;
-      }
-    }
-  }
+  for (int u = 0; u < 16; ++u) cs_none[u] = 0.f;
+  loc_prefix<GQ_THREADS / 64>(tid, b, E, k, ntiles, ws_hist, s_cur, s_tot, fl.dispatch_count);
+  loc_rank<GQ_THREADS / 64>(tid, t0, t1, Tn, E, k, idx, s_idx, tile, -1, false, s_cur, fl.loc, fl.capacity, fl.slot_map);
+  if (b == 0) loc_finish<GQ_THREADS / 64>(tid, Tn, E, k, ntiles, ws_colsum, s_tot, s_parts, s_red, s_redi, cs_none, false, fl.stats, fl.l_aux, fl.l_aux_dtype);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -564,10 +642,15 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cumsum_kernel(const int32_t *__
 // -------------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------------
+// the fused routing kernel applies to the small-E layout (E <= 128) while the tile's expert ids fit in LDS
+static bool route_fusable(int Tn, int E, int k) {
+  return E <= 128 && (size_t)k * rt_tile(Tn) * 4 <= 16384;
+}
+
 template <typename T>
 static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, int k, int normalize,
                             void *scores_out, int32_t *idx, void *gates, void *ws,
-                            int32_t *clear_map, int clear_n, hipStream_t st) {
+                            int32_t *clear_map, int clear_n, hipStream_t st, const FusedLoc *fused = nullptr) {
   const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
@@ -576,10 +659,22 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
     const int epq = (E + GQ_LPT - 1) / GQ_LPT;                 // 1..8
     const int epq_t = epq <= 1 ? 1 : (epq <= 2 ? 2 : (epq <= 4 ? 4 : 8));
     const size_t lds_q = ((size_t)k * E + (size_t)64 * (GQ_LPT * epq_t + 1)) * 4;
+    // fused: + the tile's expert ids [k][tile] + the column-sum parts of the loss [RT_THREADS]
+    const size_t lds_f = lds_q + ((size_t)k * tile + RT_THREADS) * 4;
+    FusedLoc fl = {};
+    if (fused != nullptr) fl = *fused;
+    fl.ntiles = nt;
 #define GQ_LAUNCH(EPQ)                                                                         \
-    hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ>), dim3(nt), dim3(GQ_THREADS), lds_q, st,  \
-                       (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out, \
-                       idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n)
+    do {                                                                                       \
+      if (fused != nullptr)                                                                    \
+        hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ, true>), dim3(nt), dim3(GQ_THREADS), lds_f, st,  \
+                           (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,      \
+                           idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, fl);                     \
+      else                                                                                     \
+        hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ, false>), dim3(nt), dim3(GQ_THREADS), lds_q, st, \
+                           (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,      \
+                           idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, fl);                     \
+    } while (0)
     if (epq_t == 1) GQ_LAUNCH(1);
     else if (epq_t == 2) GQ_LAUNCH(2);
     else if (epq_t == 4) GQ_LAUNCH(4);
@@ -588,6 +683,7 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
     TUTEL_CHECK_LAUNCH("tutel_amd_gate_topk");
     return 0;
   }
+  TUTEL_REQUIRE(fused == nullptr, "tutel_amd_route: the fused routing kernel takes E <= 128");
   const int epl = (E + 63) / 64;
 #define GT_LAUNCH(EPL)                                                                          \
   do {                                                                                          \
@@ -627,6 +723,28 @@ extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax,
   if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   return launch_gate_topk<f16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
+}
+
+extern "C" int tutel_amd_route(const void *logits, int dtype, int T, int E, int k, int normalize_gate, int32_t *idx, void *gates,
+                               void *ws, size_t ws_bytes, int32_t *loc, int32_t *dispatch_count, int32_t *stats, void *l_aux,
+                               int capacity, int32_t *slot_map, uint32_t *sync, tutel_stream_t stream) {
+  TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_route: unsupported dtype %d", dtype);
+  TUTEL_REQUIRE(T >= 1 && E >= 1 && k >= 1 && k <= RT_MAX_K && k <= E, "tutel_amd_route: bad sizes T=%d E=%d k=%d", T, E, k);
+  if (!route_fusable(T, E, k)) return TUTEL_AMD_ENOTSUP;  // (not an error: the caller runs tutel_amd_gate_topk + tutel_amd_compute_location)
+  TUTEL_REQUIRE(logits && idx && gates && ws && loc && dispatch_count && sync, "tutel_amd_route: null pointer");
+  TUTEL_REQUIRE(ws_bytes >= tutel_amd_routing_workspace_bytes(T, E, k), "tutel_amd_route: workspace too small");
+  TUTEL_REQUIRE(capacity >= 0 && (slot_map != nullptr || capacity == 0), "tutel_amd_route: a capacity needs a slot map");
+  TUTEL_REQUIRE((long long)k * T < 0x7fffffffLL, "tutel_amd_route: k*T overflows int32");
+  hipStream_t st = (hipStream_t)stream;
+  StageScope stage(TUTEL_STAGE_GATE_TOPK, st);
+  FusedLoc fl;
+  fl.loc = loc; fl.dispatch_count = dispatch_count; fl.stats = stats; fl.l_aux = l_aux; fl.l_aux_dtype = dtype;
+  fl.capacity = capacity > 0 ? capacity : 0; fl.slot_map = capacity > 0 ? slot_map : nullptr; fl.sync = sync; fl.ntiles = 0;
+  int32_t *clear = capacity > 0 ? slot_map : nullptr;
+  const int clear_n = capacity > 0 ? E * capacity : 0;
+  if (dtype == TUTEL_F32) return launch_gate_topk<float>(logits, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear, clear_n, st, &fl);
+  if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(logits, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear, clear_n, st, &fl);
+  return launch_gate_topk<f16_t>(logits, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear, clear_n, st, &fl);
 }
 
 extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int k, int hist_ready,

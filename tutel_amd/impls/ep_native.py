@@ -238,33 +238,53 @@ def usable(layer, x, crit, degree):
     return crit[4] % max(degree, 1) == 0 and degree <= 32
 
 
-class _Workspace:
-    """the buffers of one pipeline configuration + its argument struct (pointers that never change filled in once)"""
+FUSE_ENCODE = int(os.environ.get("TUTEL_AMD_FUSE_ENCODE", "1")) != 0   # A/B switch: single-rank fc1 gathers its rows from the tokens
+WS_MAX = 4   # workspaces kept per layer (least recently used goes first)
 
-    def __init__(self, layer, x, E, C, k, degree, comm):
+
+def _bucket_tokens(T):
+    """token-count bucket of a workspace: steps of a quarter of the power of two below T (at least 256), so that growing
+    batches reallocate O(log) times and a workspace is never more than ~25 % larger than needed"""
+    T = max(int(T), 1)
+    step = max(256, (1 << (T.bit_length() - 1)) // 4)
+    return (T + step - 1) // step * step
+
+
+def _bucket_capacity(C):
+    return (max(int(C), 1) + 31) // 32 * 32
+
+
+class _Workspace:
+    """the buffers of one pipeline configuration + its argument struct.  Buffers are sized for a BUCKET (T_cap tokens,
+    C_cap rows per expert): any call with T <= T_cap and capacity <= C_cap reuses them -- the strides the kernels use come
+    from the call's own T / capacity in the argument struct, the allocation only has to be large enough."""
+
+    def __init__(self, layer, x, E, C_cap, k, degree, comm, T_cap):
         ex = layer.experts
         W = layer.world_size
-        T, M = x.shape
+        M = x.shape[1]
         H, Mo = ex.batched_fc1_w.size(1), ex.output_dim
         dev, dt = x.device, x.dtype
         E_loc = E // W
-        fuse = comm is None and degree <= 1 and layer.is_postscore
+        self.T_cap, self.C_cap = int(T_cap), int(C_cap)
+        fuse = comm is None and degree <= 1 and layer.is_postscore and FUSE_ENCODE
         a = _lib.EpArgs()
-        a.T, a.M, a.H, a.M_out, a.num_experts, a.world, a.k, a.capacity, a.degree = T, M, H, Mo, E, W, k, C, max(degree, 1)
+        a.M, a.H, a.M_out, a.num_experts, a.world, a.k, a.degree = M, H, Mo, E, W, k, max(degree, 1)
         a.allow_sliced, a.dtype, a.act = 1, ops._DT[dt], ops.ACT_CODES[ex.fused_activation()]
         a.is_postscore, a.fuse_encode = int(bool(layer.is_postscore)), int(fuse)
         self.bufs = {}
 
-        def buf(name, rows, cols):
-            t = torch.empty([rows, cols], dtype=dt, device=dev)
+        def buf(name, rows, cols, alias=None):
+            t = self.bufs[alias] if alias is not None else torch.empty([rows, cols], dtype=dt, device=dev)
             self.bufs[name] = t
             setattr(a, name, t.data_ptr())
-        buf("hid", E_loc * W * C, H)
-        buf("send", E * C, Mo)
+        buf("hid", E_loc * W * C_cap, H)
+        buf("send", E * C_cap, Mo)
         if not fuse:
-            buf("enc", E * C, M)
-            buf("recv", E * C, M)
-            buf("back", E * C, Mo)
+            buf("enc", E * C_cap, M)
+            # without a communicator the "exchange" is the identity: the stage buffers alias and no copy is made (ADVICE r2)
+            buf("recv", E * C_cap, M, alias="enc" if comm is None else None)
+            buf("back", E * C_cap, Mo, alias="send" if comm is None else None)
         else:
             z = _zero_rows.get((dev, dt))
             if z is None or z.numel() < M:
@@ -275,6 +295,26 @@ class _Workspace:
         if comm is not None and hasattr(comm, "register"):
             for t in self.bufs.values():
                 comm.register(t)
+
+
+def _workspace(layer, static_key, T, C, make):
+    """least-recently-used cache of at most WS_MAX workspaces per layer; a hit is ANY workspace of the same configuration
+    that is large enough (variable token counts -- serving -- keep hitting the largest one allocated so far)"""
+    import collections
+    cache = layer.__dict__.get("_ep_workspaces")
+    if not isinstance(cache, collections.OrderedDict):
+        cache = layer.__dict__["_ep_workspaces"] = collections.OrderedDict()
+    for key, ws in cache.items():
+        if key[0] == static_key and ws.T_cap >= T and ws.C_cap >= C:
+            cache.move_to_end(key)
+            return ws
+    T_cap, C_cap = _bucket_tokens(T), _bucket_capacity(C)
+    ws = make(T_cap, C_cap)
+    cache[(static_key, T_cap, C_cap)] = ws
+    layer.__dict__["_ep_workspace_allocations"] = layer.__dict__.get("_ep_workspace_allocations", 0) + 1
+    while len(cache) > WS_MAX:
+        cache.popitem(last=False)
+    return ws
 
 
 def forward(layer, x, crit, degree):
@@ -289,15 +329,11 @@ def forward(layer, x, crit, degree):
         return None
     if not with_comm:
         degree = 1  # a single rank has nothing to overlap (the reference returns expert_fn(input) there, overlap.py:16-17)
-    key = (tuple(x.shape), x.dtype, x.device, crit[0], crit[4], crit.idx2d.shape[0], degree, bool(layer.is_postscore),
-           ex.fused_activation(), ops._stream(), with_comm)
-    cache = layer.__dict__.setdefault("_ep_workspaces", {})
-    ws = cache.get(key)
-    if ws is None:
-        if len(cache) > 8:
-            cache.clear()
-        ws = cache[key] = _Workspace(layer, x, crit[0], crit[4], crit.idx2d.shape[0], degree, comm)
+    k = crit.idx2d.shape[0]
+    key = ("ep", x.shape[1], x.dtype, x.device, crit[0], k, degree, bool(layer.is_postscore), ex.fused_activation(), ops._stream(), with_comm)
+    ws = _workspace(layer, key, x.shape[0], crit[4], lambda Tc, Cc: _Workspace(layer, x, crit[0], Cc, k, degree, comm, Tc))
     a = ws.args
+    a.T, a.capacity = x.shape[0], crit[4]
     w1, b1, w2, b2, kmajor = ex.fused_params(x.dtype)
     gates = crit.gates2d
     y = torch.empty([x.shape[0], ex.output_dim], dtype=x.dtype, device=x.device)
@@ -325,15 +361,18 @@ def forward(layer, x, crit, degree):
 class _MoeWorkspace(_Workspace):
     """_Workspace + the routing buffers (idx / loc / gates / slot map / per-tile histograms), all reused call after call"""
 
-    def __init__(self, layer, x, logits, k, capacity, degree, comm):
-        E, T = logits.shape[1], logits.shape[0]
+    def __init__(self, layer, x, logits, k, capacity, degree, comm, T_cap):
+        E, T = logits.shape[1], int(T_cap)
         dev = x.device
-        super().__init__(layer, x, E, capacity, k, degree, comm)
+        super().__init__(layer, x, E, capacity, k, degree, comm, T_cap)
         self.idx = torch.empty([k, T], dtype=torch.int32, device=dev)
         self.loc = torch.empty([k, T], dtype=torch.int32, device=dev)
         self.gates = torch.empty([k, T], dtype=logits.dtype, device=dev)
         self.slot_map = torch.empty([E * capacity], dtype=torch.int32, device=dev)
-        self.ws = ops.routing_workspace(T, E, k, dev)
+        # routing scratch for the largest tiling any T takes (<= 128 token tiles, csrc/routing.hip); route_sync: the two words
+        # the fused routing kernel synchronises its blocks on (zero-initialised once, the kernel leaves them zero)
+        self.ws = torch.empty([max(int(_lib.lib().tutel_amd_routing_workspace_bytes(64 * 128, E, k)), 4)], dtype=torch.uint8, device=dev)
+        self.route_sync = torch.zeros([2], dtype=torch.int32, device=dev)
         self.stats = torch.empty([1], dtype=torch.int32, device=dev)
         # the dropless capacity is read back into this workspace's own pinned word (no process-global slot: ADVICE r2)
         self.cap_host = torch.zeros([1], dtype=torch.int32).pin_memory()
@@ -345,6 +384,7 @@ class _MoeWorkspace(_Workspace):
         m.logits_dtype = ops._DT[logits.dtype]
         m.ws, m.ws_bytes, m.stats = self.ws.data_ptr(), self.ws.numel(), self.stats.data_ptr()
         m.capacity_out = ctypes.pointer(self.cap_c)
+        m.route_sync = self.route_sync.data_ptr()
         self.margs = m
 
 
@@ -368,16 +408,12 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
     if dropless is not None:
         capacity = max(capacity, sizes.get(skey, 0))
     for attempt in range(4):
-        key = ("moe", tuple(x.shape), x.dtype, x.device, tuple(logits.shape), logits.dtype, k, capacity, degree, bool(layer.is_postscore),
+        key = ("moe", x.shape[1], x.dtype, x.device, logits.shape[1], logits.dtype, k, degree, bool(layer.is_postscore),
                ex.fused_activation(), ops._stream(), with_comm)
-        cache = layer.__dict__.setdefault("_ep_workspaces", {})
-        ws = cache.get(key)
-        if ws is None:
-            if len(cache) > 8:
-                cache.clear()
-            ws = cache[key] = _MoeWorkspace(layer, x, logits, k, capacity, degree, comm)
+        ws = _workspace(layer, key, x.shape[0], capacity, lambda Tc, Cc: _MoeWorkspace(layer, x, logits, k, Cc, degree, comm, Tc))
         m = ws.margs
         a = m.ep
+        a.T = x.shape[0]
         w1, b1, w2, b2, kmajor = ex.fused_params(x.dtype)
         dev = x.device
         y = torch.empty([x.shape[0], ex.output_dim], dtype=x.dtype, device=dev)
@@ -398,7 +434,7 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
         cap_out = ws.cap_c
         if dropless is not None:
             a.capacity = 0
-            m.capacity_limit, m.alignment, m.max_capacity = int(dropless[0]), int(dropless[1]), int(capacity)
+            m.capacity_limit, m.alignment, m.max_capacity = int(dropless[0]), int(dropless[1]), int(ws.C_cap)
         else:
             a.capacity = int(capacity)
             m.capacity_limit, m.alignment, m.max_capacity = 0, 1, int(capacity)

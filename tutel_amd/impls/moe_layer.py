@@ -228,54 +228,81 @@ class MOELayer(torch.nn.Module):
         self.protected_shape = torch.Size([E_loc, W * Cc, Mo])
         return C.simple_all_to_all(send, group=self.group)
 
-    def _fast_path(self, x, gate, top_k, capacity_factor, degree, alignment, reserve_shape, inequivalent_tokens,
-                   megablocks_size, adaptive_r, original_dtype):
-        cf = capacity_factor or gate.capacity_factor
-        dropless = cf <= 0   # capacity = max expert load: read back inside the native call, single rank only
-        if (not ep_native.ENABLED or not ep_native.FAST_PATH or not x.is_cuda or _FORCE_OVERLAP or torch.is_autocast_enabled()
-                or (dropless and self.world_size > 1) or inequivalent_tokens
-                or (megablocks_size > 0 and not (dropless and self.is_postscore))
-                or self.batch_prioritized_routing or not self.is_gshard_loss or len(reserve_shape) != 1 or C.SKIP_A2A
-                or (adaptive_r if adaptive_r is not None else self.adaptive_degree) == 0
-                or self.num_global_experts < self.world_size or not isinstance(self.experts, FusedExpertsNetwork)
-                or (degree > 1 and self.use_2dh) or degree > 32 or (self.training and gate.gate_noise > 0)
-                or not self.experts.can_fuse(x, self)):
-            return None
-        if self.world_size > 1 and not (dist.is_initialized() and (dist.get_backend(self.group) == "nccl" or ep_native.HOSTED)):
-            return None
-        with torch.autocast("cuda", enabled=False):
-            logits = gate(x)
-        if (logits.dtype not in (torch.float32, torch.bfloat16, torch.float16) or logits.dim() != 2
-                or (torch.is_grad_enabled() and logits.requires_grad)
-                or not (x.dtype == logits.dtype or (logits.dtype == torch.float32 and x.dtype == original_dtype))):
-            return None   # (the gate projection is recomputed by the general path: rare configurations only)
+    # ---- which device path runs this forward: every predicate in ONE place -------------------------------------------
+    # Paths (same results; tests assert their equality):
+    #   "native_moe"     routing + encode + exchange(s) + expert FFN + exchange(s) + decode in ONE native call
+    #                    (tutel_amd_moe_forward): inference with the capacity known up front, or dropless on a single rank
+    #   "native_ep"      the same pipeline after a separate routing step (tutel_amd_ep_forward): batch-prioritised routing,
+    #                    load-importance loss, gate noise, unequal token counts, autocast, a trainable router with frozen experts
+    #   "python_overlap" the overlapped pipeline orchestrated from Python over torch.distributed (impls/overlap.py): gloo
+    #                    rendezvous, or the library communicator could not be created
+    #   "fused_encode"   single rank: fc1 gathers its rows from the tokens, no bucket array (what native_* does when the
+    #                    native pipeline is switched off)
+    #   "generic"        the reference's op sequence on the HIP ops: training (autograd), custom / fp32 experts, CPU tensors,
+    #                    sharded experts, adaptive_r = 0, 2DH with overlap
+    def _plan(self, stage, x, logits, gate, top_k, cf, degree, alignment, reserve_shape, inequivalent_tokens, megablocks_size,
+              original_dtype, crit=None, allow_native=True):
+        W = self.world_size
+        fusable = (x.is_cuda and len(reserve_shape) == 1 and isinstance(self.experts, FusedExpertsNetwork) and not C.SKIP_A2A
+                   and self.num_global_experts >= W and self.adaptive_degree != 0 and logits.dim() == 2
+                   and (x.dtype == logits.dtype or (logits.dtype == torch.float32 and x.dtype == original_dtype))
+                   and self.experts.can_fuse(x, self))
+        if not fusable:
+            return "generic"
+        native = (allow_native and ep_native.ENABLED and not _FORCE_OVERLAP and degree <= 32 and (degree == 1 or not self.use_2dh)
+                  and (W == 1 or (dist.is_initialized() and (dist.get_backend(self.group) == "nccl" or ep_native.HOSTED))))
+        if stage == "before_routing":
+            T, E = logits.shape
+            k = min(top_k, E)
+            dropless = cf <= 0
+            ok = (native and ep_native.FAST_PATH and not torch.is_autocast_enabled() and not inequivalent_tokens
+                  and not self.batch_prioritized_routing and self.is_gshard_loss and not (self.training and gate.gate_noise > 0)
+                  and logits.dtype in (torch.float32, torch.bfloat16, torch.float16)
+                  and not (torch.is_grad_enabled() and logits.requires_grad)
+                  and k <= 16 and E <= 1024 and k * E <= 8192)
+            if ok and dropless:   # capacity = max expert load: read back inside the native call, single rank only
+                ok = W == 1 and (megablocks_size == 0 or self.is_postscore)
+            elif ok:
+                ok = megablocks_size == 0 and self._static_capacity(T, E, k, cf, alignment) > 0 \
+                    and self._static_capacity(T, E, k, cf, alignment) % max(degree, 1) == 0
+            return "native_moe" if ok else "routed"
+        # after routing: crit is known
+        plan_ok = isinstance(crit, RoutingPlan)
+        if native and plan_ok and ep_native.usable(self, x, crit, degree):
+            return "native_ep"
+        if (degree > 1 and plan_ok and (W > 1 or _FORCE_OVERLAP) and crit[4] > 0 and crit[4] % degree == 0 and not self.use_2dh
+                and crit.gates2d is not None):   # (a trainable router keeps its gates in crit[3] with autograd -> generic)
+            return "python_overlap"
+        if W == 1 and self.is_postscore and plan_ok and crit[4] > 0 and _FUSE_ENCODE:
+            return "fused_encode"
+        return "generic"
+
+    @staticmethod
+    def _static_capacity(T, E, k, cf, alignment):
+        """capacity_factor > 0: k * int(cf * ceil(T / E)) rounded up to the alignment (fast_dispatch.py:188-199)"""
+        capacity = k * int(cf * ((T + E - 1) // E))
+        rem = capacity % alignment
+        return capacity + ((alignment - rem) if rem > 0 else 0)
+
+    def _run_native_moe(self, x, logits, top_k, cf, degree, alignment, megablocks_size):
         T, E = logits.shape
         k = min(top_k, E)
-        if k > 16 or E > 1024 or k * E > 8192:
-            return None
         spe = (T + E - 1) // E
-        if dropless:   # capacity = max expert load, read back inside the native call (fast_dispatch.py:191-199)
+        xc = x if x.is_contiguous() else x.contiguous()
+        if cf <= 0:   # dropless: capacity = max expert load, read back inside the native call (fast_dispatch.py:191-199)
             guess = (k * spe * 3 // 2 + 31) // 32 * 32
-            res = ep_native.forward_from_logits(self, x if x.is_contiguous() else x.contiguous(), logits.contiguous(), k, guess, 1,
-                                                self.normalize_gate, want_loss=True, dropless=(k * int(-cf * spe) if cf < 0 else 0, alignment),
-                                                megablocks_size=megablocks_size)
+            res = ep_native.forward_from_logits(self, xc, logits.contiguous(), k, guess, 1, self.normalize_gate, want_loss=True,
+                                                dropless=(k * int(-cf * spe) if cf < 0 else 0, alignment), megablocks_size=megablocks_size)
         else:
-            capacity = k * int(cf * spe)
-            rem = capacity % alignment
-            capacity += (alignment - rem) if rem > 0 else 0
-            if capacity <= 0 or capacity % max(degree, 1) != 0:
-                return None
-            res = ep_native.forward_from_logits(self, x if x.is_contiguous() else x.contiguous(), logits.contiguous(), k, capacity,
-                                                degree, self.normalize_gate, want_loss=True)
-        if res is None:
+            res = ep_native.forward_from_logits(self, xc, logits.contiguous(), k, self._static_capacity(T, E, k, cf, alignment), degree,
+                                                self.normalize_gate, want_loss=True)
+        if res is None:   # the library's communicator could not be created: every rank falls back together
             return None
         y, l_aux, cnt, capacity = res
         self.megablocks_size = megablocks_size
         self.dispatch_count = cnt
-        if adaptive_r is not None:
-            self.adaptive_degree = adaptive_r
         if C.get_world_rank(self.group) == 0 and logging.getLogger().isEnabledFor(logging.INFO):
-            logging.info("Capacity = %d, real-time capacity-factor for top-%d = %s", capacity, top_k, capacity / max(1, k * ((T + E - 1) // E)))
+            logging.info("Capacity = %d, real-time capacity-factor for top-%d = %s", capacity, top_k, capacity / max(1, k * spe))
         return y, l_aux
 
     # ---- forward ------------------------------------------------------------------------
@@ -302,27 +329,36 @@ class MOELayer(torch.nn.Module):
             self.a2a_ffn_overlap_degree = a2a_ffn_overlap_degree
         degree = self.a2a_ffn_overlap_degree
         top_k = top_k or gate.top_k
+        cf = capacity_factor or gate.capacity_factor
         if megablocks_size > 0 and (self.num_local_experts <= 1 or torch.is_grad_enabled() or self.world_size > 1):
             megablocks_size = 0
+        if adaptive_r is not None:
+            self.adaptive_degree = adaptive_r
 
         mega = max(megablocks_size, 1)
         alignment = (self.sharded_count * degree + mega - 1) // mega * mega
         if alignment > 256:
             alignment = (alignment + 127) // 128 * 128
 
-        # ---- fast path: everything after the gate projection in ONE native call (tutel_amd_moe_forward) -----------------
-        # inference configuration of the headline metric: capacity known up front (capacity_factor > 0), gshard loss,
-        # no batch-prioritised routing, no autograd, fused-able FFN experts
-        fast = self._fast_path(x, gate, top_k, capacity_factor, degree, alignment, reserve_shape, inequivalent_tokens,
-                               megablocks_size, adaptive_r, original_dtype)
-        if fast is not None:
-            y, l_aux = fast
+        def finish(y, l_aux):
             y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
             self.l_aux = y.l_aux = l_aux
             return self.result_func(y) if self.result_func is not None else y
 
-        def routing():
+        # the gate projection: computed ONCE, autocast off (moe_layer.py:315-323), whatever path consumes it
+        if x.is_cuda:
+            with torch.autocast("cuda", enabled=False):
+                logits = gate(x)
+        else:
             logits = gate(x)
+        plan_args = (gate, top_k, cf, degree, alignment, reserve_shape, inequivalent_tokens, megablocks_size, original_dtype)
+
+        if self._plan("before_routing", x, logits, *plan_args) == "native_moe":
+            res = self._run_native_moe(x, logits, top_k, cf, degree, alignment, megablocks_size)
+            if res is not None:
+                return finish(*res)
+
+        def routing():
             noisy = logits
             if self.training and gate.gate_noise > 0:
                 noisy = logits + gate.gate_noise * torch.randn_like(logits) / self.num_global_experts
@@ -333,7 +369,7 @@ class MOELayer(torch.nn.Module):
                     return losses.load_importance_loss(F.softmax(logits, dim=1), noisy.gather(index=topk_ids, dim=1),
                                                        self.num_global_experts, gate.gate_noise)
             return logits.dtype, extract_critical(
-                None, top_k=top_k, loss_fn=loss_fn, capacity_factor=capacity_factor or gate.capacity_factor,
+                None, top_k=top_k, loss_fn=loss_fn, capacity_factor=cf,
                 batch_prioritized_routing=self.batch_prioritized_routing, normalize_gate=self.normalize_gate,
                 group=self.group, alignment=alignment, inequivalent_tokens=inequivalent_tokens, _logits=noisy)
 
@@ -345,50 +381,28 @@ class MOELayer(torch.nn.Module):
 
         self.megablocks_size = megablocks_size
         self.dispatch_count = get_dispatch_count(crit)
-        if adaptive_r is not None:
-            self.adaptive_degree = adaptive_r
+        plan = self._plan("after_routing", x, logits, *plan_args, crit=crit)
 
-        # the whole post-routing pipeline behind ONE native call (csrc/ep.hip): encode -> all-to-all -> expert FFN ->
-        # all-to-all -> decode, `degree` stages pipelined over the caller's stream and the library's RCCL stream
-        if (x.is_cuda and self.adaptive_degree != 0 and len(reserve_shape) == 1 and not _FORCE_OVERLAP
-                and self.num_global_experts >= self.world_size and isinstance(self.experts, FusedExpertsNetwork)
-                and isinstance(crit, RoutingPlan) and not C.SKIP_A2A and (degree == 1 or not self.use_2dh)
-                and (x.dtype == logits_dtype or (logits_dtype == torch.float32 and x.dtype == original_dtype))
-                and ep_native.usable(self, x, crit, degree) and self.experts.can_fuse(x, self)):
+        if plan == "native_ep":
+            # the whole post-routing pipeline behind ONE native call (csrc/ep.hip): encode -> all-to-all -> expert FFN ->
+            # all-to-all -> decode, `degree` stages pipelined over the caller's stream and the library's side stream
             y = ep_native.forward(self, x if x.is_contiguous() else x.contiguous(), crit, degree)
             if y is not None:
-                y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
-                self.l_aux = y.l_aux = l_aux
-                return self.result_func(y) if self.result_func is not None else y
+                return finish(y, l_aux)
+            plan = self._plan("after_routing", x, logits, *plan_args, crit=crit, allow_native=False)   # no communicator: all ranks agree
 
-        # overlapped expert parallelism on the HIP path: one fused routine, no layout copies
-        if (degree > 1 and x.is_cuda and self.adaptive_degree != 0 and len(reserve_shape) == 1
-                and (self.world_size > 1 or _FORCE_OVERLAP) and self.num_global_experts >= self.world_size
-                and isinstance(self.experts, FusedExpertsNetwork) and isinstance(crit, RoutingPlan)
-                and crit[4] > 0 and crit[4] % degree == 0 and not C.SKIP_A2A and not self.use_2dh
-                and crit.gates2d is not None  # trainable router: gates live in crit[3] with autograd -> generic path
-                and (x.dtype == logits_dtype or (logits_dtype == torch.float32 and x.dtype == original_dtype))
-                and self.experts.can_fuse(x, self)):
+        if plan == "python_overlap":   # overlapped expert parallelism driven from Python: one fused routine, no layout copies
             y = a2a_ffn_overlap_fused(self, x if x.is_contiguous() else x.contiguous(), crit, degree, self.is_postscore)
-            y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
-            self.l_aux = y.l_aux = l_aux
-            return self.result_func(y) if self.result_func is not None else y
+            return finish(y, l_aux)
 
-        # single rank, is_postscore: fast_encode is a pure row copy, so fc1 gathers its rows straight
-        # from the tokens through the slot map -- the [E,C,M] bucket array is never materialised
-        if (self.world_size == 1 and self.is_postscore and x.is_cuda and len(reserve_shape) == 1
-                and isinstance(self.experts, FusedExpertsNetwork) and isinstance(crit, RoutingPlan)
-                and crit[4] > 0 and _FUSE_ENCODE
-                and (x.dtype == logits_dtype or (logits_dtype == torch.float32 and x.dtype == original_dtype))
-                and self.experts.can_fuse(x, self)):
-            y = self.experts.forward_fused(x if x.is_contiguous() else x.contiguous(), self, R=crit[4],
-                                           slot_map=crit.slot_map)
+        if plan == "fused_encode":
+            # single rank, is_postscore: fast_encode is a pure row copy, so fc1 gathers its rows straight
+            # from the tokens through the slot map -- the [E,C,M] bucket array is never materialised
+            y = self.experts.forward_fused(x if x.is_contiguous() else x.contiguous(), self, R=crit[4], slot_map=crit.slot_map)
             self.protected_shape = y.shape
-            y = fast_decode(y, crit, self.is_postscore)
-            y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
-            self.l_aux = y.l_aux = l_aux
-            return self.result_func(y) if self.result_func is not None else y
+            return finish(fast_decode(y, crit, self.is_postscore), l_aux)
 
+        # ---- generic: the reference's op sequence -----------------------------------------------------------------------
         # encode: with is_postscore the bucket rows are verbatim copies, so the reference's
         # round trip through logits_dtype (moe_layer.py:327) is value-preserving and skipped.
         if self.is_postscore or x.dtype == logits_dtype:
@@ -438,9 +452,7 @@ class MOELayer(torch.nn.Module):
             y = fast_decode(y if y.is_contiguous() else y.contiguous(), crit, self.is_postscore)
         else:
             y = fast_decode(y.to(logits_dtype), crit, self.is_postscore)
-        y = y.view(list(original_shape[:-reserve_dims]) + list(self.protected_shape[-reserve_dims:])).to(original_dtype)
-        self.l_aux = y.l_aux = l_aux
-        return self.result_func(y) if self.result_func is not None else y
+        return finish(y, l_aux)
 
 
 moe_layer = MOELayer

@@ -110,6 +110,35 @@ def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False, l_aux_dtype=
     return loc, cnt, stats, l_aux, smap
 
 
+def route(logits, k, capacity, normalize_gate=True, sync=None):
+    """softmax + top-k + locations + slot map + counts + gshard loss in ONE launch (tutel_amd_route).  Returns
+    (idx [k,T], gates [k,T], loc [k,T], dispatch_count [E], stats [1], l_aux [1], slot_map | None), or None when the
+    fused kernel does not take this shape (E > 128, huge tiles): the caller then uses gate_topk + compute_location.
+    sync: an int32[2] tensor that was ZERO before its first use (reused call after call)."""
+    _dev(logits)
+    assert logits.dim() == 2 and logits.is_contiguous()
+    T, E = logits.shape
+    k = min(int(k), E)
+    dev = logits.device
+    if sync is None:
+        sync = torch.zeros([2], dtype=torch.int32, device=dev)
+    idx = torch.empty([k, T], dtype=torch.int32, device=dev)
+    loc = torch.empty_like(idx)
+    gates = torch.empty([k, T], dtype=logits.dtype, device=dev)
+    cnt = torch.empty([E], dtype=torch.int32, device=dev)
+    stats = torch.empty([1], dtype=torch.int32, device=dev)
+    l_aux = torch.empty([1], dtype=logits.dtype, device=dev)
+    smap = torch.empty([E * capacity], dtype=torch.int32, device=dev) if capacity > 0 else None
+    ws = routing_workspace(T, E, k, dev)
+    rc = _lib.lib().tutel_amd_route(_ptr(logits), _code(logits), T, E, k, int(bool(normalize_gate)), _ptr(idx), _ptr(gates), _ptr(ws),
+                                    ws.numel(), _ptr(loc), _ptr(cnt), _ptr(stats), _ptr(l_aux), int(capacity), _ptr(smap), _ptr(sync),
+                                    _stream())
+    if rc == _lib.ENOTSUP:
+        return None
+    _lib.check(rc, "tutel_amd_route")
+    return idx, gates, loc, cnt, stats, l_aux, smap
+
+
 def slot_map(idx, loc, E, capacity):
     _dev(idx, loc)
     assert idx.dtype == torch.int32 and loc.dtype == torch.int32
