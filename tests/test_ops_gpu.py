@@ -462,3 +462,54 @@ def test_routing_limits_fail_loudly_and_the_edges_work(oracle):
         with pytest.raises(_lib.TutelAmdError) as ei:
             moe.top_k_routing(scores, k)
         assert word in str(ei.value), str(ei.value)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_fused_routing_kernel_equals_the_two_launches(oracle, dtype):
+    """tutel_amd_route (top-k + grid barrier + locations in one launch) returns, bit for bit, what tutel_amd_gate_topk +
+    tutel_amd_compute_location return -- idx, gates, loc, slot map, counts, max load AND the loss -- and the integers are the
+    oracle's.  Same sync words reused call after call (the kernel must leave them zero), also from a replayed HIP graph."""
+    from tutel_amd import ops
+    g = torch.Generator().manual_seed(17)
+    sync = torch.zeros([2], dtype=torch.int32, device="cuda")
+    bits = torch.int32 if dtype == torch.float32 else torch.int16
+    shapes = [(4096, 64, 2, 128), (4095, 64, 2, 0), (1, 8, 2, 4), (63, 16, 1, 8), (777, 128, 4, 40), (8192, 32, 2, 512),
+              (20000, 64, 2, 700), (65536, 64, 2, 2048), (300, 5, 3, 200), (2048, 128, 16, 256)]
+    for T, E, k, cap in shapes:
+        logits = torch.randn([T, E], generator=g).to(dtype).cuda()
+        got = ops.route(logits, k, cap, sync=sync)
+        assert got is not None, (T, E, k)
+        idx, gates, loc, cnt, stats, l_aux, smap = got
+        pre = torch.empty([E * cap], dtype=torch.int32, device="cuda") if cap > 0 else None
+        idx2, gates2, ws, _ = ops.gate_topk(logits, k, apply_softmax=True, clear=pre)
+        loc2, cnt2, stats2, l2, smap2 = ops.compute_location(idx2, E, ws=ws, capacity=cap, want_l_aux=True, l_aux_dtype=dtype, cleared_slot_map=pre)
+        tag = (T, E, k, cap)
+        assert torch.equal(idx, idx2) and torch.equal(gates.view(bits), gates2.view(bits)), tag
+        assert torch.equal(loc, loc2) and torch.equal(cnt, cnt2) and torch.equal(stats, stats2), tag
+        assert torch.equal(l_aux.view(bits), l2.view(bits)), (tag, float(l_aux), float(l2))
+        if cap > 0:
+            assert torch.equal(smap, smap2), tag
+        assert int(sync.abs().sum()) == 0, "the barrier words must be zero again when the kernel ends"
+        if dtype == torch.float32:   # tie-free: the oracle's integers
+            crit, _ = oracle.extract_critical(torch.softmax(logits.cpu(), dim=1), k, 1.0)
+            assert torch.equal(idx.cpu(), torch.stack(crit[1])) and torch.equal(loc.cpu(), torch.stack(crit[2])) and torch.equal(cnt.cpu(), crit[5]), tag
+    assert ops.route(torch.randn([64, 256]).cuda(), 2, 4, sync=sync) is None   # E > 128: not this kernel's shape, nothing launched
+    # replayed from a HIP graph: the self-resetting barrier must work launch after launch without host help
+    logits = torch.randn([4096, 64], generator=g).to(dtype).cuda()
+    want = ops.route(logits, 2, 128, sync=sync)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.route(logits, 2, 128, sync=sync)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            out = ops.route(logits, 2, 128, sync=sync)
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(5):
+        for t in out:
+            t.fill_(-7)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out[:4], want[:4])) and torch.equal(out[6], want[6])
+    assert int(sync.abs().sum()) == 0
