@@ -380,7 +380,9 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *                        with a two- / three-slot LDS ring (k-major weights), 4 always the 256 x 256 ping-pong kernel
  *                        (automatic: > 128 rows per expert and enough tiles to cover the chip)
  *   TUTEL_OPT_DECODE     fast_decode launch shape: bit 0 = two waves per token, bit 1 = non-temporal stores of the output
- *   TUTEL_OPT_ROUTING    tutel_amd_moe_forward: 0 = top-k and location as two launches, 1 = the fused routing kernel
+ *                        (automatic: 2)
+ *   TUTEL_OPT_ROUTING    tutel_amd_moe_forward: 0 / automatic = top-k and location as two launches, 1 = the fused routing kernel
+ *                        (tutel_amd_route; measured equal on MI355X, so not the default)
  *   TUTEL_OPT_GEMM_PERSIST  256 x 256 ping-pong kernel: 0 = one tile per workgroup, 1 = persistent workgroups looping over tiles
  *                        (automatic: persistent when a launch has more tiles than the GPU has compute units) */
 #define TUTEL_OPT_GEMM_IMPL 0

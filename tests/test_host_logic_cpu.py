@@ -541,7 +541,7 @@ def test_workspace_cache_is_lru_over_size_buckets():
     assert len(made) <= 3 and lay._ep_workspace_allocations == len(made), made
     for T in (1, 255, 256, 257, 4096, 4097, 65536, 100000):
         b = N._bucket_tokens(T)
-        assert T <= b < T + max(256, T // 4 + 1), (T, b)
+        assert T <= b < max(257, 2 * T) and b & (b - 1) == 0, (T, b)
     # another configuration does not hit; the cache holds at most WS_MAX workspaces and drops the least recently used
     for i in range(6):
         N._workspace(lay, ("other", i), 512, 32, make)

@@ -16,7 +16,7 @@
 
 #define DP_THREADS 256
 #define DP_WAVES 4
-#define TUTEL_DECODE_DEFAULT 0   // see launch_decode
+#define TUTEL_DECODE_DEFAULT 2   // non-temporal stores: -1..2 us of a 263 us forward (profiles/r03_routing_fused_and_decode_ab.txt)
 
 
 __device__ __forceinline__ float load_gate(const void *g, int gate_dtype, size_t i) {

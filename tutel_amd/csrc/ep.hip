@@ -449,8 +449,9 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
                 "tutel_amd_moe_forward: dropless routing needs a single rank, stats, capacity_out and max_capacity");
   int32_t *smap = const_cast<int32_t *>(a.slot_map);
   int rc = TUTEL_AMD_ENOTSUP;
-  // top-k + locations in one launch where the fused kernel applies (tutel_amd_route) -- else, and always for T == 0, two launches
-  if (T > 0 && m->route_sync != nullptr && tutel_get_option(TUTEL_OPT_ROUTING) != 0 && m->logits_dtype != TUTEL_F64)
+  // top-k + locations in one launch (tutel_amd_route) only on request, TUTEL_OPT_ROUTING = 1: measured equal to the two launches
+  // (17.8 vs 9.6 + 8.6 us, profiles/r03_routing_fused_and_decode_ab.txt) -- the default stays two launches
+  if (T > 0 && m->route_sync != nullptr && tutel_get_option(TUTEL_OPT_ROUTING) == 1 && m->logits_dtype != TUTEL_F64)
     rc = tutel_amd_route(m->logits, m->logits_dtype, T, E, k, m->normalize_gate, const_cast<int32_t *>(a.idx), const_cast<void *>(a.gates),
                          m->ws, m->ws_bytes, const_cast<int32_t *>(a.loc), m->dispatch_count, m->stats, m->l_aux,
                          dropless ? 0 : a.capacity, dropless ? nullptr : smap, m->route_sync, stream);

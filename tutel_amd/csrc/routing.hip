@@ -235,8 +235,26 @@ __global__ __launch_bounds__(RT_THREADS) void tile_hist_kernel(const int32_t *__
 // K2: locations.  The three phases are device functions over NW waves so that the stand-alone kernel (4 waves) and the fused
 // routing kernel below (16 waves, after its grid-wide barrier) run the same code.
 // -------------------------------------------------------------------------------------------
+// COH = the fused kernel: data another block of the SAME launch wrote (or will overwrite) moves with device-scope relaxed atomics
+// (sc1 accesses: coherent across the XCDs' L2s without a cache-wide write-back / invalidate -- a device-scope release + acquire
+// fence pair around the barrier cost 25 us of a 40 us kernel, profiles/r03_routing_fused.txt).
+template <bool COH> __device__ __forceinline__ int ld_i32(const int32_t *p) {
+  return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COH> __device__ __forceinline__ float ld_f32(const float *p) {
+  return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COH> __device__ __forceinline__ void st_i32(int32_t *p, int v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH> __device__ __forceinline__ void st_f32(float *p, float v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
 // phases 1 + 2: s_cur[j][e] = absolute location of the tile's first token that picks (choice j, expert e); s_tot[j][e] = totals
-template <int NW>
+template <int NW, bool COH = false>
 __device__ __forceinline__ void loc_prefix(int tid, int b, int E, int k, int ntiles, const int32_t *__restrict__ ws_hist,
                                            int32_t *s_cur, int32_t *s_tot, int32_t *__restrict__ dispatch_count) {
   const int lane = tid & 63, wid = tid >> 6, kE = k * E;
@@ -251,7 +269,7 @@ __device__ __forceinline__ void loc_prefix(int tid, int b, int E, int k, int nti
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         int tl = tl0 + u * NW;
-        h[u] = (tl < ntiles) ? ws_hist[(size_t)tl * kE + i] : 0;
+        h[u] = (tl < ntiles) ? ld_i32<COH>(ws_hist + (size_t)tl * kE + i) : 0;
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -280,7 +298,7 @@ __device__ __forceinline__ void loc_prefix(int tid, int b, int E, int k, int nti
 
 // phase 3: stable rank inside the tile: a wave handles one choice, 64 tokens per step.  `lidx` (optional): the tile's expert
 // ids in LDS, [k][t1 - t0 rounded up to the tile]; `e_first`: the wave's first 64 ids when the caller loaded them early.
-template <int NW>
+template <int NW, bool COH = false>
 __device__ __forceinline__ void loc_rank(int tid, int t0, int t1, int Tn, int E, int k, const int32_t *__restrict__ idx,
                                          const int32_t *lidx, int lidx_stride, int e_first, bool have_first, int32_t *s_cur,
                                          int32_t *__restrict__ loc, int capacity, int32_t *__restrict__ slot_map) {
@@ -312,7 +330,7 @@ __device__ __forceinline__ void loc_rank(int tid, int t0, int t1, int Tn, int E,
       if (leader) cur[e] = base + cnt;
       if (t < t1) {
         loc[(size_t)j * Tn + t] = valid ? l : 0;
-        if (slot_map != nullptr && valid && l < capacity) slot_map[(size_t)e * capacity + l] = j * Tn + t;
+        if (slot_map != nullptr && valid && l < capacity) st_i32<COH>(slot_map + (size_t)e * capacity + l, j * Tn + t);
       }
     }
   }
@@ -321,7 +339,7 @@ __device__ __forceinline__ void loc_rank(int tid, int t0, int t1, int Tn, int E,
 // phase 4 (one block): max count and gshard loss.  Column sums: `parts` threads per expert, each a contiguous tile range in
 // fixed order, combined in fixed order.  The arithmetic is done by the block's first RT_THREADS threads in BOTH kernels, so the
 // loss does not depend on which kernel computed it (deterministic, bit for bit).
-template <int NW>
+template <int NW, bool COH = false>
 __device__ __forceinline__ void loc_finish(int tid, int Tn, int E, int k, int ntiles, const float *__restrict__ ws_colsum,
                                            const int32_t *s_tot, float *s_parts, float *s_red, int *s_redi, const float *cs_first,
                                            bool cs_early, int32_t *__restrict__ stats, void *__restrict__ l_aux, int l_aux_dtype) {
@@ -349,7 +367,7 @@ __device__ __forceinline__ void loc_finish(int tid, int Tn, int E, int k, int nt
           float cs[16];
 #pragma unroll
           for (int u = 0; u < 16; ++u)
-            cs[u] = (cs_early && tl0 == a) ? cs_first[u] : ((tl0 + u < z) ? ws_colsum[(size_t)(tl0 + u) * E + e] : 0.f);
+            cs[u] = (cs_early && tl0 == a) ? cs_first[u] : ((tl0 + u < z) ? ld_f32<COH>(ws_colsum + (size_t)(tl0 + u) * E + e) : 0.f);
 #pragma unroll
           for (int u = 0; u < 16; ++u) me += cs[u];
         }
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
   if (clear_map != nullptr) {
     const int per = (clear_n + (int)gridDim.x - 1) / (int)gridDim.x;
     const int c0 = b * per, c1 = min(clear_n, c0 + per);
-    for (int i = c0 + tid; i < c1; i += GQ_THREADS) clear_map[i] = -1;
+    for (int i = c0 + tid; i < c1; i += GQ_THREADS) st_i32<FUSED>(clear_map + i, -1);   // (FUSED: other blocks of this launch fill it)
   }
   for (int i = tid; i < k * E; i += GQ_THREADS) s_hist[i] = 0;
   float colsum = 0.f;  // thread e < E accumulates column e over the tile, in token order
@@ -564,26 +582,28 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     }
     __syncthreads();
   }
-  for (int i = tid; i < k * E; i += GQ_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
-  if (tid < E) ws_colsum[(size_t)b * E + tid] = colsum;
+  for (int i = tid; i < k * E; i += GQ_THREADS) st_i32<FUSED>(ws_hist + (size_t)b * k * E + i, s_hist[i]);
+  if (tid < E) st_f32<FUSED>(ws_colsum + (size_t)b * E + tid, colsum);
   if (!FUSED) return;
 
-  // ---- grid-wide barrier: every tile's histogram (and column sums, and its slice of the cleared slot map) is published
+  // ---- grid-wide barrier: every tile's histogram (and column sums, and its slice of the cleared slot map) is published.
+  // Everything the blocks exchange goes through device-scope (sc1) accesses, so no cache-wide fence is needed: each wave waits
+  // for its own stores to be acknowledged (workgroup-scope release = s_waitcnt), the block meets, one thread signals.
   const int ntiles = fl.ntiles;
-  __threadfence();   // release, device scope: this thread's stores above are visible before the arrival below
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (tid == 0) {
-    __hip_atomic_fetch_add(&fl.sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(&fl.sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntiles) __builtin_amdgcn_s_sleep(2);
+    __hip_atomic_fetch_add(&fl.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(&fl.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntiles) __builtin_amdgcn_s_sleep(1);
     // departures: the last block out puts both words back to zero (no block can still be spinning on the arrivals then)
-    const unsigned left = __hip_atomic_fetch_add(&fl.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned left = __hip_atomic_fetch_add(&fl.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (left == (unsigned)ntiles - 1) {
       __hip_atomic_store(&fl.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&fl.sync[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&fl.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every thread: the other blocks' histograms are read from memory, not a stale line
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (compiler + wave ordering; the loads below are sc1 themselves)
 
   // ---- the location phases (== location_kernel), 16 waves.  LDS: s_cur / s_tot take over the score tile (dead now)
   int32_t *s_cur = reinterpret_cast<int32_t *>(s_sc);                         // [k][E]
@@ -594,9 +614,9 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
   float cs_none[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) cs_none[u] = 0.f;
-  loc_prefix<GQ_THREADS / 64>(tid, b, E, k, ntiles, ws_hist, s_cur, s_tot, fl.dispatch_count);
-  loc_rank<GQ_THREADS / 64>(tid, t0, t1, Tn, E, k, idx, s_idx, tile, -1, false, s_cur, fl.loc, fl.capacity, fl.slot_map);
-  if (b == 0) loc_finish<GQ_THREADS / 64>(tid, Tn, E, k, ntiles, ws_colsum, s_tot, s_parts, s_red, s_redi, cs_none, false, fl.stats, fl.l_aux, fl.l_aux_dtype);
+  loc_prefix<GQ_THREADS / 64, true>(tid, b, E, k, ntiles, ws_hist, s_cur, s_tot, fl.dispatch_count);
+  loc_rank<GQ_THREADS / 64, true>(tid, t0, t1, Tn, E, k, idx, s_idx, tile, -1, false, s_cur, fl.loc, fl.capacity, fl.slot_map);
+  if (b == 0) loc_finish<GQ_THREADS / 64, true>(tid, Tn, E, k, ntiles, ws_colsum, s_tot, s_parts, s_red, s_redi, cs_none, false, fl.stats, fl.l_aux, fl.l_aux_dtype);
 }
 
 // -------------------------------------------------------------------------------------------

@@ -243,15 +243,18 @@ WS_MAX = 4   # workspaces kept per layer (least recently used goes first)
 
 
 def _bucket_tokens(T):
-    """token-count bucket of a workspace: steps of a quarter of the power of two below T (at least 256), so that growing
-    batches reallocate O(log) times and a workspace is never more than ~25 % larger than needed"""
-    T = max(int(T), 1)
-    step = max(256, (1 << (T.bit_length() - 1)) // 4)
-    return (T + step - 1) // step * step
+    """token-count bucket of a workspace: the next power of two (at least 256) -- growing batches reallocate O(log T) times
+    (288 GB of HBM: a workspace up to twice the size needed costs nothing that matters)"""
+    T = max(int(T), 256)
+    return 1 << (T - 1).bit_length()
 
 
-def _bucket_capacity(C):
-    return (max(int(C), 1) + 31) // 32 * 32
+def _bucket_capacity(C, T, T_cap):
+    """rows per expert of the bucket: what the capacity grows to when the batch grows to T_cap tokens (the capacity is
+    proportional to the token count, fast_dispatch.py:188-199), rounded up to 32"""
+    C = max(int(C), 1)
+    C = (C * int(T_cap) + max(int(T), 1) - 1) // max(int(T), 1)
+    return (C + 31) // 32 * 32
 
 
 class _Workspace:
@@ -308,7 +311,8 @@ def _workspace(layer, static_key, T, C, make):
         if key[0] == static_key and ws.T_cap >= T and ws.C_cap >= C:
             cache.move_to_end(key)
             return ws
-    T_cap, C_cap = _bucket_tokens(T), _bucket_capacity(C)
+    T_cap = _bucket_tokens(T)
+    C_cap = _bucket_capacity(C, T, T_cap)
     ws = make(T_cap, C_cap)
     cache[(static_key, T_cap, C_cap)] = ws
     layer.__dict__["_ep_workspace_allocations"] = layer.__dict__.get("_ep_workspace_allocations", 0) + 1

@@ -28,6 +28,9 @@ class GraphedForward:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.static_out = layer(self.static_in, **forward_kwargs)
+        # the captured kernels hold raw pointers into the layer's cached pipeline workspaces (impls/ep_native.py keeps an LRU of
+        # them): pin the ones alive now for as long as this graph lives, so that eviction cannot free memory a replay writes
+        self._pinned = list(layer.__dict__.get("_ep_workspaces", {}).values())
         self.l_aux = getattr(self.static_out, "l_aux", None)
         torch.cuda.current_stream().wait_stream(self.stream)
 
