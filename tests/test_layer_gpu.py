@@ -865,3 +865,41 @@ def test_gate_is_projected_once_per_forward(oracle):
             with torch.no_grad():
                 y = layer(xd)
         assert calls == [1], (cfg, calls)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_training_forward_and_data_gradients_on_the_mfma_gemm(oracle, monkeypatch, dtype):
+    """Round 3: with autograd the bf16 / fp16 ReLU experts run forward and data-gradient GEMMs on the grouped MFMA kernels
+    (experts/ffn.py::_FFNTrain; weight gradients on ATen).  Against (a) the same layer on the ATen path (the reference's op
+    sequence) and (b) an fp32 autograd reference of the same layer: outputs and ALL gradients, at the dtype's bar."""
+    from tutel_amd import ops
+    from tutel_amd.experts import ffn
+    T, M, H, E, k = 1024, 256, 384, 8, 2
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=41)
+
+    def run(fused, dt):
+        monkeypatch.setattr(ffn, "_TRAIN_FUSED", fused)
+        w = [t.to(dt) for t in weights]
+        layer = make_layer(M, H, E, k, 1.0, dt, w, gate={"fp32_gate": True}).train()
+        xin = x.to(dt).cuda().requires_grad_(True)
+        calls = []
+        real = ops.expert_gemm
+        monkeypatch.setattr(ops, "expert_gemm", lambda *a, **kw: calls.append(1) or real(*a, **kw))
+        y = layer(xin)
+        loss = (y.float() * torch.linspace(-1, 1, M, device="cuda")).sum() + y.l_aux.float()
+        loss.backward()
+        monkeypatch.setattr(ops, "expert_gemm", real)
+        ex = layer.experts
+        return (y.detach().float().cpu(), [g.float().cpu() for g in (xin.grad, ex.batched_fc1_w.grad, ex.batched_fc1_bias.grad,
+                                                                     ex.batched_fc2_w.grad, ex.batched_fc2_bias.grad,
+                                                                     layer.gates[0].wg.weight.grad)], len(calls))
+    y_f, g_f, n_f = run(True, dtype)
+    y_a, g_a, n_a = run(False, dtype)
+    y_r, g_r, _ = run(False, torch.float32)
+    assert n_f == 4 and n_a == 0, (n_f, n_a)     # 2 forward + 2 data-gradient launches; none on the ATen path
+    eps = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    names = ("x", "fc1_w", "fc1_bias", "fc2_w", "fc2_bias", "gate_w")
+    for tag, a, b, mult in [("y vs aten", y_f, y_a, 4), ("y vs fp32", y_f, y_r, 4)] + \
+            [(f"d{n} vs aten", a, b, 8) for n, a, b in zip(names, g_f, g_a)] + [(f"d{n} vs fp32", a, b, 8) for n, a, b in zip(names, g_f, g_r)]:
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= mult * eps * scale + 1e-6, (tag, float((a - b).abs().max()), scale)

@@ -22,6 +22,46 @@ from .. import net, ops
 
 # eval-mode weight pre-layout: keep a [E, N, K] (k-major) copy of weights stored [E, K, N]; 0 disables
 _PREPACK = int(os.environ.get("TUTEL_AMD_PREPACK", "1")) != 0
+# training: forward + data gradients of the bf16 / fp16 ReLU FFN on the MFMA grouped GEMM (weight gradients stay on ATen); 0 disables
+_TRAIN_FUSED = int(os.environ.get("TUTEL_AMD_TRAIN_FUSED", "1")) != 0
+
+
+class _FFNTrain(torch.autograd.Function):
+    """y = relu(x @ W1^T + b1) @ W2 + b2 per expert WITH autograd, on the grouped GEMM kernels (round 3).
+
+    forward : two launches (bias + ReLU fused into the first, bias into the second); the hidden activation is kept for backward.
+    backward: d hid = (gy @ W2^T) * [hid > 0] -- one launch, the ReLU mask rides in the GEMM's gating epilogue (W2 [E, H, M_out] is
+              the k-major operand of that product as stored); d x = d hid @ W1 -- one launch (W1 [E, H, M] is its [K, N] operand as
+              stored, consumed through the transposing LDS read).  The weight gradients contract over the ROW dimension
+              (hid^T @ gy, d hid^T @ x): library batched GEMMs, as in the reference (ffn.py:114-120 under autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        hid = ops.expert_gemm(x, w1, b1, True, act="relu")
+        y = ops.expert_gemm(hid, w2, b2, False)
+        ctx.save_for_backward(x, w1, w2, hid)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1, w2, hid = ctx.saved_tensors
+        gy = gy.contiguous()
+        need_x, need_w1, need_b1, need_w2, need_b2 = ctx.needs_input_grad
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        if need_w2:
+            gw2 = torch.matmul(hid.transpose(1, 2), gy)
+        if need_b2 and ctx.has_bias[1]:
+            gb2 = gy.sum(dim=1)
+        if need_x or need_w1 or (need_b1 and ctx.has_bias[0]):
+            ghid = ops.expert_gemm(gy, w2, None, True, mul=(hid > 0).to(hid.dtype))
+            if need_x:
+                gx = ops.expert_gemm(ghid, w1, None, False)
+            if need_w1:
+                gw1 = torch.matmul(ghid.transpose(1, 2), x)
+            if need_b1 and ctx.has_bias[0]:
+                gb1 = ghid.sum(dim=1)
+        return gx, gw1, gb1, gw2, gb2
 
 
 class KMajorCache:
@@ -227,6 +267,19 @@ class FusedExpertsNetwork(torch.nn.Module):
         return (dt is not None and ops.gemm_supported(dt, w1.size(1), w1.size(2)) and
                 ops.gemm_supported(dt, w2.size(2), w2.size(1)) and self.fused_activation() is not None)
 
+    def can_fuse_training(self, x, ctx):
+        """the same local experts WITH autograd: bf16 / fp16 (or autocast over fp32 master weights), ReLU, all four GEMM
+        products MFMA-able (forward K = M, H; backward K = M_out, H)"""
+        if (not _TRAIN_FUSED or self.skip_expert or not x.is_cuda or x.dim() != 3 or self._no_autograd(x)
+                or getattr(ctx, "adaptive_degree", 1) == 0 or getattr(ctx, "sharded_count", 1) > 1):
+            return False
+        w1, w2 = self.batched_fc1_w, self.batched_fc2_w
+        dt = self.compute_dtype(x)
+        b2 = self.batched_fc2_bias
+        return (dt is not None and self.fused_activation() == "relu" and x.size(0) == w1.size(0) and (b2 is None or b2.size(-1) == self.output_dim)
+                and ops.gemm_supported(dt, w1.size(1), w1.size(2)) and ops.gemm_supported(dt, w2.size(2), w2.size(1))
+                and ops.gemm_supported(dt, w2.size(1), w2.size(2)) and ops.gemm_supported(dt, w1.size(2), w1.size(1)))
+
     def fused_params(self, dtype):
         """(w1, b1, w2, b2, w2_kmajor) of this rank's experts in the GEMM's compute dtype: the parameters themselves, or
         cached casts under autocast; fc2 as a k-major copy in eval mode."""
@@ -293,6 +346,12 @@ class FusedExpertsNetwork(torch.nn.Module):
             return x
         if self.can_fuse(x, ctx):
             return self.forward_fused(x.contiguous(), ctx)
+
+        if self.can_fuse_training(x, ctx):
+            dt = self.compute_dtype(x)
+            b1, b2 = self.batched_fc1_bias, self.batched_fc2_bias
+            return _FFNTrain.apply(x.contiguous(), self.batched_fc1_w.to(dt), b1.to(dt) if b1 is not None else None,
+                                   self.batched_fc2_w.to(dt), b2.to(dt) if b2 is not None else None)
 
         w1, w2 = self.batched_fc1_w, self.batched_fc2_w
         b1 = self.batched_fc1_bias.unsqueeze(1) if self.batched_fc1_bias is not None else None
