@@ -32,7 +32,12 @@ def pin_lib():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", src, "-o", so])
     L = ctypes.CDLL(so)
     L.cu_pin.restype, L.cu_pin.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    L.cu_stamp.restype, L.cu_stamp.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]
     return L
+
+
+STAMPS = None   # int64[2] on the device: wall-clock ticks (100 MHz) right before / after the timed GEMMs, on their stream
+PINLIB = None
 
 
 def time_gemm(fn, iters, before=None, after=None):
@@ -44,15 +49,28 @@ def time_gemm(fn, iters, before=None, after=None):
         if before:
             before()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        PINLIB.cu_stamp(STAMPS.data_ptr(), ops._stream())
         s.record()
         for _ in range(iters):
             fn()
         e.record()
+        PINLIB.cu_stamp(STAMPS.data_ptr() + 8, ops._stream())
         torch.cuda.synchronize()
         if after:
             after()
         best.append(s.elapsed_time(e) * 1e3 / iters)
     return round(min(best), 2), round(sorted(best)[1], 2)
+
+
+def overlap(sink, n):
+    """fraction of the last timed GEMM region during which all n pinning blocks were resident (device wall clock)"""
+    st = STAMPS.cpu().tolist()
+    iv = sink[:2 * n].cpu().view(n, 2)
+    lo, hi = int(iv[:, 0].max()), int(iv[:, 1].min())
+    if os.environ.get("PROBE_DEBUG"):
+        print("debug: gemm region", (st[1] - st[0]) / 100.0, "us; pin starts (rel. to region start, us)", (int(iv[:, 0].min()) - st[0]) / 100.0, (lo - st[0]) / 100.0,
+              "pin ends", (hi - st[0]) / 100.0, (int(iv[:, 1].max()) - st[0]) / 100.0, file=sys.stderr)
+    return round(max(0, min(hi, st[1]) - max(lo, st[0])) / max(1, st[1] - st[0]), 3)
 
 
 def main():
@@ -63,15 +81,26 @@ def main():
     dist.init_process_group("nccl", device_id=dev)
     from tutel_amd.impls import ep_native
     comm = ep_native.communicator(None, dev)   # the library's own RCCL communicator (1 rank: ncclAllToAll is a device copy)
-    P = pin_lib()
-    side = torch.cuda.Stream()
-    sink = torch.zeros([512], dtype=torch.int32, device=dev)
+    global STAMPS, PINLIB
+    P = PINLIB = pin_lib()
+    STAMPS = torch.zeros([2], dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(priority=-1)   # high priority: never multiplexed onto the default stream's hardware queue (profiles/r03_stream_queues.txt)
+    sink = torch.zeros([512], dtype=torch.int64, device=dev)
     a2a_src = torch.randn([16 * 1024 * 1024], device=dev).bfloat16()
     a2a_dst = torch.empty_like(a2a_src)
     g = torch.Generator(device=dev).manual_seed(1)
     out = {"note": "us per launch: [min, median] of 3 rounds; pinned CUs hold 160 KB of LDS each for the whole timed region", "shapes": {}}
     shapes = [("stage 4x1024 K=N=2048 (N=8 headline, degree 2)", 4, 1024, 2048, 2048), ("rank 8x1024 K=N=2048 (N=8 headline, degree 1)", 8, 1024, 2048, 2048),
               ("stage 4x1024 K=N=4096 (configs[3], degree 2)", 4, 1024, 4096, 4096), ("rank 8x1024 K=N=4096 (configs[3], degree 1)", 8, 1024, 4096, 4096)]
+    # which stream carries what: "gemm on default" = the GEMMs on torch's default stream and the co-runner on a non-blocking side
+    # stream; "gemm on side" = the product's arrangement (collectives on the caller's stream, stage GEMMs on the library's side stream)
+    arrangement = os.environ.get("PROBE_GEMM_STREAM", "default")
+    out["gemm_stream"] = arrangement
+    gemm_stream = torch.cuda.current_stream() if arrangement == "default" else torch.cuda.Stream(priority=-1)
+    co_stream = side if arrangement == "default" else torch.cuda.default_stream()
+    torch.cuda.set_stream(gemm_stream)
+    if os.environ.get("PROBE_DEBUG"):
+        shapes = shapes[:1]
     for name, El, R, K, N in shapes:
         a = torch.randn([El, R, K], device=dev, generator=g).bfloat16()
         w = (torch.randn([El, N, K], device=dev, generator=g) * 0.03).bfloat16()
@@ -85,13 +114,14 @@ def main():
             r = {"alone": time_gemm(fn, iters)}
             for n in (16, 32, 64):
                 def before(n=n):
-                    with torch.cuda.stream(side):
+                    with torch.cuda.stream(co_stream):
                         assert P.cu_pin(n, 3000.0, sink.data_ptr(), ops._stream()) == 0
                     torch.cuda._sleep(200000)   # let the pinning blocks become resident before the GEMMs are queued
                 r[f"{n} CUs pinned"] = time_gemm(fn, iters, before=before, after=torch.cuda.synchronize)
+                r[f"{n} CUs pinned: overlap of the pin with the timed region"] = overlap(sink, n)
 
             def before_a2a():
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(co_stream):
                     for _ in range(40):
                         comm.all_to_all(a2a_dst, a2a_src)
             r["1-rank RCCL all-to-all (32 MiB copies) co-running"] = time_gemm(fn, iters, before=before_a2a, after=torch.cuda.synchronize)

@@ -5,14 +5,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-__global__ void cu_pin_kernel(unsigned long long ticks, int *sink) {
+__global__ void cu_pin_kernel(unsigned long long ticks, long long *sink) {
   extern __shared__ unsigned char lds[];
-  const unsigned long long t0 = wall_clock64();  // 100 MHz
+  const unsigned long long t0 = wall_clock64();  // 100 MHz, one clock for the whole device
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-  if (threadIdx.x == 0 && sink != nullptr) sink[blockIdx.x] = lds[0];
+  if (threadIdx.x == 0 && sink != nullptr) {   // when this block really ran: [start, end] in device wall-clock ticks
+    sink[2 * blockIdx.x] = (long long)t0 + (lds[0] & 0);
+    sink[2 * blockIdx.x + 1] = (long long)wall_clock64();
+  }
 }
 
-extern "C" int cu_pin(int n_cus, double microseconds, int *sink, void *stream) {
+__global__ void cu_stamp_kernel(long long *out) { out[0] = (long long)wall_clock64(); }
+
+extern "C" int cu_stamp(long long *out, void *stream) {
+  hipLaunchKernelGGL(cu_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int cu_pin(int n_cus, double microseconds, long long *sink, void *stream) {
   static bool optin = false;
   const int lds = 160 * 1024;
   if (!optin) {

@@ -88,6 +88,9 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free;
 static int g_timing = 0;
 
 void tutel_stage_hint(int stage) { g_stage_hint = stage; }
+static thread_local int g_gemm_corun = 0;
+void tutel_gemm_corun_hint(int on) { g_gemm_corun = on; }
+int tutel_gemm_corun() { return g_gemm_corun; }
 
 int tutel_stage_begin(int stage, hipStream_t st) {
   if (!g_timing) return -1;

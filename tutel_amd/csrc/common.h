@@ -17,6 +17,8 @@ int tutel_get_option(int key);  // TUTEL_OPT_*: -1 automatic, 0 / 1 forced (api.
 int tutel_stage_begin(int stage, hipStream_t st);  // returns a token (-1: timing off)
 void tutel_stage_end(int token, hipStream_t st);
 void tutel_stage_hint(int stage);                  // the next launches of this thread belong to `stage` (-1: clear)
+void tutel_gemm_corun_hint(int on);                // the next GEMM launches of this thread run beside a collective on another stream
+int tutel_gemm_corun();
 void tutel_stage_range_push(int stage);            // roctx range named after the stage (no-op without libroctx64)
 void tutel_stage_range_pop();
 struct StageScope {

@@ -104,9 +104,30 @@ struct tutel_amd_ep_comm {
   tutel_amd_exchange_v_fn hosted_v;
   void *hosted_user;
 
-  hipStream_t side_stream;  // the GEMMs of the overlapped pipeline (the collectives run on the caller's stream)
+  // The GEMMs of the overlapped pipeline run on a side stream (the collectives on the caller's).  HIP multiplexes streams onto a
+  // few hardware queues PER PRIORITY LEVEL, and two streams that share a queue run strictly one after the other: every fourth
+  // normal-priority stream created in a process lands on the default stream's queue and would then never overlap with it
+  // (measured on MI355X, tools/stream_concurrency_check.py, profiles/r03_stream_queues.txt).  Streams of different priority never
+  // share a queue, so the communicator owns TWO side streams -- highest and lowest priority -- and a call uses the one whose
+  // priority differs from its caller's stream.
+  hipStream_t side_stream;      // highest priority: used unless the caller's stream has that priority itself
+  hipStream_t side_stream_low;  // lowest priority
   hipEvent_t recv_ev[EP_MAX_SPLIT], done_ev[EP_MAX_SPLIT];
 };
+
+static bool create_side_streams(tutel_amd_ep_comm *c) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+  return hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, greatest) == hipSuccess &&
+         hipStreamCreateWithPriority(&c->side_stream_low, hipStreamNonBlocking, least) == hipSuccess;
+}
+
+// the side stream whose priority differs from the caller's (see struct tutel_amd_ep_comm)
+static hipStream_t side_stream_for(tutel_amd_ep_comm *c, hipStream_t caller) {
+  int least = 0, greatest = 0, pr = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamGetPriority(caller, &pr) != hipSuccess) return c->side_stream;
+  return pr == greatest && least != greatest ? c->side_stream_low : c->side_stream;
+}
 
 extern "C" int tutel_amd_ep_unique_id(void *out, size_t bytes) {
   TUTEL_REQUIRE(out != nullptr && bytes >= sizeof(ncclUniqueId), "tutel_amd_ep_unique_id: need a %zu-byte buffer", sizeof(ncclUniqueId));
@@ -142,7 +163,7 @@ extern "C" int tutel_amd_ep_comm_create(const void *id, size_t bytes, int world,
     tutel_set_error("ncclCommInitRank: RCCL error %d (%s)", (int)nr, g_rccl.GetErrorString(nr));
     return fail((int)nr);
   }
-  bool ok = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) == hipSuccess;
+  bool ok = create_side_streams(c);
   for (int i = 0; ok && i < EP_MAX_SPLIT; ++i)
     ok = hipEventCreateWithFlags(&c->recv_ev[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->done_ev[i], hipEventDisableTiming) == hipSuccess;
@@ -162,7 +183,7 @@ extern "C" int tutel_amd_ep_comm_create_hosted(int world, int rank, tutel_amd_ex
   c->rank = rank;
   c->hosted = fn;
   c->hosted_user = user;
-  bool ok = hipGetDevice(&c->device) == hipSuccess && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) == hipSuccess;
+  bool ok = hipGetDevice(&c->device) == hipSuccess && create_side_streams(c);
   for (int i = 0; ok && i < EP_MAX_SPLIT; ++i)
     ok = hipEventCreateWithFlags(&c->recv_ev[i], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->done_ev[i], hipEventDisableTiming) == hipSuccess;
@@ -178,8 +199,10 @@ extern "C" int tutel_amd_ep_comm_create_hosted(int world, int rank, tutel_amd_ex
 extern "C" int tutel_amd_ep_comm_destroy(tutel_amd_ep_comm_t *c) {
   if (c == nullptr) return 0;
   if (c->side_stream != nullptr) (void)hipStreamSynchronize(c->side_stream);
+  if (c->side_stream_low != nullptr) (void)hipStreamSynchronize(c->side_stream_low);
   if (c->comm != nullptr && g_rccl.CommDestroy != nullptr) (void)g_rccl.CommDestroy(c->comm);
   if (c->side_stream != nullptr) (void)hipStreamDestroy(c->side_stream);
+  if (c->side_stream_low != nullptr) (void)hipStreamDestroy(c->side_stream_low);
   for (int i = 0; i < EP_MAX_SPLIT; ++i) {
     if (c->recv_ev[i] != nullptr) (void)hipEventDestroy(c->recv_ev[i]);
     if (c->done_ev[i] != nullptr) (void)hipEventDestroy(c->done_ev[i]);
@@ -411,7 +434,7 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     // caller's stream is the origin of a HIP-graph capture, and RCCL can be captured there but not on a stream that
     // joined the capture through an event (segfault inside the library, tools/graph_rccl_probe.py) -- plain kernel
     // launches are fine on either.  Eager and captured execution take this one path.
-    hipStream_t ks = c->side_stream;
+    hipStream_t ks = side_stream_for(c, cur);
     {
       Range r("tutel_amd.all_to_all(dispatch)");
       for (int i = 0; i < degree; ++i) {
@@ -422,7 +445,9 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     }
     for (int i = 0; i < degree; ++i) {
       HIP_CHECK(hipStreamWaitEvent(ks, c->recv_ev[i], 0), "hipStreamWaitEvent");  // first wait: the side stream joins (forks from) the caller's
+      tutel_gemm_corun_hint(c->comm != nullptr);  // a real collective runs beside these GEMMs (the hosted test exchange is synchronous)
       rc = stage_gemms(i, ks);
+      tutel_gemm_corun_hint(0);
       if (rc) return rc;
       HIP_CHECK(hipEventRecord(c->done_ev[i], ks), "hipEventRecord");
       HIP_CHECK(hipStreamWaitEvent(cur, c->done_ev[i], 0), "hipStreamWaitEvent");  // last wait: the side stream is joined back

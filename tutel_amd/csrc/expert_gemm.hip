@@ -1229,7 +1229,12 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
     const long long t256 = mt256 * ((a.N + 255) / 256), t128 = mt256 * ((a.N + 127) / 128);
     // more than one 128-row tile per expert (R > 128) already pays: the 128-tile kernels would stream every
     // weight tile once per M-tile (dropless capacity 157 at the headline shape: fc1 214 us vs 118 at R = 128)
-    if (KM && a.fits32 && (big == 4 || (big < 0 && a.R > GM_BM && t256 >= 192))) return launch_pp<T, ACT>(a, st);
+    // Beside a co-running collective (a stage of the overlapped pipeline: RCCL's kernels hold whole CUs on the other stream) a grid of
+    // one workgroup per CU turns into two rounds as soon as a few CUs are taken: the 256 x 128 ring kernel at 4 x 1024 x 2048^2 goes
+    // from 42 us to 70 us with 16 CUs held and to 57 us beside a device copy, the 128-block 256 x 256 grid stays at 52 us
+    // (tools/contention_probe.py, profiles/r03_contention.json).  So with the co-run hint the half-filled 256 x 256 grid wins.
+    const bool corun_pp = tutel_gemm_corun() && big < 0 && a.R > GM_BM && t256 >= 96 && t256 < 192;
+    if (KM && a.fits32 && (big == 4 || corun_pp || (big < 0 && a.R > GM_BM && t256 >= 192))) return launch_pp<T, ACT>(a, st);
     if (big == 1 || big == 4 || (big < 0 && a.R > GM_BM && t256 >= 192)) return launch_big<T, KM, ACT, 4>(a, st);
     // 256 x 128: a three-slot ring (3 x 48 KB of LDS) keeps two tiles in flight: +3-4 % over two slots on the
     // stage shapes it is chosen for (tools/stage_probe.py); big = 2 forces the two-slot form for A/B runs

@@ -25,9 +25,17 @@ _comm_streams = {}
 
 
 def _comm_stream(device):
-    key = (device.type, device.index)
+    """the communication stream: HIGH priority, so that it never shares a hardware queue with a normal-priority caller stream
+    -- HIP serialises streams that share a queue, and every fourth normal-priority stream lands on the default stream's
+    (profiles/r03_stream_queues.txt).  A caller that is itself on a high-priority stream gets a low-priority one."""
+    cur_prio = torch.cuda.current_stream(device).priority
+    prio = -1 if cur_prio >= 0 else 1
+    key = (device.type, device.index, prio)
     if key not in _comm_streams:
-        _comm_streams[key] = torch.cuda.Stream(device=device)
+        try:
+            _comm_streams[key] = torch.cuda.Stream(device=device, priority=prio)
+        except (RuntimeError, ValueError):   # a build that knows two levels only
+            _comm_streams[key] = torch.cuda.Stream(device=device, priority=0 if prio > 0 else prio)
     return _comm_streams[key]
 
 
