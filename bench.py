@@ -330,7 +330,7 @@ def main():
     # counter traffic and the profiler's own average of the dominant kernel are NOT measured in this run: they are read from
     # profiles/traffic.json, which tools/profile_r03.sh writes together with the sha256 of the kernel source they were measured
     # on -- a different source means a different kernel, and then both are reported as null with the reason
-    traffic, rocprof_us, traffic_note = None, None, None
+    traffic, rocprof_us, traffic_note, dec_rocprof_us = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     headline = world == 1 and (T, M, H, E, k) == (4096, 2048, 2048, 64, 2) and args.capacity_factor == 1.0 and dtype == torch.bfloat16
     if not headline:
@@ -346,6 +346,7 @@ def main():
         else:
             traffic = tj.get("expert_gemm_fc1_hbm_bytes_per_launch")
             rocprof_us = tj.get("expert_gemm_fc1_avg_us_rocprofv3")
+            dec_rocprof_us = tj.get("fast_decode_avg_us_rocprofv3")
             traffic_note = f"{tj.get('source')}; kernel {tj.get('kernel')}; measured at git {tj.get('git_head')}"
 
     fc2_obj = {"avg_launch_us": round(fc2_us, 2), "achieved_GBs": round(gemm_bytes / max(fc2_us, 1e-9) * 1e-3, 1),
@@ -378,7 +379,10 @@ def main():
                   "achieved": round(dec_bytes / max(dec_us, 1e-9) * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(dec_bytes / max(dec_us, 1e-9) * 1e-3 / HBM_PEAK_GBS, 4),
                   "frac_of_achievable": round(dec_bytes / max(dec_us, 1e-9) * 1e-3 / HBM_ACHIEVABLE_GBS, 4),
-                  "note": "from timing pass 4 (events around every launch)"}
+                  "avg_launch_us_rocprofv3": dec_rocprof_us,
+                  "frac_rocprof": round(dec_bytes / dec_rocprof_us * 1e-3 / HBM_PEAK_GBS, 4) if dec_rocprof_us else None,
+                  "note": "avg_launch_us from timing pass 4 (events around every launch: each record drains the queue, +1-2 us per launch); "
+                          "avg_launch_us_rocprofv3 from profiles/traffic.json (kernel trace of the same command, stamped like the fc1 figures)"}
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * T / (elapsed / args.steps)

@@ -383,8 +383,8 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *                        (automatic: 2)
  *   TUTEL_OPT_ROUTING    tutel_amd_moe_forward: 0 / automatic = top-k and location as two launches, 1 = the fused routing kernel
  *                        (tutel_amd_route; measured equal on MI355X, so not the default)
- *   TUTEL_OPT_GEMM_PERSIST  256 x 256 ping-pong kernel: 0 = one tile per workgroup, 1 = persistent workgroups looping over tiles
- *                        (automatic: persistent when a launch has more tiles than the GPU has compute units) */
+ *   TUTEL_OPT_GEMM_PERSIST  256 x 256 ping-pong kernel, bias operand: 0 = fetched after the K loop, 1 / automatic = before it
+ *                        (32 more live registers, its L2 round trip hidden behind the loop) */
 #define TUTEL_OPT_GEMM_IMPL 0
 #define TUTEL_OPT_GEMM_TILE 1
 #define TUTEL_OPT_DECODE 2

@@ -29,11 +29,13 @@ for name in ("fetch", "write"):
             fo.write(f"{k:100s} {c:12s} avg {s / n:14.1f} (n={n})\n")
             if FC1 in k:
                 val[name] = (k, s / n, n)
-avg_us, kern = None, None
+avg_us, kern, dec_us, dec_kern = None, None, None, None
 for st in glob.glob(f"{out}/bench_n1/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(st)):
         if FC1 in r["Name"]:
             avg_us, kern = float(r["AverageNs"]) * 1e-3, r["Name"]
+        if "decode_kernel<bf16_t, 2," in r["Name"]:
+            dec_us, dec_kern = float(r["AverageNs"]) * 1e-3, r["Name"][:60]
 h = hashlib.sha256()
 for f in ("expert_gemm.hip", "common.h"):
     h.update(open(os.path.join("tutel_amd", "csrc", f), "rb").read())
@@ -41,6 +43,7 @@ fv, wv = val.get("fetch", (None, None, 0))[1], val.get("write", (None, None, 0))
 tj = {"expert_gemm_hip_sha256": h.hexdigest(), "git_head": os.environ.get("GIT_HEAD", "unknown"), "kernel": kern,
       "expert_gemm_fc1_hbm_bytes_per_launch": int(fv * 2 * 1024 + wv * 1024) if fv and wv else None,
       "fetch_size_kb_avg": fv, "write_size_kb_avg": wv, "expert_gemm_fc1_avg_us_rocprofv3": avg_us,
+      "fast_decode_avg_us_rocprofv3": dec_us, "fast_decode_kernel": dec_kern,
       "source": "tools/profile_r03.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (gfx950: FETCH_SIZE x 2, KB -> bytes) and "
                 "rocprofv3 --kernel-trace --stats of `python bench.py --steps 20 --warmup 5`"}
 json.dump(tj, open(f"{out}/traffic.json", "w"), indent=1)

@@ -894,7 +894,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
 // -------------------------------------------------------------------------------------------
 #define PP_BUF (4 * GL_STAGE)   // elements per LDS K-tile buffer: [256][64] tokens + [256][64] weights = 64 KB
 
-template <typename T, int ACT, bool W_ONCE, bool RAGGED = false>
+template <typename T, int ACT, bool W_ONCE, bool RAGGED = false, bool EARLY_BIAS = false>
 __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t *lds = reinterpret_cast<uint16_t *>(smem);  // [2][ tokens 2*GL_STAGE | weights 2*GL_STAGE ]
@@ -1085,6 +1085,20 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
       PP_PHASE(MODE, 3, cur, false, if (more2) PP_ISSUE_A(j + 2, cur, 1));               \
     }                                                                                    \
   } while (0)
+  // EARLY_BIAS: the epilogue's 16 bias loads per lane go out before the K loop (32 more live registers) instead of after it,
+  // where their L2 round trip is exposed once per tile
+  uint2 bias_r[4][4];
+#define PP_LOAD_BIAS()                                                                                \
+  do {                                                                                                \
+    const uint16_t *be_ = p.bias ? reinterpret_cast<const uint16_t *>(p.bias) + (size_t)e * p.bias_stride_e : nullptr; \
+    _Pragma("unroll") for (int ni_ = 0; ni_ < 4; ++ni_)                                               \
+      _Pragma("unroll") for (int rg_ = 0; rg_ < 4; ++rg_) {                                           \
+        int n_ = n0 + wn * 128 + ni_ * 32 + rg_ * 8 + kg * 4;                                         \
+        n_ = n_ < p.N ? n_ : p.N - 4;                                                                 \
+        bias_r[ni_][rg_] = be_ ? *reinterpret_cast<const uint2 *>(be_ + n_) : make_uint2(0u, 0u);     \
+      }                                                                                               \
+  } while (0)
+  if (EARLY_BIAS) PP_LOAD_BIAS();
   // RAGGED: one branch per wave OUTSIDE the loop picks the loop version (every version runs the same DMA issues,
   // waits and barriers; only the MFMA blocks differ), so the loop bodies stay branch-free
   if (!RAGGED || mi_on[1]) PP_MAINLOOP(2);
@@ -1097,7 +1111,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
 #undef PP_ISSUE_W
 #undef PP_KOFF
 
-  GM_PRELOAD_BIAS_N(4);
+  if (!EARLY_BIAS) PP_LOAD_BIAS();
+#undef PP_LOAD_BIAS
   if ((p.ldd & 7) || (p.d_stride_e & 7) || (p.d_stride_w & 7) || (reinterpret_cast<uintptr_t>(p.D) & 15)) {
     gemm_epilogue<T, ACT, 4>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);  // rows not 16-byte aligned
     return;
@@ -1106,11 +1121,11 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   gemm_epilogue_lds<T, ACT>(p, acc, bias_r, smem + wid * (64 * EP_PITCH), e, m0, n0, wm, wn, lane, row_limit);
 }
 
-template <typename T, int ACT, bool W_ONCE, bool RAGGED = false>
+template <typename T, int ACT, bool W_ONCE, bool RAGGED = false, bool EARLY_BIAS = false>
 static int launch_pp_cfg(const GemmArgs &b, hipStream_t st) {
   const size_t lds = (size_t)8 * 64 * EP_PITCH;  // 136 KB: the epilogue staging (8 waves x 64 rows x 272 B) > the two K-tile buffers (128 KB)
   static_assert((size_t)8 * 64 * EP_PITCH >= (size_t)2 * PP_BUF * 2, "LDS request must cover the K-tile buffers");
-  auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, RAGGED>;
+  auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, RAGGED, EARLY_BIAS>;
   static bool optin = false;
   if (!optin) {
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1130,9 +1145,11 @@ static int launch_pp(const GemmArgs &a, hipStream_t st) {
   // a last M-tile with >= 32 padding rows, or per-expert row counts: the variant that skips padded 32-row groups
   const int tail_rows = b.R % GB_BM;
   const bool ragged = b.row_counts != nullptr || (tail_rows != 0 && tail_rows <= GB_BM - 32);
+  // bias fetched before the K loop (full tiles; +0.5-1.7 % on every MFMA-bound shape, profiles/r03_pp_bias_ab.json); 0 = after it, for A/B
+  const bool early = tutel_get_option(TUTEL_OPT_GEMM_PERSIST) != 0;
   if (b.ntm == 1 && (long long)b.E_loc * b.ntn >= 256)
-    return ragged ? launch_pp_cfg<T, ACT, true, true>(b, st) : launch_pp_cfg<T, ACT, true>(b, st);
-  return ragged ? launch_pp_cfg<T, ACT, false, true>(b, st) : launch_pp_cfg<T, ACT, false>(b, st);
+    return ragged ? launch_pp_cfg<T, ACT, true, true>(b, st) : (early ? launch_pp_cfg<T, ACT, true, false, true>(b, st) : launch_pp_cfg<T, ACT, true>(b, st));
+  return ragged ? launch_pp_cfg<T, ACT, false, true>(b, st) : (early ? launch_pp_cfg<T, ACT, false, false, true>(b, st) : launch_pp_cfg<T, ACT, false>(b, st));
 }
 
 template <typename T, bool KM, int ACT, int NI, int NS = 2, bool BUF = false>
