@@ -36,7 +36,9 @@ expert-parallel run: one pipeline stage, and the whole rank).
 Launch mode: with capacity_factor > 0 the forward never talks to the host, so the default is to capture it once in a HIP graph
 (tutel_amd.impls.graph.GraphedForward -- kernels, and with N > 1 the RCCL collectives of the library's communicator) and REPLAY
 it per step; `--eager` measures the Python-enqueued forward instead, and the line always carries the other mode beside it
-(`launch_modes`).  If capture fails the script says so on stderr and in the line and runs eager.
+(`launch_modes`).  If capture fails the script says so on stderr and in the line and runs eager.  N > 1 is timed eager (GPU-bound:
+0.16 ms of host enqueue against >= 0.25 ms of device work per forward) because replaying captured RCCL collectives was seen to
+hang after a few hundred replays with this RCCL build (profiles/r03_ep_streams.txt); `--graph` forces the replay there.
 `cpu_baseline`: the CPU oracle (a port of the reference CPU path, oracle/moe_oracle.py) timed on this box's host
 cores on a bounded sample, rank 0, N=1 only, next to the figure BASELINE.md measured with the reference itself.
 Checker code is used here ONLY as that reported baseline; it is never part of the measured GPU path.
@@ -259,7 +261,11 @@ def main():
     step = (lambda t: layer(t, **fwd_kw)) if fwd_kw else layer
     eager_step = step
     launch, graph_note, graphed = "eager", None, None
-    want_graph = (args.graph or not args.eager) and args.capacity_factor > 0 and not share
+    # N > 1: eager unless --graph is given.  Replaying captured RCCL collectives is not safe to default to with this RCCL build: in
+    # the 1-rank-communicator probe (tools/r3_ep_streams_ab.py, profiles/r03_ep_streams.txt) capture succeeds and the first
+    # ~200 replays run, then a later replay never completes.  The N > 1 forward is GPU-bound eager (0.16 ms of host enqueue per
+    # forward against >= 0.25 ms of device work per rank), so eager is what is timed; N = 1 (no collectives) replays the graph.
+    want_graph = (args.graph or (not args.eager and world == 1)) and args.capacity_factor > 0 and not share
     if want_graph:
         # same kernels (and, N > 1, the same RCCL collectives on the caller's stream), enqueued by ONE hipGraphLaunch per step:
         # the host cost of a forward drops from ~0.09 (N = 1) / ~0.16 ms (N > 1, degree 2) to one launch, so the step is
@@ -283,6 +289,9 @@ def main():
             step, launch = graphed, "hip-graph replay"
     elif args.capacity_factor <= 0:
         graph_note = "dropless routing reads the capacity back to the host every step: not capturable, eager"
+    elif world > 1 and not share:
+        graph_note = ("N > 1 is timed eager: replaying captured RCCL collectives hung after a few hundred replays in the 1-rank-communicator "
+                      "probe (profiles/r03_ep_streams.txt); --graph forces the replay")
 
     with torch.no_grad():
         for _ in range(args.settle):

@@ -374,7 +374,7 @@ int tutel_amd_marks_report(double *delta_us, int n);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG / TUTEL_AMD_DECODE /
- * TUTEL_AMD_ROUTING / TUTEL_AMD_GEMM_PERSIST seed it once), >= 0 = force.  Every choice computes bit-identical results.
+ * TUTEL_AMD_ROUTING / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS seed it once), >= 0 = force.  Every choice computes bit-identical results.
  *   TUTEL_OPT_GEMM_IMPL  128-tile kernels: 0 register-staged, 1 LDS-DMA
  *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
  *                        with a two- / three-slot LDS ring (k-major weights), 4 always the 256 x 256 ping-pong kernel
@@ -384,13 +384,16 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *   TUTEL_OPT_ROUTING    tutel_amd_moe_forward: 0 / automatic = top-k and location as two launches, 1 = the fused routing kernel
  *                        (tutel_amd_route; measured equal on MI355X, so not the default)
  *   TUTEL_OPT_GEMM_PERSIST  256 x 256 ping-pong kernel, bias operand: 0 = fetched after the K loop, 1 / automatic = before it
- *                        (32 more live registers, its L2 round trip hidden behind the loop) */
+ *                        (32 more live registers, its L2 round trip hidden behind the loop)
+ *   TUTEL_OPT_EP_STREAMS overlapped pipeline: 1 = every stage's GEMMs on ONE side stream, 2 / automatic = stages alternate between
+ *                        two side streams (the half-chip GEMM grids of two stages run side by side) */
 #define TUTEL_OPT_GEMM_IMPL 0
 #define TUTEL_OPT_GEMM_TILE 1
 #define TUTEL_OPT_DECODE 2
 #define TUTEL_OPT_ROUTING 3
 #define TUTEL_OPT_GEMM_PERSIST 4
-#define TUTEL_OPT_COUNT 5
+#define TUTEL_OPT_EP_STREAMS 5
+#define TUTEL_OPT_COUNT 6
 int tutel_amd_set_option(int key, int value);
 
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------

@@ -108,10 +108,12 @@ struct tutel_amd_ep_comm {
   // few hardware queues PER PRIORITY LEVEL, and two streams that share a queue run strictly one after the other: every fourth
   // normal-priority stream created in a process lands on the default stream's queue and would then never overlap with it
   // (measured on MI355X, tools/stream_concurrency_check.py, profiles/r03_stream_queues.txt).  Streams of different priority never
-  // share a queue, so the communicator owns TWO side streams -- highest and lowest priority -- and a call uses the one whose
-  // priority differs from its caller's stream.
-  hipStream_t side_stream;      // highest priority: used unless the caller's stream has that priority itself
+  // share a queue, so the communicator owns THREE side streams -- highest, lowest and normal priority -- and a call uses the two
+  // whose priority differs from its caller's stream: stage i of the pipeline runs on side stream i % 2, so that the GEMMs of two
+  // stages (each a half-chip grid of 128 workgroups at the expert-parallel shapes) run side by side.
+  hipStream_t side_stream;      // highest priority
   hipStream_t side_stream_low;  // lowest priority
+  hipStream_t side_stream_mid;  // normal priority (used only when the caller's stream is one of the other two)
   hipEvent_t recv_ev[EP_MAX_SPLIT], done_ev[EP_MAX_SPLIT];
 };
 
@@ -119,14 +121,20 @@ static bool create_side_streams(tutel_amd_ep_comm *c) {
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
   return hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, greatest) == hipSuccess &&
-         hipStreamCreateWithPriority(&c->side_stream_low, hipStreamNonBlocking, least) == hipSuccess;
+         hipStreamCreateWithPriority(&c->side_stream_low, hipStreamNonBlocking, least) == hipSuccess &&
+         hipStreamCreateWithPriority(&c->side_stream_mid, hipStreamNonBlocking, (least + greatest) / 2) == hipSuccess;
 }
 
-// the side stream whose priority differs from the caller's (see struct tutel_amd_ep_comm)
-static hipStream_t side_stream_for(tutel_amd_ep_comm *c, hipStream_t caller) {
+// the two side streams whose priority differs from the caller's (see struct tutel_amd_ep_comm); TUTEL_OPT_EP_STREAMS = 1: one
+static void side_streams_for(tutel_amd_ep_comm *c, hipStream_t caller, hipStream_t out[2]) {
   int least = 0, greatest = 0, pr = 0;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamGetPriority(caller, &pr) != hipSuccess) return c->side_stream;
-  return pr == greatest && least != greatest ? c->side_stream_low : c->side_stream;
+  out[0] = c->side_stream;
+  out[1] = c->side_stream_low;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && hipStreamGetPriority(caller, &pr) == hipSuccess && least != greatest) {
+    if (pr == greatest) out[0] = c->side_stream_mid;
+    else if (pr == least) out[1] = c->side_stream_mid;
+  }
+  if (tutel_get_option(TUTEL_OPT_EP_STREAMS) == 1) out[1] = out[0];
 }
 
 extern "C" int tutel_amd_ep_unique_id(void *out, size_t bytes) {
@@ -200,9 +208,11 @@ extern "C" int tutel_amd_ep_comm_destroy(tutel_amd_ep_comm_t *c) {
   if (c == nullptr) return 0;
   if (c->side_stream != nullptr) (void)hipStreamSynchronize(c->side_stream);
   if (c->side_stream_low != nullptr) (void)hipStreamSynchronize(c->side_stream_low);
+  if (c->side_stream_mid != nullptr) (void)hipStreamSynchronize(c->side_stream_mid);
   if (c->comm != nullptr && g_rccl.CommDestroy != nullptr) (void)g_rccl.CommDestroy(c->comm);
   if (c->side_stream != nullptr) (void)hipStreamDestroy(c->side_stream);
   if (c->side_stream_low != nullptr) (void)hipStreamDestroy(c->side_stream_low);
+  if (c->side_stream_mid != nullptr) (void)hipStreamDestroy(c->side_stream_mid);
   for (int i = 0; i < EP_MAX_SPLIT; ++i) {
     if (c->recv_ev[i] != nullptr) (void)hipEventDestroy(c->recv_ev[i]);
     if (c->done_ev[i] != nullptr) (void)hipEventDestroy(c->done_ev[i]);
@@ -434,7 +444,8 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     // caller's stream is the origin of a HIP-graph capture, and RCCL can be captured there but not on a stream that
     // joined the capture through an event (segfault inside the library, tools/graph_rccl_probe.py) -- plain kernel
     // launches are fine on either.  Eager and captured execution take this one path.
-    hipStream_t ks = side_stream_for(c, cur);
+    hipStream_t kss[2];
+    side_streams_for(c, cur, kss);
     {
       Range r("tutel_amd.all_to_all(dispatch)");
       for (int i = 0; i < degree; ++i) {
@@ -443,14 +454,21 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
         HIP_CHECK(hipEventRecord(c->recv_ev[i], cur), "hipEventRecord");
       }
     }
+    // Stage i's GEMMs go to side stream i % 2: fc1 of stage i + 1 does not depend on fc2 of stage i, and at the expert-parallel
+    // shapes a stage launch is a half-chip grid (128 workgroups of the 256 x 256 kernel), so two stages side by side fill the
+    // GPU: 4 launches take ~3 launch times instead of 4 (degree 2).  The ENQUEUE order stays stage by stage -- GEMMs of stage i,
+    // join, return exchange of stage i -- so that every RCCL call is captured with all forked streams joined back (RCCL cannot
+    // be captured next to an open fork, tools/graph_rccl_probe.py); the device runs by dependencies, not by enqueue order:
+    // stage i + 1 on the other stream only waits for its own recv event.
     for (int i = 0; i < degree; ++i) {
-      HIP_CHECK(hipStreamWaitEvent(ks, c->recv_ev[i], 0), "hipStreamWaitEvent");  // first wait: the side stream joins (forks from) the caller's
+      hipStream_t ks = kss[i & 1];
+      HIP_CHECK(hipStreamWaitEvent(ks, c->recv_ev[i], 0), "hipStreamWaitEvent");  // the side stream forks from the caller's
       tutel_gemm_corun_hint(c->comm != nullptr);  // a real collective runs beside these GEMMs (the hosted test exchange is synchronous)
       rc = stage_gemms(i, ks);
       tutel_gemm_corun_hint(0);
       if (rc) return rc;
       HIP_CHECK(hipEventRecord(c->done_ev[i], ks), "hipEventRecord");
-      HIP_CHECK(hipStreamWaitEvent(cur, c->done_ev[i], 0), "hipStreamWaitEvent");  // last wait: the side stream is joined back
+      HIP_CHECK(hipStreamWaitEvent(cur, c->done_ev[i], 0), "hipStreamWaitEvent");  // and is joined back
       Range r("tutel_amd.all_to_all(combine)");
       rc = exchange(c, (const char *)a->send + (size_t)i * msg_out, (char *)a->back + (size_t)i * msg_out, (size_t)rows * Mo * es, W, cur, TUTEL_STAGE_A2A_COMBINE);
       if (rc) return rc;
