@@ -50,3 +50,8 @@ json.dump(tj, open(f"{out}/traffic.json", "w"), indent=1)
 print(json.dumps(tj, indent=1))
 PY
 find $OUT -name "*kernel_stats.csv" | head
+# 4. per-rank shapes of the expert-parallel configurations, emulated on one GPU (bench lines only; kernel stats for the 8-expert one)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_ep8shape -- python bench.py --steps 20 --warmup 5 --experts 8 --no_cpu_baseline --no_extra > $OUT/bench_ep8shape.json 2> $OUT/bench_ep8shape.err
+python bench.py --steps 20 --warmup 5 --model_dim 4096 --hidden_size 4096 --experts 8 --no_cpu_baseline --no_extra > $OUT/bench_config3_rank.json 2> /dev/null
+python bench.py --steps 20 --warmup 5 --tokens 8192 --model_dim 4096 --hidden_size 4096 --experts 16 --dtype float16 --no_cpu_baseline --no_extra > $OUT/bench_config4_rank.json 2> /dev/null
+python bench.py --steps 20 --warmup 5 --tokens 65536 --no_cpu_baseline --no_extra > $OUT/bench_65536.json 2> /dev/null
