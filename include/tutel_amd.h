@@ -68,7 +68,7 @@ size_t tutel_amd_routing_workspace_bytes(int T, int E, int k);
  *   gates [k,T] dtype  scores[t, idx_k[t]], divided by clamp(sum_k, eps(dtype)) when
  *                      normalize_gate != 0 and k > 1, each step rounded in `dtype` exactly as
  *                      fast_dispatch.py:151,173-175 does.
- * Limits: 1 <= k <= min(E, 16), E <= 1024.
+ * Limits: 1 <= k <= min(E, 16), E <= 4096, k * E <= 8192 (per-tile expert histograms live in LDS).
  * clear_map / clear_n (optional, NULL / 0): an int32 array this launch also fills with -1 -- pass
  * the slot_map that the following tutel_amd_compute_location builds (slot_map_cleared = 1) to
  * save the separate fill launch. */

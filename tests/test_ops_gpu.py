@@ -444,20 +444,20 @@ def test_routing_randomized_shapes_vs_oracle(oracle):
 
 
 def test_routing_limits_fail_loudly_and_the_edges_work(oracle):
-    """The routing kernels hold 1 <= k <= 16, E <= 1024 and k * E <= 8192 (include/tutel_amd.h, INTEGRATION.md "Limits"); the
+    """The routing kernels hold 1 <= k <= 16, E <= 4096 and k * E <= 8192 (include/tutel_amd.h, INTEGRATION.md "Limits"); the
     reference's ATen op chain takes any E (fast_dispatch.py:143-148).  Inside the limits -- including their edges -- the
     result is the oracle's, bit for bit; outside, the call raises with the limit in the message: never a silent fallback to
     another implementation, never a wrong answer."""
     from tutel import moe
     from tutel_amd import _lib
     g = torch.Generator().manual_seed(3)
-    for T, E, k in ((300, 1024, 2), (257, 512, 16), (128, 1024, 8)):   # the edges: E = 1024, k = 16, k * E = 8192
+    for T, E, k in ((300, 1024, 2), (257, 512, 16), (128, 1024, 8), (200, 2048, 4), (130, 4096, 2), (65, 3000, 1)):   # the edges: E = 4096, k = 16, k * E = 8192
         scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
         crit, l_aux = moe.top_k_routing(scores.cuda(), k)
         ref, l_ref = oracle.extract_critical(scores, k)
         assert torch.equal(torch.stack(crit[1]).cpu(), torch.stack(ref[1])) and torch.equal(torch.stack(crit[2]).cpu(), torch.stack(ref[2]))
         assert crit[4] == ref[4] and torch.equal(crit[5].cpu(), ref[5]) and abs(float(l_aux) - float(l_ref)) < 1e-5
-    for T, E, k, word in ((64, 1025, 2, "1024"), (64, 2048, 1, "1024"), (64, 64, 17, "16"), (64, 1024, 9, "8192")):
+    for T, E, k, word in ((64, 4097, 2, "4096"), (64, 8192, 1, "4096"), (64, 64, 17, "16"), (64, 1024, 9, "8192"), (64, 4096, 3, "8192")):
         scores = torch.softmax(torch.randn([T, E], generator=g), dim=1).cuda()
         with pytest.raises(_lib.TutelAmdError) as ei:
             moe.top_k_routing(scores, k)

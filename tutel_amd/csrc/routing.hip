@@ -27,7 +27,8 @@
 #define GT_WAVES 16
 #define RT_MAX_TILES 128
 #define RT_MAX_K 16
-#define RT_MAX_E 1024
+#define RT_MAX_E 4096
+#define GT_COL_SLAB 1024  // experts per pass of the column-sum reduction through LDS (bounds the LDS footprint for large E)
 
 static inline int rt_tile(int T) {
   int per = (T + 64 * RT_MAX_TILES - 1) / (64 * RT_MAX_TILES);
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
   using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);             // [k][E]
-  float *s_col = reinterpret_cast<float *>(smem) + (size_t)k * E;  // [GT_WAVES][E]
+  float *s_col = reinterpret_cast<float *>(smem) + (size_t)k * E;  // [GT_WAVES][min(E, GT_COL_SLAB)]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.x;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
       }
 
     // k rounds of wave arg-max, order: score desc, expert index asc.
-    uint32_t taken[GT_BATCH];
+    unsigned long long taken[GT_BATCH];   // bit j: this lane's j-th expert was picked in an earlier round (EPL <= 64)
     CT myg[GT_BATCH];
     int myidx[GT_BATCH];
 #pragma unroll
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
           int e = lane + 64 * j;
-          bool ok = (e < E) && !((taken[u] >> j) & 1u);
+          bool ok = (e < E) && !((taken[u] >> j) & 1ull);
           if (ok && (v[u][j] > bv[u] || (v[u][j] == bv[u] && e < be[u]))) { bv[u] = v[u][j]; be[u] = e; }
         }
       }
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
         }
 #pragma unroll
       for (int u = 0; u < GT_BATCH; ++u) {
-        if ((be[u] & 63) == lane) taken[u] |= 1u << (be[u] >> 6);
+        if ((be[u] & 63) == lane) taken[u] |= 1ull << (be[u] >> 6);
         if (lane == c) { myg[u] = bv[u]; myidx[u] = be[u]; }
       }
     }
@@ -195,18 +196,24 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
     }
   }
 
-#pragma unroll
-  for (int j = 0; j < EPL; ++j) {
-    int e = lane + 64 * j;
-    if (e < E) s_col[wid * E + e] = colacc[j];
-  }
   __syncthreads();
   for (int i = tid; i < k * E; i += GT_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
-  for (int e = tid; e < E; e += GT_THREADS) {
-    float s = 0.f;
+  // per-expert column sums: the 16 waves' partial sums meet in LDS, one slab of experts at a time, added in wave order
+  const int slab = E < GT_COL_SLAB ? E : GT_COL_SLAB;
+  for (int e0 = 0; e0 < E; e0 += slab) {
 #pragma unroll
-    for (int w = 0; w < GT_WAVES; ++w) s += s_col[w * E + e];
-    ws_colsum[(size_t)b * E + e] = s;
+    for (int j = 0; j < EPL; ++j) {
+      int e = lane + 64 * j;
+      if (e >= e0 && e < e0 + slab && e < E) s_col[wid * slab + (e - e0)] = colacc[j];
+    }
+    __syncthreads();
+    for (int e = e0 + tid; e < e0 + slab && e < E; e += GT_THREADS) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < GT_WAVES; ++w) s += s_col[w * slab + (e - e0)];
+      ws_colsum[(size_t)b * E + e] = s;
+    }
+    __syncthreads();
   }
 }
 
@@ -674,7 +681,7 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
   const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
-  size_t lds = ((size_t)k * E + (size_t)GT_WAVES * E) * 4;
+  size_t lds = ((size_t)k * E + (size_t)GT_WAVES * (E < GT_COL_SLAB ? E : GT_COL_SLAB)) * 4;
   if (E <= 128) {
     const int epq = (E + GQ_LPT - 1) / GQ_LPT;                 // 1..8
     const int epq_t = epq <= 1 ? 1 : (epq <= 2 ? 2 : (epq <= 4 ? 4 : 8));
@@ -707,9 +714,11 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
   const int epl = (E + 63) / 64;
 #define GT_LAUNCH(EPL)                                                                          \
   do {                                                                                          \
-    if (lds > 65536)                                                                            \
+    if (lds > 65536) {                                                                          \
       (void)hipFuncSetAttribute((const void *)gate_topk_kernel<T, EPL, (EPL <= 4 ? 4 : (EPL <= 8 ? 2 : 1))>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+      (void)hipGetLastError();                                                                  \
+    }                                                                                           \
     hipLaunchKernelGGL((gate_topk_kernel<T, EPL, (EPL <= 4 ? 4 : (EPL <= 8 ? 2 : 1))>), dim3(nt), dim3(GT_THREADS), lds, st,         \
                        (const T *)in, apply_softmax, Tn, E, k, normalize, tile,                 \
                        (T *)scores_out, idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n);  \
@@ -718,7 +727,9 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
   else if (epl <= 2) GT_LAUNCH(2);
   else if (epl <= 4) GT_LAUNCH(4);
   else if (epl <= 8) GT_LAUNCH(8);
-  else GT_LAUNCH(16);
+  else if (epl <= 16) GT_LAUNCH(16);
+  else if (epl <= 32) GT_LAUNCH(32);
+  else GT_LAUNCH(64);
 #undef GT_LAUNCH
   TUTEL_CHECK_LAUNCH("tutel_amd_gate_topk");
   return 0;
@@ -806,7 +817,12 @@ extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int 
     slot_map = nullptr;
     capacity = 0;
   }
-  hipLaunchKernelGGL(location_kernel, dim3(nt), dim3(RT_THREADS), ((size_t)2 * k * E + (size_t)(E > RT_THREADS ? E : RT_THREADS)) * 4, st, idx, T, E, k,
+  const size_t lds_loc = ((size_t)2 * k * E + (size_t)(E > RT_THREADS ? E : RT_THREADS)) * 4;
+  if (lds_loc > 65536) {
+    (void)hipFuncSetAttribute((const void *)location_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_loc);
+    (void)hipGetLastError();
+  }
+  hipLaunchKernelGGL(location_kernel, dim3(nt), dim3(RT_THREADS), lds_loc, st, idx, T, E, k,
                      tile, nt, ws_hist, ws_col, loc, dispatch_count, stats, l_aux, l_aux_dtype, capacity, slot_map);
   TUTEL_CHECK_LAUNCH("tutel_amd_compute_location");
   return 0;

@@ -259,7 +259,7 @@ class MOELayer(torch.nn.Module):
                   and not self.batch_prioritized_routing and self.is_gshard_loss and not (self.training and gate.gate_noise > 0)
                   and logits.dtype in (torch.float32, torch.bfloat16, torch.float16)
                   and not (torch.is_grad_enabled() and logits.requires_grad)
-                  and k <= 16 and E <= 1024 and k * E <= 8192)
+                  and k <= 16 and E <= 4096 and k * E <= 8192)
             if ok and dropless:   # capacity = max expert load: read back inside the native call, single rank only
                 ok = W == 1 and (megablocks_size == 0 or self.is_postscore)
             elif ok:
