@@ -36,7 +36,10 @@ def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False, l_aux_dtype=
     stats = cnt.max().reshape(1)
     l_aux = None
     if want_l_aux and ws is not None:
-        l_aux = O.gshard_loss(ws["scores"], ws["idx0"]).to(l_aux_dtype).reshape(1)
+        if idx.shape[1] == 0:   # a rank without tokens: the HIP path writes 0 (the reference's loss divides by the token count)
+            l_aux = torch.zeros([1], dtype=l_aux_dtype)
+        else:
+            l_aux = O.gshard_loss(ws["scores"], ws["idx0"]).to(l_aux_dtype).reshape(1)
     smap = _smap(idx, loc, E, capacity) if capacity > 0 else None
     return loc, cnt, stats, l_aux, smap
 

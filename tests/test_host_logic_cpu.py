@@ -324,6 +324,54 @@ def test_expert_parallel_world2_gloo(degree, use_2dh):
         assert ok, f"rank {rank}: {info}"
 
 
+def _uneq_worker(rank, world, port, tokens, degree, q):
+    """inequivalent_tokens=True over gloo (kernels replaced by the oracle shim): every rank sizes its buckets from the LARGEST
+    rank (fast_dispatch.py:181-186) and a rank without tokens still takes part in every exchange."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import _cpu_ops as shim
+        from oracle import moe_oracle as O
+        from tutel_amd import ops
+        for name in ("gate_topk", "compute_location", "slot_map", "cumsum_sub_one", "fast_encode", "fast_decode", "gate_grad"):
+            setattr(ops, name, getattr(shim, name))
+        from tutel import system
+        system.init_data_model_parallel(backend="gloo")
+        T, M, H, E_loc, k = 256, 32, 16, 2, 2
+        E = E_loc * world
+        xs = [O.make_problem(T, M, H, E, seed=100 + r)[0][:tokens[r]] for r in range(world)]
+        _, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, seed=7)
+        sl = slice(rank * E_loc, (rank + 1) * E_loc)
+        layer = _make_layer(M, H, E_loc, k, 1.0, a2a_ffn_overlap_degree=degree).eval()
+        _load(layer, wg, w1[sl], b1[sl], w2[sl], b2[sl])
+        with torch.no_grad():
+            y = layer(xs[rank], inequivalent_tokens=True)
+        parts = lambda t: [t[r * E_loc:(r + 1) * E_loc] for r in range(world)]
+        want, crits = O.moe_forward_ep(xs, wg, parts(w1), parts(b1), parts(w2), parts(b2), top_k=k, alignment=degree, inequivalent_tokens=True)
+        ok = y.shape == want[rank].shape and torch.equal(y, want[rank]) and torch.equal(layer.dispatch_count, crits[rank][5])
+        q.put((rank, bool(ok), f"capacity {crits[rank][4]}, tokens {tokens[rank]}"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("tokens,degree", [([256, 0], 1), ([0, 200], 2), ([256, 100], 2)])
+def test_unequal_and_empty_ranks_world2_gloo(tokens, degree):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneq_worker, args=(r, 2, port, tokens, degree, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, info in res:
+        assert ok, f"rank {rank}: {info}"
+
+
 def test_hierarchical_all_to_all_world4_two_nodes_of_two_gloo():
     """use_2dh with LOCAL_SIZE=2 on 4 ranks: the intra-node then inter-node exchange (communicate.py:412-430) must equal the
     flat all-to-all (the reference's test_a2a_algos, test_tutel.py:178-209) -- as a collective and through the layer."""
