@@ -463,8 +463,10 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
 // resident at once: the grid is at most RT_MAX_TILES = 128 blocks (one per CU on a 256-CU part; blocks are dispatched in index
 // order and a spinning block only ever waits for blocks that were dispatched before it or are about to be).  `sync` points to two
 // zero-initialised words: arrivals and departures; the last block to leave resets both, so the words are zero again when the
-// kernel ends (safe to replay from a HIP graph).  Cross-block visibility: tile histograms are published with a device-scope
-// release (fence + atomic add) and read after a device-scope acquire.
+// kernel ends (safe to replay from a HIP graph).  Cross-block visibility: everything one block writes and another reads inside
+// the launch (tile histograms, column sums, the slot map's clear and scatter) moves with device-scope relaxed atomics (sc1),
+// see ld_i32 / st_i32 above -- a release / acquire fence pair instead costs 22 us (it writes back / invalidates the whole L2).
+// Measured equal to the two launches (17.8 vs 9.6 + 8.6 us): opt-in, TUTEL_OPT_ROUTING = 1.
 struct FusedLoc {
   int32_t *loc, *dispatch_count, *stats;
   void *l_aux;
