@@ -334,7 +334,7 @@ def moe_forward(x, wg, w1, b1, w2, b2, top_k=2, capacity_factor=1.0, fp32_gate=F
 
 def moe_forward_ep(xs, wg, w1s, b1s, w2s, b2s, top_k=2, capacity_factor=1.0, fp32_gate=False,
                    normalize_gate=True, is_postscore=True, act=torch.relu, alignment=1,
-                   accum_fp32=False, inequivalent_tokens=False):
+                   accum_fp32=False, inequivalent_tokens=False, return_expert_inputs=False):
     """Expert-parallel forward with W ranks simulated in-process: xs[r] is rank r's [T,M]
     tokens, w1s[r] etc. rank r's local expert weights.  Reference: moe_layer.py:344-351 with
     num_local_experts > 0 (E = E_loc*W, moe_layer.py:46-55).  inequivalent_tokens: the ranks hold
@@ -348,15 +348,30 @@ def moe_forward_ep(xs, wg, w1s, b1s, w2s, b2s, top_k=2, capacity_factor=1.0, fp3
         crit, _ = extract_critical(scores, top_k, capacity_factor, normalize_gate, alignment, with_loss=xr.shape[0] > 0,
                                    num_samples=n_max)
         crits.append(crit)
-        encs.append(fast_encode(xr.to(ldt), crit, is_postscore).to(xr.dtype))
+    if capacity_factor <= 0:
+        # dropless: the capacity is the all-reduce MAX over the ranks of the largest expert load (fast_dispatch.py:191-193),
+        # then clamped / aligned like the single-rank value (:194-199)
+        E, k = crits[0][0], len(crits[0][1])
+        cap = max(int(c[5].max()) if c[5].numel() else 0 for c in crits)
+        n = n_max if n_max is not None else int(xs[0].shape[0])
+        if capacity_factor < 0:
+            cap = min(cap, k * int(-capacity_factor * ((n + E - 1) // E)))
+        if cap % alignment:
+            cap += alignment - cap % alignment
+        crits = [(c[0], c[1], c[2], c[3], cap, c[5]) for c in crits]
+    for r in range(W):
+        xr = xs[r].to(w1s[r].dtype)
+        encs.append(fast_encode(xr.to(ldt), crits[r], is_postscore).to(xr.dtype))
     C = crits[0][4]
     assert all(c[4] == C for c in crits)
     recv = a2a_dispatch(encs)
     outs = [expert_ffn(recv[r], w1s[r], b1s[r], w2s[r], b2s[r], act, accum_fp32=accum_fp32)
             for r in range(W)]
     back = a2a_combine(outs, C)
-    return [fast_decode(back[r].to(ldt), crits[r], is_postscore).to(xs[r].dtype)
-            for r in range(W)], crits
+    ys = [fast_decode(back[r].to(ldt), crits[r], is_postscore).to(xs[r].dtype) for r in range(W)]
+    if return_expert_inputs:   # [E_loc, W*C, M] per rank: what the reference's experts see after all_to_all(y, 1, 0)
+        return ys, crits, recv
+    return ys, crits
 
 
 # ---------------------------------------------------------------------------------------------

@@ -335,6 +335,73 @@ def test_variable_size_collectives_on_the_library_communicator(world):
     _run_ranks(_vcoll_worker, world, (), timeout=300)
 
 
+def _fixture_worker(rank, world, port, path, native, q):
+    """this rank's forward against the REFERENCE's own output for that rank (tests/golden/ep_*.npz: the reference run with W ranks
+    over gloo on its CPU path) -- not the oracle: the multi-rank HIP path pinned directly to reference-generated vectors."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import numpy as np
+        import torch.distributed as dist
+        from oracle import moe_oracle as O
+        from tutel import moe
+        from tutel_amd.impls import ep_native
+        ep_native.HOSTED = bool(native)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        z = np.load(path)
+        W, T, M, H, E_loc, k, fp32_gate = [int(v) for v in z["meta"]]
+        dtype, cf = getattr(torch, str(z["dtype"][0])), float(z["cf"][0])
+        tokens, uneq = [int(v) for v in z["tokens"]], bool(int(z["inequivalent"][0]))
+        E = E_loc * W
+        x = O.make_problem(T, M, H, E, dtype=dtype, seed=100 + rank)[0][:tokens[rank]]
+        _, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=dtype, seed=7)
+        sl = slice(rank * E_loc, (rank + 1) * E_loc)
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        layer = moe.moe_layer(gate_type={"type": "top", "k": k, "fp32_gate": bool(fp32_gate), "capacity_factor": cf}, model_dim=M,
+                              experts={"type": "ffn", "num_experts_per_device": E_loc, "hidden_size_per_expert": H,
+                                       "activation_fn": lambda t: torch.nn.functional.relu(t)})
+        torch.set_default_dtype(old)
+        with torch.no_grad():
+            layer.gates[0].wg.weight.copy_(wg.to(layer.gates[0].wg.weight.dtype))
+            layer.experts.batched_fc1_w.copy_(w1[sl]); layer.experts.batched_fc1_bias.copy_(b1[sl])
+            layer.experts.batched_fc2_w.copy_(w2[sl]); layer.experts.batched_fc2_bias.copy_(b2[sl])
+        layer = layer.cuda().eval()
+        with torch.no_grad():
+            y = layer(x.cuda(), inequivalent_tokens=uneq)
+        torch.cuda.synchronize()
+        t = torch.from_numpy(np.ascontiguousarray(z[f"y_{rank}"]))
+        want = t.view(torch.bfloat16) if dtype == torch.bfloat16 else t
+        ok = torch.equal(layer.dispatch_count.cpu(), torch.from_numpy(z[f"count_{rank}"]))
+        err = (y.cpu().double() - want.double()).abs()
+        if dtype == torch.float32:
+            bar = 1e-5 * max(1.0, float(want.double().abs().max()))       # north_star: 1e-5 fp32
+        else:
+            bar = 2 ** -6 * float(want.double().abs().max())              # the reference's own bf16 output rounds after each of its 4 ops
+        ok = ok and y.shape == want.shape and (err.numel() == 0 or float(err.max()) <= bar)
+        q.put((rank, bool(ok), f"max err {float(err.max()) if err.numel() else 0.0:.3e} (bar {bar:.1e}), l_aux {float(y.l_aux):.6f} vs {float(z[f'l_aux_{rank}'][0]):.6f}", []))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc(), []))
+
+
+def _ep_fixtures():
+    import glob
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ep_*.npz")))
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["native-one-call", "python-orchestrated"])
+@pytest.mark.parametrize("path", _ep_fixtures(), ids=lambda p: os.path.basename(p)[3:-4])
+def test_expert_parallel_vs_reference_multi_rank_fixture(path, native):
+    import numpy as np
+    assert len(_ep_fixtures()) >= 6
+    world = int(np.load(path)["meta"][0])
+    _run_ranks(_fixture_worker, world, (path, native), timeout=300)
+
+
 def _train_worker(rank, world, port, frozen_experts, q):
     """degree > 1, W > 1, grad enabled, layer INPUT without grad.  (a) trainable experts: the
     overlapped path must keep the autograd graph to the expert weights (same grads as degree 1);

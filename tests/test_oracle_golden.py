@@ -70,6 +70,31 @@ def test_oracle_noisy_gate_load_importance_matches_reference_fixture(oracle, pat
     assert abs(float(l_aux) - float(z["l_aux"][0])) <= 1e-6 * max(1.0, abs(float(l_aux)))
 
 
+EP = sorted(glob.glob(os.path.join(GOLD, "ep_*.npz")))
+
+
+@pytest.mark.parametrize("path", EP, ids=lambda p: os.path.basename(p)[3:-4])
+def test_oracle_expert_parallel_matches_reference_fixture(oracle, path):
+    """moe_forward_ep (the W-rank simulation every multi-rank test is checked against) replayed against outputs of the reference
+    itself running with W ranks over gloo (tests/golden/make_golden_ep.py): per rank y, the [E_loc, W*C, M] rows its experts
+    received after the all-to-all, dispatch counts, l_aux -- bit for bit; incl. unequal token counts and dropless capacity."""
+    z = np.load(path)
+    assert len(EP) >= 6
+    W, T, M, H, E_loc, k, fp32_gate = [int(v) for v in z["meta"]]
+    dtype, cf = DT[str(z["dtype"][0])], float(z["cf"][0])
+    tokens, uneq = [int(v) for v in z["tokens"]], bool(int(z["inequivalent"][0]))
+    E = E_loc * W
+    xs = [oracle.make_problem(T, M, H, E, dtype=dtype, seed=100 + r)[0][:tokens[r]] for r in range(W)]
+    _, wg, w1, b1, w2, b2 = oracle.make_problem(T, M, H, E, dtype=dtype, seed=7)
+    parts = lambda t: [t[r * E_loc:(r + 1) * E_loc] for r in range(W)]
+    ys, crits, recvs = oracle.moe_forward_ep(xs, wg, parts(w1), parts(b1), parts(w2), parts(b2), top_k=k, capacity_factor=cf,
+                                             fp32_gate=bool(fp32_gate), inequivalent_tokens=uneq, return_expert_inputs=True)
+    for r in range(W):
+        assert torch.equal(ys[r], _t(z[f"y_{r}"], dtype)), f"rank {r}: y"
+        assert torch.equal(recvs[r], _t(z[f"recv_{r}"], dtype).reshape(recvs[r].shape)), f"rank {r}: rows after the all-to-all"
+        assert torch.equal(crits[r][5], torch.from_numpy(z[f"count_{r}"])), f"rank {r}: dispatch counts"
+
+
 def test_headline_integer_fixture(oracle):
     """BASELINE configs[1] shape: token->expert/slot assignment of the reference, bit-exact."""
     z = np.load(os.path.join(GOLD, "headline_integers.npz"))
