@@ -28,6 +28,59 @@ CASES = [
 ]
 
 
+# sharded experts (one expert's hidden dim sliced over the ranks, num_experts_per_device = -W): the three
+# parallel modes the reference compares with each other (tests/test_tutel.py:154-159) -- weights from the layer's own seeds
+SHARDED = ("sharded_w2_f32_k1", 2, 128, 32, 16, 1)   # name, W, T, M, H, k
+
+
+def _sharded_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        sys.path = [REF, os.path.join(ROOT, "oracle", "_ref")] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT] + [ROOT]
+        import logging
+        import torch
+        import torch.distributed as dist
+        logging.disable(logging.CRITICAL)
+        import tutel
+        assert os.path.abspath(tutel.__file__).startswith(REF), tutel.__file__
+        from tutel import moe as ref_moe
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        name, W, T, M, H, k = SHARDED
+        outs = {}
+        for ptype in ("data", "model", "adaptive:0"):
+            layer = ref_moe.moe_layer(gate_type={"type": "top", "k": k},
+                                      experts={"type": "ffn", "num_experts_per_device": -W, "hidden_size_per_expert": H,
+                                               "activation_fn": lambda t: torch.nn.functional.relu(t)},
+                                      model_dim=M, parallel_type=ptype, seeds=(1, rank + 1, 1)).eval()
+            torch.manual_seed(0)
+            x = torch.randn(T, M)
+            with torch.no_grad():
+                outs[ptype] = layer(x)
+        q.put((rank, {k: v.numpy().copy() for k, v in outs.items()}, True, None, None))   # by value: the worker may exit before the parent reads
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None, None))
+
+
+def run_sharded_reference():
+    import torch.multiprocessing as mp
+    W = SHARDED[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, W, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[2] is not None, r[1]
+    return res
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -144,6 +197,12 @@ def main():
     if args.check:
         print("oracle-vs-reference (expert parallel, W > 1): %d mismatches" % bad)
         sys.exit(1 if bad else 0)
+    out = {"meta": np.array(SHARDED[1:], dtype=np.int64)}
+    for rank, outs, _, _, _ in run_sharded_reference():
+        for ptype, y in outs.items():
+            out[f"y_{ptype.replace(':', '')}_{rank}"] = y
+    np.savez_compressed(os.path.join(HERE, f"{SHARDED[0]}.npz"), **out)
+    print("wrote", SHARDED[0], sorted(k for k in out if k != "meta"))
 
 
 if __name__ == "__main__":

@@ -542,6 +542,25 @@ def _sharded_worker(rank, world, port, q):
         if ok:
             d = float((outs["data"] - outs["model"]).abs().max())
             ok, info = d <= 2 ** -6 * float(outs["data"].abs().max()), f"data vs model: {d:.3e}"
+        if ok:
+            # fp32, the reference's own configuration: against the REFERENCE's output for this rank and mode (the reference run with
+            # two ranks over gloo, tests/golden/make_golden_ep.py; same seeds -> same sharded weights)
+            import numpy as np
+            ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sharded_w2_f32_k1.npz"))
+            Wf, Tf, Mf, Hf, kf = [int(v) for v in ref["meta"]]
+            for ptype in ("data", "model", "adaptive:0"):
+                layer = moe.moe_layer(gate_type={"type": "top", "k": kf}, model_dim=Mf,
+                                      experts={"type": "ffn", "num_experts_per_device": -world, "hidden_size_per_expert": Hf,
+                                               "activation_fn": lambda t: torch.nn.functional.relu(t)},
+                                      parallel_type=ptype, seeds=(1, rank + 1, 1)).cuda().eval()
+                torch.manual_seed(0)
+                xf = torch.randn(Tf, Mf)
+                with torch.no_grad():
+                    yf = layer(xf.cuda()).cpu()
+                yr = torch.from_numpy(ref[f"y_{ptype.replace(':', '')}_{rank}"])
+                if not torch.allclose(yf, yr, rtol=1e-5, atol=1e-5):
+                    ok, info = False, f"fp32 {ptype} vs the reference's own output: {float((yf - yr).abs().max()):.3e}"
+                    break
         q.put((rank, bool(ok), info, []))
         dist.destroy_process_group()
     except Exception:  # pragma: no cover

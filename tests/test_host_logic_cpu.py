@@ -402,7 +402,10 @@ def _sharded_worker(rank, world, port, q):
         ops.routing_dtype = lambda dt: True
         from tutel import system, net
         system.init_data_model_parallel(backend="gloo")
+        import numpy as np
         T, M, H, k = 128, 32, 16, 1
+        ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sharded_w2_f32_k1.npz"))   # the reference, 2 ranks over gloo
+        assert [int(v) for v in ref["meta"]] == [world, T, M, H, k]
         outs = {}
         for ptype in ("data", "model", "adaptive:0"):
             layer = _make_layer(M, H, -world, k, 1.0, parallel_type=ptype, seeds=(1, rank + 1, 1)).eval()
@@ -420,8 +423,11 @@ def _sharded_worker(rank, world, port, q):
             wg = layer.gates[0].wg.weight.data
             want, _, _, _ = O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)
             ok = torch.allclose(outs[ptype], want, rtol=1e-5, atol=1e-5)
+            # and the REFERENCE's own output for this rank and mode (same seeds -> same sharded weights, same tokens)
+            yr = torch.from_numpy(ref[f"y_{ptype.replace(':', '')}_{rank}"])
+            ok = ok and torch.allclose(outs[ptype], yr, rtol=1e-5, atol=1e-5)
             if not ok:
-                q.put((rank, False, f"{ptype}: max diff {(outs[ptype] - want).abs().max()}"))
+                q.put((rank, False, f"{ptype}: max diff vs oracle {(outs[ptype] - want).abs().max()}, vs reference {(outs[ptype] - yr).abs().max()}"))
                 return
         ok = torch.allclose(outs["data"], outs["model"], rtol=1e-5, atol=1e-6)
         q.put((rank, bool(ok), "data vs model"))
