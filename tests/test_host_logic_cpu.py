@@ -634,12 +634,12 @@ def _world2_cases():
     return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "helloworld_losses.json")))["world2_cases"]
 
 
-@pytest.mark.parametrize("case", _world2_cases(), ids=lambda c: c["flags"].split("--num_steps=6")[1].strip().replace(" ", ""))
+@pytest.mark.parametrize("case", _world2_cases(), ids=lambda c: c["flags"].split("--num_steps=")[1][2:].strip().replace(" ", ""))
 def test_helloworld_two_rank_training_losses_match_reference(case):
     """The reference's own helloworld TRAINING with two ranks over gloo (its CPU path, run in the build container; losses committed in
     tests/golden/helloworld_losses.json) replayed by this repo's driver on two gloo ranks: expert-parallel all-to-all forward AND
-    backward, gate-gradient all-reduce, sharded experts in data / model parallel mode -- printed losses equal at the reference
-    test's rounding (3 decimals)."""
+    backward, gate-gradient all-reduce, sharded experts in data / model parallel mode, and the helloworld_switch sweep (adaptive_r x
+    overlap degree per step, --eval) -- printed losses equal at the reference test's rounding (3 decimals)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
