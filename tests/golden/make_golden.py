@@ -325,6 +325,25 @@ def check_oracle_against_reference():
         gg = torch.empty([T])
         ck.invoke_cpu_fp32([gg, cr[1][j], cr[2][j], x, buf], [T, M, cr[4]], 2)
         expect(torch.equal(gg, O.gate_grad(x, buf, cr[1][j], cr[2][j], cr[4])), f"gate_grad j={j}")
+    # the dispatcher class with MASKED tokens (idx < 0: the documented way to drop tokens through fast_dispatcher.update,
+    # fast_dispatch.py:101-134; CPU kernel custom_kernel.cpp:293-312 skips them)
+    g = torch.Generator().manual_seed(13)
+    T, E, k, M = 300, 8, 2, 24
+    scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
+    cr, _ = ref_moe.top_k_routing(scores, k, capacity_factor=1.0)
+    idx = [i.clone() for i in cr[1]]
+    idx[0][::7] = -1
+    idx[1][::5] = -1
+    x = torch.randn([T, M], generator=g)
+    for post in (True, False):
+        d = ref_moe.fast_dispatcher(E, cr[4], M, torch.float32)
+        d.update(idx, cr[2], cr[3], capacity=cr[4], is_postscore=post)
+        enc_r = d.encode(x)
+        dec_r = d.decode(enc_r.view(E, -1, M))
+        crit_o = (E, idx, cr[2], cr[3], cr[4], cr[5])
+        enc_o = O.fast_encode(x, crit_o, post)
+        expect(torch.equal(enc_r.view(-1, M), enc_o.view(-1, M)), f"dispatcher encode with masked tokens post={post}")
+        expect(torch.equal(dec_r.view(-1, M), O.fast_decode(enc_o, crit_o, post).view(-1, M)), f"dispatcher decode with masked tokens post={post}")
     # host-side loss functions of the product (pure torch) against the reference's
     from tutel_amd.impls import losses as my_losses
     g = torch.Generator().manual_seed(77)
