@@ -361,12 +361,96 @@ def check_oracle_against_reference():
     return len(bad)
 
 
+def check_product_host_logic_against_reference():
+    """The drop-in surface itself, product vs live reference in ONE process: the product's layer (tutel_amd, kernels
+    replaced by the oracle through tests/_cpu_ops.py -- the oracle equals the reference's CPU kernels bit for bit, see above) and the
+    reference's layer, built from the same arguments: identical initial weights from the seeds, multiple gates + gate_index,
+    forward-time top_k / capacity_factor overrides, reserve_dims with a custom expert module, result_func, the deprecated
+    spellings -- outputs, l_aux and attributes must be EQUAL."""
+    bad = []
+
+    def expect(cond, what):
+        if not cond:
+            bad.append(what)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _cpu_ops
+    from tutel_amd import ops as my_ops
+    from tutel_amd.impls import moe_layer as my_ml
+    for name in ("gate_topk", "compute_location", "slot_map", "cumsum_sub_one", "fast_encode", "fast_decode", "gate_grad"):
+        setattr(my_ops, name, getattr(_cpu_ops, name))
+    relu = lambda t: torch.nn.functional.relu(t)
+
+    # (d) seeds -> identical parameters, no copying (ffn.py:39-49 RNG order, moe_layer.py:112-233 seeding)
+    kw = dict(gate_type=[{"type": "top", "k": 1}, {"type": "top", "k": 2, "capacity_factor": 1.5}],
+              experts={"type": "ffn", "num_experts_per_device": 4, "hidden_size_per_expert": 24, "activation_fn": relu},
+              model_dim=32, seeds=(5, 6, 7), is_postscore=False)
+    fresh = lambda d: {**d, "experts": dict(d["experts"]), "gate_type": [dict(g_) for g_ in d["gate_type"]] if isinstance(d["gate_type"], list) else (dict(d["gate_type"]) if isinstance(d["gate_type"], dict) else d["gate_type"])}   # (the reference pops keys out of the dicts it is given)
+    ref, mine = ref_moe.moe_layer(**fresh(kw)), my_ml.MOELayer(**fresh(kw))
+    rs, ms = ref.state_dict(), mine.state_dict()
+    expect(sorted(rs) == sorted(ms), f"state_dict keys {sorted(set(rs) ^ set(ms))}")
+    expect(all(torch.equal(rs[n], ms[n]) for n in rs if n in ms), "seeded initial parameters")
+    # (a) multiple gates, gate_index, forward-time overrides
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn([3, 50, 32], generator=g)
+    ref.eval(); mine.eval()
+    for kwargs in ({}, {"gate_index": 1}, {"gate_index": 1, "top_k": 1}, {"capacity_factor": 2.0}, {"gate_index": 1, "capacity_factor": 0.0},
+                   {"gate_index": 0, "capacity_factor": -0.5, "top_k": 3}):
+        with torch.no_grad():
+            yr, ym = ref(x, **kwargs), mine(x, **kwargs)
+        expect(torch.equal(yr, ym), f"forward{kwargs}: max diff {(yr - ym).abs().max():.3e}")
+        expect(float(yr.l_aux) == float(ym.l_aux), f"l_aux forward{kwargs}")
+        expect(torch.equal(ref.dispatch_count.to(torch.int32), mine.dispatch_count.to(torch.int32)), f"dispatch_count forward{kwargs}")
+    for attr in ("num_global_experts", "num_local_experts", "sharded_count", "world_size", "valid_rs", "adaptive_degree", "model_dim"):
+        expect(getattr(ref, attr) == getattr(mine, attr), f"attribute {attr}: {getattr(ref, attr)} vs {getattr(mine, attr)}")
+    expect([(g_.top_k, g_.gate_noise, g_.capacity_factor) for g_ in ref.gates] == [(g_.top_k, g_.gate_noise, g_.capacity_factor) for g_ in mine.gates], "gate attributes")
+
+    # (b) reserve_dims = 2 with a custom expert module, result_func, scan_expert_func
+    class Scale(torch.nn.Module):   # called as experts(x[E_loc, R, a, b], ctx) (moe_layer.py:250-253)
+        def __init__(self, model_dim, num_experts_per_device, sharded_count, **kw_):
+            super().__init__()
+            torch.manual_seed(3)
+            self.s = torch.nn.Parameter(torch.rand(num_experts_per_device, 1, 1, 1))
+
+        def forward(self, x, ctx):
+            assert x.dim() == 4
+            return x * self.s + 1.0
+    seen_r, seen_m = [], []
+    kw = dict(gate_type={"type": "top", "k": 2}, experts={"type": "custom", "module": Scale, "num_experts_per_device": 3}, model_dim=24,
+              seeds=(1, 2, 3), result_func=lambda t: t * 2)
+    ref = ref_moe.moe_layer(scan_expert_func=lambda n, p: seen_r.append(n), **fresh(kw)).eval()
+    mine = my_ml.MOELayer(scan_expert_func=lambda n, p: seen_m.append(n), **fresh(kw)).eval()
+    x = torch.randn([2, 30, 4, 6], generator=g)
+    with torch.no_grad():
+        yr, ym = ref(x, reserve_dims=2), mine(x, reserve_dims=2)
+    expect(yr.shape == ym.shape == x.shape and torch.equal(yr, ym), "reserve_dims = 2 + custom expert + result_func")
+    expect(seen_r == seen_m and all(hasattr(p, "_tutel_expert") for p in mine.experts.parameters()), "scan_expert_func / _tutel_expert tag")
+    expect(ref.protected_shape == mine.protected_shape, f"protected_shape {ref.protected_shape} vs {mine.protected_shape}")
+    # (c) deprecated spellings and error behaviour
+    for build in (ref_moe.moe_layer, my_ml.MOELayer):
+        lay = build(gate_type="Top2Gate", experts={"type": "ffn", "count_per_node": 2, "hidden_size_per_expert": 8, "activation_fn": relu},
+                    model_dim=8, pad_samples=True)
+        expect(lay.gates[0].top_k == 2 and lay.num_local_experts == 2, f"{build.__module__}: deprecated spellings")
+        for badkw, exc in ((dict(no_such_option=1), Exception), (dict(parallel_type="nonsense"), Exception)):
+            try:
+                build(gate_type={"type": "top", "k": 1}, experts={"type": "ffn", "num_experts_per_device": -1 if "parallel_type" in badkw else 1,
+                                                                   "hidden_size_per_expert": 8, "activation_fn": relu}, model_dim=8, **badkw)
+                expect("parallel_type" in badkw, f"{build.__module__}: {badkw} must raise")   # (sharded_count == 1: any parallel_type passes)
+            except exc:
+                pass
+    for b in bad:
+        print("MISMATCH:", b)
+    print("product-vs-reference host logic: %d mismatches" % len(bad))
+    return len(bad)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     if args.check:
-        sys.exit(1 if check_oracle_against_reference() else 0)
+        n = check_oracle_against_reference()
+        n += check_product_host_logic_against_reference()
+        sys.exit(1 if n else 0)
     for case in LAYER_CASES:
         name, out, _ = run_layer_case(case)
         np.savez_compressed(os.path.join(HERE, f"layer_{name}.npz"), **out)
