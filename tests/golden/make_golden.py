@@ -404,6 +404,21 @@ def check_product_host_logic_against_reference():
         expect(getattr(ref, attr) == getattr(mine, attr), f"attribute {attr}: {getattr(ref, attr)} vs {getattr(mine, attr)}")
     expect([(g_.top_k, g_.gate_noise, g_.capacity_factor) for g_ in ref.gates] == [(g_.top_k, g_.gate_noise, g_.capacity_factor) for g_ in mine.gates], "gate attributes")
 
+    # (a') training: forward + backward through dispatch / combine (data and gate gradients) and the experts, both layers
+    for post in (True, False):
+        kw_t = dict(gate_type={"type": "top", "k": 2}, experts={"type": "ffn", "num_experts_per_device": 4, "hidden_size_per_expert": 24, "activation_fn": relu},
+                    model_dim=32, seeds=(5, 6, 7), is_postscore=post)
+        ref_t, mine_t = ref_moe.moe_layer(**fresh(kw_t)).train(), my_ml.MOELayer(**fresh(kw_t)).train()
+        xt = torch.randn([100, 32], generator=g)
+        grads = []
+        for lay in (ref_t, mine_t):
+            xi = xt.clone().requires_grad_(True)
+            y = lay(xi)
+            (y.square().sum() + 3.0 * y.l_aux).backward()
+            grads.append([xi.grad] + [p.grad for _, p in sorted(lay.named_parameters()) if p.grad is not None])
+        # (the router's gradient comes out of differentiable torch forms of the same formulas on both sides, in another op order: fp32 rounding)
+        expect(len(grads[0]) == len(grads[1]) and all(torch.allclose(a, b, rtol=1e-5, atol=1e-5 * max(1.0, float(b.abs().max()))) for a, b in zip(*grads)),
+               f"training gradients is_postscore={post}: " + str([float((a - b).abs().max()) for a, b in zip(*grads)]))
     # (b) reserve_dims = 2 with a custom expert module, result_func, scan_expert_func
     class Scale(torch.nn.Module):   # called as experts(x[E_loc, R, a, b], ctx) (moe_layer.py:250-253)
         def __init__(self, model_dim, num_experts_per_device, sharded_count, **kw_):
