@@ -59,6 +59,27 @@ def test_argument_errors_are_reported_not_enqueued(L):
     assert L.tutel_amd_expert_gemm(None, 0, 0, 1, 0, None, 1, 0, 0, None, 0, None, 0, 0, 1, 0, 0, 0, 8, 64, 2, 0, None, 1, None) == 0
 
 
+def test_round3_entry_points_reject_bad_arguments(L):
+    from tutel_amd import _lib
+    # one-launch routing: bad dtype is an error; a shape the fused kernel does not take is ENOTSUP (nothing launched, no error text needed)
+    assert L.tutel_amd_route(None, 99, 64, 8, 2, 1, None, None, None, 0, None, None, None, None, 4, None, None, None) not in (0, _lib.ENOTSUP)
+    assert b"dtype" in L.tutel_amd_last_error()
+    assert L.tutel_amd_route(None, _lib.F32, 64, 256, 2, 1, None, None, None, 0, None, None, None, None, 4, None, None, None) == _lib.ENOTSUP
+    assert L.tutel_amd_route(None, _lib.F32, 64, 8, 2, 1, None, None, None, 0, None, None, None, None, 4, None, None, None) not in (0, _lib.ENOTSUP)  # null pointers
+    # variable-size collectives need a communicator
+    u64 = (ctypes.c_uint64 * 2)(8, 8)
+    assert L.tutel_amd_ep_all_to_all_v(None, None, None, u64, u64, None) != 0 and b"communicator" in L.tutel_amd_last_error()
+    assert L.tutel_amd_ep_all_gather_v(None, None, None, u64, None) != 0 and b"communicator" in L.tutel_amd_last_error()
+    assert L.tutel_amd_ep_comm_set_hosted_v(None, None) != 0
+    # limits named in the error text (INTEGRATION.md "Limits")
+    assert L.tutel_amd_gate_topk(None, 0, 0, 4, 4097, 1, 1, None, None, None, None, 0, None, 0, None) != 0 and b"4096" in L.tutel_amd_last_error()
+    assert L.tutel_amd_gate_topk(None, 0, 0, 4, 4096, 3, 1, None, None, None, None, 0, None, 0, None) != 0 and b"8192" in L.tutel_amd_last_error()
+    # options: the round-3 keys exist, unknown keys are refused
+    for key in (_lib.OPT_DECODE, _lib.OPT_ROUTING, _lib.OPT_GEMM_PERSIST, _lib.OPT_EP_STREAMS):
+        assert L.tutel_amd_set_option(key, -1) == 0
+    assert L.tutel_amd_set_option(99, 0) != 0
+
+
 def test_product_has_no_cpu_path():
     import torch
     from tutel_amd import _lib, ops
