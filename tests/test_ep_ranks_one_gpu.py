@@ -75,11 +75,15 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
         if native:
             assert len(fast_calls) == 3 and any(ep_native._comms.values()), "the native one-call pipeline must be the path taken"
             plans = [ep_native.plan(E, world, int(layer.protected_shape[1]) // world, degree)["sliced"] == 1] if degree > 1 else []
-        want, crits = O.moe_forward_ep(xs, wg, [w1[r * E_loc:(r + 1) * E_loc] for r in range(world)],
-                                       [b1[r * E_loc:(r + 1) * E_loc] for r in range(world)],
-                                       [w2[r * E_loc:(r + 1) * E_loc] for r in range(world)],
-                                       [b2[r * E_loc:(r + 1) * E_loc] for r in range(world)],
-                                       top_k=k, fp32_gate=True, alignment=degree, accum_fp32=True)
+        box = [None]   # rank 0 computes the expectation for every rank (the same CPU GEMMs would otherwise run W times side by side)
+        if rank == 0:
+            box[0] = O.moe_forward_ep(xs, wg, [w1[r * E_loc:(r + 1) * E_loc] for r in range(world)],
+                                      [b1[r * E_loc:(r + 1) * E_loc] for r in range(world)],
+                                      [w2[r * E_loc:(r + 1) * E_loc] for r in range(world)],
+                                      [b2[r * E_loc:(r + 1) * E_loc] for r in range(world)],
+                                      top_k=k, fp32_gate=True, alignment=degree, accum_fp32=True)
+        dist.broadcast_object_list(box, src=0)
+        want, crits = box[0]
         err = (y.cpu().double() - want[rank].double()).abs()
         # bf16 bar (tests/test_layer_gpu.py header): 2 ulps of the element + an absolute term.  The absolute
         # term covers 1-ulp flips of the bf16 EXPERT outputs (fp32 sums in another order round differently for
@@ -191,8 +195,14 @@ def _sweep_worker(rank, world, port, cfg, q):
             else:
                 assert gemm_calls, f"(r={r_ad}, degree={degree}): the MFMA grouped GEMM must run"
             if degree not in wants:   # the overlap degree enters the capacity alignment (moe_layer.py:298-301)
-                wants[degree] = O.moe_forward_ep(xs, wg, parts(w1), parts(b1), parts(w2), parts(b2), top_k=k, fp32_gate=True,
-                                                 alignment=degree, accum_fp32=True, inequivalent_tokens=uneq)
+                # rank 0 computes the expectation for every rank and hands it out (the ranks would otherwise compute the same
+                # CPU GEMMs side by side on the same host cores)
+                box = [None]
+                if rank == 0:
+                    box[0] = O.moe_forward_ep(xs, wg, parts(w1), parts(b1), parts(w2), parts(b2), top_k=k, fp32_gate=True,
+                                              alignment=degree, accum_fp32=True, inequivalent_tokens=uneq)
+                dist.broadcast_object_list(box, src=0)
+                wants[degree] = box[0]
             want, crits = wants[degree]
             cap = crits[rank][4]   # (layer.protected_shape is the shape of the LAST expert call -- a chunk on the generic overlap path, as in the reference)
             assert torch.equal(layer.dispatch_count.cpu(), crits[rank][5]), "token -> expert assignment"
