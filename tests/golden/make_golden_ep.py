@@ -81,6 +81,109 @@ def run_sharded_reference():
     return res
 
 
+def _net_worker(rank, world, port, q):
+    """tutel.net of the REFERENCE and of this repo (tutel_amd.net) side by side in one process per rank, gloo: the collectives with
+    and without autograd, same inputs -> equal outputs and equal gradients.  Calls the reference cannot run on a gloo group are
+    listed, not compared."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        sys.path = [REF, os.path.join(ROOT, "oracle", "_ref")] + [p for p in sys.path if os.path.abspath(p or ".") != ROOT] + [ROOT]
+        import logging
+        import torch
+        import torch.distributed as dist
+        logging.disable(logging.CRITICAL)
+        import tutel
+        assert os.path.abspath(tutel.__file__).startswith(REF), tutel.__file__
+        from tutel import net as rnet
+        from tutel_amd import net as mnet
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        g = torch.Generator().manual_seed(40 + rank)
+        bad, skipped = [], []
+
+        def both(name, fn, *tensors, grad=False):
+            outs = []
+            for net in (rnet, mnet):
+                ins = [t.clone().requires_grad_(grad) for t in tensors]
+                try:
+                    y = fn(net, *ins)
+                except Exception as ex:   # noqa: BLE001
+                    if net is rnet:
+                        skipped.append(f"{name}: reference raises on gloo ({type(ex).__name__})")
+                        return
+                    bad.append(f"{name}: product raises {type(ex).__name__}: {ex}")
+                    return
+                ys = list(y) if isinstance(y, (tuple, list)) else [y]
+                ys = [t for t in ys if torch.is_tensor(t)]
+                gr = []
+                if grad:
+                    sum((t.float() * torch.arange(t.numel(), dtype=torch.float32).view(t.shape)).sum() for t in ys).backward()
+                    gr = [i.grad for i in ins]
+                outs.append((ys, gr))
+            (yr, gr_), (ym, gm) = outs
+            if len(yr) != len(ym) or not all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(yr, ym)):
+                bad.append(f"{name}: outputs differ")
+            if grad and not all((a is None and b is None) or (a is not None and b is not None and torch.allclose(a, b)) for a, b in zip(gr_, gm)):
+                bad.append(f"{name}: gradients differ")
+        x = torch.randn([4 * world, 6, 8], generator=g)
+        both("simple_all_reduce", lambda n, t: n.simple_all_reduce(t), x)
+        both("simple_all_to_all", lambda n, t: n.simple_all_to_all(t), x)
+        both("simple_split", lambda n, t: n.simple_split(t), x)
+        both("simple_all_gather", lambda n, t: n.simple_all_gather(t), x)
+        both("simple_reduce_scatter", lambda n, t: n.simple_reduce_scatter(t), x)
+        for i, o in ((0, 1), (1, 0), (0, 2), (2, 0), (1, 2), (0, 0)):
+            xx = torch.randn([2 * world, 3 * world, 4 * world], generator=g)
+            both(f"all_to_all({i},{o})", lambda n, t, i=i, o=o: n.all_to_all(t, i, o), xx, grad=True)
+            both(f"all_to_all({i},{o},use_2dh)", lambda n, t, i=i, o=o: n.all_to_all(t, i, o, use_2dh=True), xx, grad=True)
+        both("all_to_all_single", lambda n, t: n.all_to_all_single(t), x, grad=True)
+        for d in (0, 1, 2):
+            both(f"all_gather(dim={d})", lambda n, t, d=d: n.all_gather(t, d), x, grad=True)
+            both(f"reduce_scatter(dim={d})", lambda n, t, d=d: n.reduce_scatter(t, d), torch.randn([2 * world, 2 * world, 2 * world], generator=g), grad=True)
+            both(f"spatial_split(dim={d})", lambda n, t, d=d: n.spatial_split(t, d), torch.randn([2 * world, 2 * world, 2 * world], generator=g), grad=True)
+        both("allreduce_forward", lambda n, t: n.allreduce_forward(t), x, grad=True)
+        both("allreduce_backward", lambda n, t: n.allreduce_backward(t), x, grad=True)
+        both("zero_gather", lambda n, t: n.zero_gather(t), torch.randn([5, 3], generator=g), grad=True)
+        both("zero_scatter", lambda n, t: n.zero_scatter(t, n.simple_split)[0], torch.randn([7, 3], generator=g))
+        # group construction: same partitions
+        for gc in (1, 2, -2):
+            try:
+                a, b = rnet.create_groups_from_world(group_count=gc), mnet.create_groups_from_world(group_count=gc)
+                for attr in ("global_size", "global_rank", "group_count", "data_rank", "model_rank", "is_distributed"):
+                    if getattr(a, attr, None) != getattr(b, attr, None):
+                        bad.append(f"create_groups_from_world({gc}).{attr}: {getattr(a, attr, None)} vs {getattr(b, attr, None)}")
+            except Exception as ex:   # noqa: BLE001
+                skipped.append(f"create_groups_from_world({gc}): {type(ex).__name__}")
+        q.put((rank, bad, skipped, True, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, [traceback.format_exc()], [], True, None))
+
+
+def check_net_against_reference():
+    import torch.multiprocessing as mp
+    W = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_net_worker, args=(r, W, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    n = 0
+    for rank, bad, skipped, _, _ in sorted(res):
+        for b in bad:
+            print(f"MISMATCH (rank {rank}):", b)
+            n += 1
+        if rank == 0:
+            for s_ in skipped:
+                print("not compared:", s_)
+    print("tutel.net, product vs reference over gloo: %d mismatches" % n)
+    return n
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -196,6 +299,7 @@ def main():
         print("wrote", case[0], [tuple(r[1].shape) for r in res], [tuple(r[2].shape) for r in res])
     if args.check:
         print("oracle-vs-reference (expert parallel, W > 1): %d mismatches" % bad)
+        bad += check_net_against_reference()
         sys.exit(1 if bad else 0)
     out = {"meta": np.array(SHARDED[1:], dtype=np.int64)}
     for rank, outs, _, _, _ in run_sharded_reference():
