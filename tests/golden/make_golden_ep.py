@@ -143,6 +143,20 @@ def _net_worker(rank, world, port, q):
         both("allreduce_backward", lambda n, t: n.allreduce_backward(t), x, grad=True)
         both("zero_gather", lambda n, t: n.zero_gather(t), torch.randn([5, 3], generator=g), grad=True)
         both("zero_scatter", lambda n, t: n.zero_scatter(t, n.simple_split)[0], torch.randn([7, 3], generator=g))
+        # TutelDistributedOptimizer (tutel/net.py:15-60): three SGD steps on a shared parameter of awkward size + an "expert" one
+        finals = []
+        for net in (rnet, mnet):
+            torch.manual_seed(11)
+            shared, expert = torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(4, 2) + rank)
+            expert._tutel_expert = True
+            opt = net.TutelDistributedOptimizer([shared, expert], average_shared=True).warp_local(torch.optim.SGD, lr=0.1, momentum=0.5)
+            for step in range(3):
+                opt.zero_grad()
+                ((shared * (rank + 1 + step)).sum() ** 2 + (expert ** 2).sum()).backward()
+                opt.step()
+            finals.append((shared.data.clone(), expert.data.clone()))
+        if not all(torch.equal(a, b) for a, b in zip(*finals)):
+            bad.append("TutelDistributedOptimizer: parameters after 3 steps differ")
         # group construction: same partitions
         for gc in (1, 2, -2):
             try:
