@@ -243,6 +243,45 @@ typedef int (*tutel_amd_exchange_fn)(void *user, const void *send, void *recv, s
 int tutel_amd_ep_comm_create_hosted(int world, int rank, tutel_amd_exchange_fn fn, void *user, tutel_amd_ep_comm_t **out);
 int tutel_amd_ep_comm_info(const tutel_amd_ep_comm_t *comm, int *world, int *rank);
 
+/* ---- IPC transport: the exchange as peer stores over xGMI, no collective on the hot path ----------------------------------
+ * Replaces the exchange kernels of the reference's asynchronous all-to-all (custom_kernel.cpp:520-654: one ncclSend / ncclRecv
+ * pair per peer and chunk inside ncclGroupStart / End, :559-579, :627-648) and its event hand-offs (:553, :648).  The GPUs of a
+ * node address each other's HBM (hipIpc*), so the kernels that PRODUCE the exchanged rows store them where the all-to-all would
+ * have put them: fast_encode into the receive array of the rank that owns the expert, the second expert GEMM into the return
+ * array of the rank the row came from.  One 32-bit flag per (direction, stage, peer), written by a one-workgroup kernel after
+ * the producer and polled by a one-workgroup kernel before the consumer, is the only synchronisation; epochs are counted in
+ * device memory, so a captured forward replays from a HIP graph.  Works between processes that share ONE device as well
+ * (how the tests run it with 2 and 4 ranks on a 1-GPU box).
+ *
+ * A segment is device memory of this rank that every peer maps: allocate, all-gather the TUTEL_AMD_IPC_HANDLE_BYTES-byte
+ * handles with the host's process group (like the RCCL id), open.  flag_memory != 0: uncached / fine-grained memory for the
+ * communicator's flag words (tutel_amd_ep_flag_bytes() of them, zeroed).  tutel_amd_ep_segment_ptr: base of `peer`'s segment in
+ * this process (peer < 0: the local base). */
+typedef struct tutel_amd_ep_segment tutel_amd_ep_segment_t;
+#define TUTEL_AMD_IPC_HANDLE_BYTES 64
+int tutel_amd_ep_segment_alloc(size_t bytes, int flag_memory, tutel_amd_ep_segment_t **out, void *handle_out, size_t handle_bytes);
+int tutel_amd_ep_segment_open(tutel_amd_ep_segment_t *seg, int world, int rank, const void *handles, size_t handle_bytes);
+void *tutel_amd_ep_segment_ptr(const tutel_amd_ep_segment_t *seg, int peer);
+/* bytes [off, off + bytes) of the local segment -> dst (device memory), enqueued on `stream` */
+int tutel_amd_ep_segment_read(const tutel_amd_ep_segment_t *seg, size_t off, void *dst, size_t bytes, tutel_stream_t stream);
+int tutel_amd_ep_segment_free(tutel_amd_ep_segment_t *seg);
+size_t tutel_amd_ep_flag_bytes(void);
+/* a communicator whose only exchange is the IPC transport (no RCCL, no callback): at most 16 ranks of one node */
+int tutel_amd_ep_comm_create_ipc(int world, int rank, tutel_amd_ep_comm_t **out);
+/* gives any communicator (RCCL-backed, hosted or IPC-only) the IPC transport: `flags` = an opened flag segment of this
+ * communicator's ranks, owned by the caller and kept alive as long as the communicator; timeout_ms bounds every wait for a
+ * peer (<= 0: 20 s) -- a wait that times out records which peer and stage never arrived, the forward's output is then
+ * garbage and the NEXT call on the communicator fails with that text (tutel_amd_ep_ipc_status reads it without a call). */
+int tutel_amd_ep_comm_attach_ipc(tutel_amd_ep_comm_t *comm, tutel_amd_ep_segment_t *flags, int timeout_ms);
+int tutel_amd_ep_comm_has_ipc(const tutel_amd_ep_comm_t *comm);
+int tutel_amd_ep_ipc_status(tutel_amd_ep_comm_t *comm);
+/* all_to_all_single with equal splits over the IPC transport: block r of `send` (any device buffer, bytes_per_peer bytes,
+ * multiple of 16) lands at byte offset recv_off + <my rank> * bytes_per_peer of rank r's `seg`; when the call's work on
+ * `stream` completes, this rank's world blocks have arrived.  Two exchanges into the same offset must be kept apart by the
+ * caller (there are no credits). */
+int tutel_amd_ep_ipc_exchange(tutel_amd_ep_comm_t *comm, tutel_amd_ep_segment_t *seg, const void *send, size_t bytes_per_peer,
+                              size_t recv_off, tutel_stream_t stream);
+
 /* all_to_all_single with equal splits (simple_all_to_all, communicate.py:181-192): block r of `send`
  * (bytes_per_peer bytes) goes to rank r and lands as block <my rank> of its `recv`; enqueued on `stream`. */
 int tutel_amd_ep_all_to_all(tutel_amd_ep_comm_t *comm, const void *send, void *recv, size_t bytes_per_peer,
@@ -314,6 +353,10 @@ typedef struct {
   const int32_t *row_counts;     /* dropless / megablocks (moe_layer.py:278-280: single rank only): per-expert row counts, */
   int row_align;                 /*   rows >= ceil(count/row_align)*row_align are skipped by both GEMMs; NULL / 1 = all rows */
   void *y;                       /* out: [T, M_out] */
+  /* IPC transport (see tutel_amd_ep_segment_alloc): the opened segment that holds `recv` and `back` at the same offsets on
+   * every rank.  Then fast_encode stores into the peers' `recv`, the second GEMM into the peers' `back`, `enc` / `send` are
+   * not touched and no collective is enqueued.  NULL: the exchange is the communicator's (RCCL / host callback / copy). */
+  const struct tutel_amd_ep_segment *peer_seg;
 } tutel_amd_ep_args_t;
 int tutel_amd_ep_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_ep_args_t *args, tutel_stream_t stream);
 

@@ -21,6 +21,14 @@ def _free_port():
     return p
 
 
+def _set_transport(ep_native, native):
+    """native: False = Python-orchestrated paths; True / "hosted" = the native one-call pipeline with its exchange done by a host
+    callback over gloo; "ipc" = the native pipeline over the IPC transport (peer stores between the rank processes, which all
+    map cuda:0 -- the device-side protocol a multi-GPU node runs, tests/test_ep_ipc_one_gpu.py)"""
+    ep_native.HOSTED = native is True or native == "hosted"
+    ep_native.TRANSPORT = "ipc" if native == "ipc" else "rccl"
+
+
 def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
@@ -32,7 +40,7 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
         from tutel_amd.impls import overlap as OV, ep_native
         # native=True: the ONE-call native pipeline (tutel_amd_moe_forward / tutel_amd_ep_forward: stage layouts, buffers, both
         # streams, events in C) with its exchange done by a host callback over gloo; native=False: the Python-orchestrated paths
-        ep_native.HOSTED = bool(native)
+        _set_transport(ep_native, native)
         fast_calls = []
         real_fast = ep_native.forward_from_logits
         ep_native.forward_from_logits = lambda *a, **kw: fast_calls.append(1) or real_fast(*a, **kw)
@@ -72,8 +80,21 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
                 for _ in range(2):   # cached workspace, events re-recorded: repeated calls must agree bit for bit
                     assert torch.equal(layer(xs[rank].cuda()), y)
         torch.cuda.synchronize()
+        if native == "ipc":
+            comm = ep_native.communicator(layer.group, torch.device("cuda", 0))
+            assert comm is not None and comm.ipc and not comm.generic, "the IPC transport must be the exchange"
+            assert all(w.segment is not None and "enc" not in w.bufs and "send" not in w.bufs for w in layer._ep_workspaces.values())
+            # the same forward through the host-staged exchange (another communicator over the same group): bit for bit
+            ep_native._comms.clear()
+            layer.__dict__.pop("_ep_workspaces")
+            _set_transport(ep_native, "hosted")
+            with torch.no_grad():
+                y_hosted = layer(xs[rank].cuda())
+            torch.cuda.synchronize()
+            assert torch.equal(y_hosted, y), "IPC transport and hosted exchange must agree bit for bit"
+            _set_transport(ep_native, "ipc")
         if native:
-            assert len(fast_calls) == 3 and any(ep_native._comms.values()), "the native one-call pipeline must be the path taken"
+            assert len(fast_calls) == (4 if native == "ipc" else 3) and any(ep_native._comms.values()), "the native one-call pipeline must be the path taken"
             plans = [ep_native.plan(E, world, int(layer.protected_shape[1]) // world, degree)["sliced"] == 1] if degree > 1 else []
         box = [None]   # rank 0 computes the expectation for every rank (the same CPU GEMMs would otherwise run W times side by side)
         if rank == 0:
@@ -153,7 +174,7 @@ def _sweep_worker(rank, world, port, cfg, q):
         from tutel import moe
         from tutel_amd import ops
         from tutel_amd.impls import ep_native
-        ep_native.HOSTED = True
+        _set_transport(ep_native, cfg.get("transport", "hosted"))
         native_calls, gemm_calls = [], []
         for name in ("forward_from_logits", "forward"):
             real = getattr(ep_native, name)
@@ -357,7 +378,7 @@ def _fixture_worker(rank, world, port, path, native, q):
         from oracle import moe_oracle as O
         from tutel import moe
         from tutel_amd.impls import ep_native
-        ep_native.HOSTED = bool(native)
+        _set_transport(ep_native, native)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         torch.cuda.set_device(0)
         z = np.load(path)

@@ -55,7 +55,7 @@ class EpArgs(ctypes.Structure):
                                    "dtype", "gate_dtype", "act", "is_postscore", "w2_kmajor", "fuse_encode")] +
                 [(n, _vp) for n in ("x", "slot_map", "idx", "loc", "gates", "w1", "b1", "w2", "b2",
                                     "enc", "recv", "hid", "send", "back", "zero_row", "row_counts")] +
-                [("row_align", _i), ("y", _vp)])
+                [("row_align", _i), ("y", _vp), ("peer_seg", _vp)])
 
 
 class MoeArgs(ctypes.Structure):
@@ -80,6 +80,17 @@ SIGNATURES.update({
     "tutel_amd_ep_all_gather_v": (_i, [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint64), _vp]),
     "tutel_amd_ep_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(EpPlan)]),
     "tutel_amd_ep_forward": (_i, [_vp, ctypes.POINTER(EpArgs), _vp]),
+    "tutel_amd_ep_segment_alloc": (_i, [_sz, _i, ctypes.POINTER(_vp), _vp, _sz]),
+    "tutel_amd_ep_segment_open": (_i, [_vp, _i, _i, _vp, _sz]),
+    "tutel_amd_ep_segment_ptr": (_vp, [_vp, _i]),
+    "tutel_amd_ep_segment_read": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "tutel_amd_ep_segment_free": (_i, [_vp]),
+    "tutel_amd_ep_flag_bytes": (_sz, []),
+    "tutel_amd_ep_comm_create_ipc": (_i, [_i, _i, ctypes.POINTER(_vp)]),
+    "tutel_amd_ep_comm_attach_ipc": (_i, [_vp, _vp, _i]),
+    "tutel_amd_ep_comm_has_ipc": (_i, [_vp]),
+    "tutel_amd_ep_ipc_status": (_i, [_vp]),
+    "tutel_amd_ep_ipc_exchange": (_i, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "tutel_amd_mark": (_i, [_vp]),
     "tutel_amd_marks_reserve": (_i, [_i]),
     "tutel_amd_marks_report": (_i, [ctypes.POINTER(ctypes.c_double), _i]),
@@ -92,6 +103,7 @@ EXCHANGE_FN = ctypes.CFUNCTYPE(_i, _vp, _vp, _vp, _sz, _i)
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 EXCHANGE_V_FN = ctypes.CFUNCTYPE(_i, _vp, _vp, _vp, _u64p, _u64p, _u64p, _i)
 EP_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 EAGAIN, ENOTSUP = 1000, 1001
 STAGES = ("gate_topk", "location", "fast_encode", "expert_fc1", "expert_fc2", "fast_decode", "all_to_all_dispatch", "all_to_all_combine", "other")
 

@@ -31,6 +31,24 @@ struct StageScope {
   }
 };
 
+// ---- internal entry points shared between translation units (not part of the C ABI) -----------------------------------
+// peer stores of the IPC transport (ep.hip): tab[w] = base address, in this process, of rank w's exchange segment
+struct EncodePeer {
+  const uint64_t *tab;  // device array of `world` segment bases (nullptr: plain local output)
+  long long off;        // byte offset of the receive array inside every rank's segment
+  int rank, rows;       // my rank; bucket rows per (stage, destination rank) block
+  int slot0;            // first bucket row of this launch (stages are encoded by separate launches)
+};
+int tutel_encode_launch(const void *x, int dtype, const int32_t *slot_map, const void *gates, int gate_dtype, int T, int M,
+                        int n_slots, int capacity, int num_experts, int chunk_rows, int expert_slice, int ep_world, void *out,
+                        const EncodePeer &peer, hipStream_t st);
+// tutel_amd_expert_gemm with the output rows of source rank w written to d_peer[w] + d_peer_off (bytes) instead of
+// D + w * d_stride_w: the second expert GEMM stores straight into the return buffers of the ranks the rows came from
+int tutel_expert_gemm_peer(const void *A, int64_t a_stride_e, int64_t a_stride_w, int a_rows_per_w, int lda, const void *W,
+                           int w_kmajor, int64_t w_stride_e, int ldw, const void *bias, int64_t bias_stride_e,
+                           const uint64_t *d_peer, int64_t d_peer_off, int64_t d_stride_e, int d_rows_per_w, int ldd, int E_loc,
+                           int R, int N, int K, int dtype, int act, hipStream_t st);
+
 #define TUTEL_REQUIRE(cond, ...)           \
   do {                                     \
     if (!(cond)) {                         \

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
                                                            int gate_dtype, int Tn, int M,
                                                            int n_slots, int capacity, int num_experts,
                                                            int chunk_rows, int expert_slice, int ep_world,
-                                                           T *__restrict__ out) {
+                                                           T *__restrict__ out, EncodePeer peer) {
   constexpr int VN = Vec<T>::N;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
   const int nvec = M / VN;  // full 16-byte vectors per row (rows are 16B aligned when M % VN == 0)
   const bool vec_ok = (M % VN) == 0;
 
-  for (int slot = wave; slot < n_slots; slot += nwaves) {
+  for (int slot = peer.slot0 + wave; slot < n_slots; slot += nwaves) {
     // output row `slot` in the requested bucket order -> row e*C + l of the plain slot map (the inverse of
     // the decode kernel's addressing: chunk-major [C/c][E][c] or expert-sliced [E_loc/s][W][s][C])
     int plain = slot;
@@ -58,6 +58,13 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
     int q = slot_map[plain];  // wave-uniform
     q = __builtin_amdgcn_readfirstlane(q);
     T *dst = out + (size_t)slot * M;
+    if (peer.tab != nullptr) {
+      // peer stores (csrc/ep.hip, IPC transport): bucket row `slot` of the exchange layout [stage][dst rank][rows] is written
+      // straight into the receive buffer of the rank that owns the expert, where an all-to-all would have delivered it:
+      // block <my rank> of its [stage][src rank][rows] array.  peer.tab[w] = base of rank w's segment in THIS process.
+      const int blk = slot / peer.rows, rem = slot % peer.rows, st = blk / ep_world, w = blk % ep_world;
+      dst = reinterpret_cast<T *>(peer.tab[w] + peer.off) + ((size_t)(st * ep_world + peer.rank) * peer.rows + rem) * M;
+    }
     if (q < 0) {
       if (vec_ok) {
         vec16 z = {{0u, 0u, 0u, 0u}};
@@ -284,36 +291,49 @@ static inline int dp_grid(int rows) {
   return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
 
-extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *slot_map,
-                                     const void *gates, int gate_dtype, int T, int M, int n_slots,
-                                     int capacity, int num_experts, int chunk_rows, int expert_slice,
-                                     int ep_world, void *out, tutel_stream_t stream) {
+// internal (csrc/ep.hip): fast_encode with optional peer stores and a slot range [slot0, n_slots)
+int tutel_encode_launch(const void *x, int dtype, const int32_t *slot_map, const void *gates, int gate_dtype, int T, int M,
+                        int n_slots, int capacity, int num_experts, int chunk_rows, int expert_slice, int ep_world, void *out,
+                        const EncodePeer &peer, hipStream_t st) {
   TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_fast_encode: unsupported dtype %d", dtype);
   TUTEL_REQUIRE(chunk_rows >= 0 && expert_slice >= 0 && !(chunk_rows > 0 && expert_slice > 0), "tutel_amd_fast_encode: bad bucket order");
   if (chunk_rows > 0 || expert_slice > 0) {
-    TUTEL_REQUIRE(num_experts >= 1 && capacity >= 1 && (long long)num_experts * capacity == n_slots,
-                  "tutel_amd_fast_encode: a bucket order needs n_slots == num_experts * capacity (got %d, %d x %d)", n_slots, num_experts, capacity);
+    TUTEL_REQUIRE(num_experts >= 1 && capacity >= 1 && (long long)num_experts * capacity >= n_slots,
+                  "tutel_amd_fast_encode: a bucket order needs n_slots <= num_experts * capacity (got %d, %d x %d)", n_slots, num_experts, capacity);
     TUTEL_REQUIRE(chunk_rows == 0 || capacity % chunk_rows == 0, "tutel_amd_fast_encode: chunk_rows=%d must divide capacity=%d", chunk_rows, capacity);
     TUTEL_REQUIRE(expert_slice == 0 || (ep_world >= 1 && num_experts % ep_world == 0 && (num_experts / ep_world) % expert_slice == 0),
                   "tutel_amd_fast_encode: expert_slice=%d must divide the local experts of each of %d ranks", expert_slice, ep_world);
   }
   TUTEL_REQUIRE(gates == nullptr || dtype_ok(gate_dtype), "tutel_amd_fast_encode: unsupported gate dtype %d", gate_dtype);
-  TUTEL_REQUIRE(T >= 0 && M >= 1 && n_slots >= 0, "tutel_amd_fast_encode: bad sizes T=%d M=%d n_slots=%d", T, M, n_slots);
-  if (n_slots == 0) return 0;
-  TUTEL_REQUIRE(slot_map && out && (x || T == 0), "tutel_amd_fast_encode: null pointer");
-  TUTEL_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_amd_fast_encode: x/out must be 16-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
+  TUTEL_REQUIRE(T >= 0 && M >= 1 && n_slots >= 0 && peer.slot0 >= 0, "tutel_amd_fast_encode: bad sizes T=%d M=%d n_slots=%d", T, M, n_slots);
+  TUTEL_REQUIRE(peer.tab == nullptr || (peer.rows >= 1 && ep_world >= 1 && peer.rank >= 0 && peer.rank < ep_world),
+                "tutel_amd_fast_encode: bad peer-store arguments");
+  if (n_slots - peer.slot0 <= 0) return 0;
+  TUTEL_REQUIRE(slot_map && (out || peer.tab) && (x || T == 0), "tutel_amd_fast_encode: null pointer");
+  TUTEL_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && (peer.off % 16) == 0, "tutel_amd_fast_encode: x/out must be 16-byte aligned");
   StageScope stage(TUTEL_STAGE_ENCODE, st);
-  int grid = dp_grid(n_slots);
+  int grid = dp_grid(n_slots - peer.slot0);
   int Tn = T > 0 ? T : 1;
   if (dtype == TUTEL_F32)
-    hipLaunchKernelGGL(encode_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (float *)out);
+    hipLaunchKernelGGL(encode_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (float *)out, peer);
   else if (dtype == TUTEL_BF16)
-    hipLaunchKernelGGL(encode_kernel<bf16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const bf16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (bf16_t *)out);
+    hipLaunchKernelGGL(encode_kernel<bf16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const bf16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (bf16_t *)out, peer);
   else
-    hipLaunchKernelGGL(encode_kernel<f16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const f16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (f16_t *)out);
+    hipLaunchKernelGGL(encode_kernel<f16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const f16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (f16_t *)out, peer);
   TUTEL_CHECK_LAUNCH("tutel_amd_fast_encode");
   return 0;
+}
+
+extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *slot_map,
+                                     const void *gates, int gate_dtype, int T, int M, int n_slots,
+                                     int capacity, int num_experts, int chunk_rows, int expert_slice,
+                                     int ep_world, void *out, tutel_stream_t stream) {
+  if (chunk_rows > 0 || expert_slice > 0)
+    TUTEL_REQUIRE((long long)num_experts * capacity == n_slots,
+                  "tutel_amd_fast_encode: a bucket order needs n_slots == num_experts * capacity (got %d, %d x %d)", n_slots, num_experts, capacity);
+  EncodePeer none = {nullptr, 0, 0, 1, 0};
+  return tutel_encode_launch(x, dtype, slot_map, gates, gate_dtype, T, M, n_slots, capacity, num_experts, chunk_rows, expert_slice,
+                             ep_world, out, none, (hipStream_t)stream);
 }
 
 template <typename T, int SPLIT, bool NTS>

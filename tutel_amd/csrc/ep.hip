@@ -20,9 +20,19 @@
 //   * degree 1 is the same plan with one stage, issued on the caller's stream alone;
 //   * world size 1 without a communicator: the exchange is the identity (stage buffers alias), and
 //     with is_postscore the first GEMM gathers its rows from the tokens (fused fast_encode).
+//   * round 4 -- the MI355X-native exchange: xGMI is load / store addressable between the GPUs of a node, so with the IPC
+//     transport (tutel_amd_ep_segment_* + tutel_amd_ep_comm_attach_ipc) there is NO collective on the hot path at all:
+//     fast_encode writes every bucket row straight into the receive buffer of the rank that owns the expert, the second
+//     expert GEMM's epilogue writes every output row straight into the return buffer of the rank the row came from, and
+//     one flag word per (direction, stage, peer) -- written by a one-workgroup kernel after the producing kernel, polled
+//     by a one-workgroup kernel before the consuming one -- replaces the four ncclAllToAll enqueues (4 x ~30 us of host
+//     time), their copy kernels (which hold CUs beside the stage GEMMs) and the send / back staging arrays.  Plain kernel
+//     launches and events only: HIP-graph replay safe (the epoch counters live in device memory).
 // Every step is one of the C-ABI entry points of this library; this file adds orchestration only.
 #include <dlfcn.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include <rccl/rccl.h>
 
@@ -97,6 +107,7 @@ struct Range {
 
 // ---- communicator: RCCL comm + the communication stream + the event table -------------------------------
 #define EP_MAX_SPLIT 32  // AllToAllStatus.max_num_split of the reference (custom_kernel.cpp:328)
+struct tutel_amd_ep_segment;
 struct tutel_amd_ep_comm {
   ncclComm_t comm;
   int world, rank, device;
@@ -115,6 +126,23 @@ struct tutel_amd_ep_comm {
   hipStream_t side_stream_low;  // lowest priority
   hipStream_t side_stream_mid;  // normal priority (used only when the caller's stream is one of the other two)
   hipEvent_t recv_ev[EP_MAX_SPLIT], done_ev[EP_MAX_SPLIT];
+
+  // IPC transport (tutel_amd_ep_comm_attach_ipc): flag words in every rank's flag segment, epoch counters, error word
+  tutel_amd_ep_segment *flag_seg;  // [2 directions][EP_FLAG_SLOTS][EP_MAX_PEERS] uint32 per rank, peer-mapped
+  uint32_t *epochs;                // device: signalled[2][EP_FLAG_SLOTS] then expected[2][EP_FLAG_SLOTS]
+  int *err_host, *err_dev;         // pinned + mapped: a wait kernel that timed out leaves (1 + dir) << 16 | stage << 8 | peer here
+  long long timeout_ticks;         // of the 100 MHz wall clock
+};
+
+// ---- IPC segments: device memory of this rank that every peer of the node maps into its own address space -------------
+#define EP_MAX_PEERS 16
+#define EP_FLAG_SLOTS (EP_MAX_SPLIT + 1)  // one flag slot per pipeline stage + one for tutel_amd_ep_ipc_exchange
+struct tutel_amd_ep_segment {
+  void *local;
+  size_t bytes;
+  int world, rank, device;
+  void *peer[EP_MAX_PEERS];    // peer[rank] == local; the others come from hipIpcOpenMemHandle
+  uint64_t *tab_dev;           // device copy of peer[]: what the peer-store kernels index by destination rank
 };
 
 static bool create_side_streams(tutel_amd_ep_comm *c) {
@@ -204,6 +232,28 @@ extern "C" int tutel_amd_ep_comm_create_hosted(int world, int rank, tutel_amd_ex
   return 0;
 }
 
+// A communicator with neither RCCL nor a host callback: the IPC transport (tutel_amd_ep_comm_attach_ipc) is its only
+// exchange -- ranks that share one GPU (RCCL refuses those), or a node where RCCL is not wanted on the path at all.
+extern "C" int tutel_amd_ep_comm_create_ipc(int world, int rank, tutel_amd_ep_comm_t **out) {
+  TUTEL_REQUIRE(out != nullptr && world >= 1 && world <= EP_MAX_PEERS && rank >= 0 && rank < world,
+                "tutel_amd_ep_comm_create_ipc: bad world / rank %d / %d (at most %d ranks: one node)", world, rank, EP_MAX_PEERS);
+  tutel_amd_ep_comm *c = (tutel_amd_ep_comm *)calloc(1, sizeof(tutel_amd_ep_comm));
+  TUTEL_REQUIRE(c != nullptr, "tutel_amd_ep_comm_create_ipc: out of memory");
+  c->world = world;
+  c->rank = rank;
+  bool ok = hipGetDevice(&c->device) == hipSuccess && create_side_streams(c);
+  for (int i = 0; ok && i < EP_MAX_SPLIT; ++i)
+    ok = hipEventCreateWithFlags(&c->recv_ev[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->done_ev[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    tutel_set_error("tutel_amd_ep_comm_create_ipc: cannot create the side streams / event table");
+    (void)tutel_amd_ep_comm_destroy(c);
+    return -1;
+  }
+  *out = c;
+  return 0;
+}
+
 extern "C" int tutel_amd_ep_comm_destroy(tutel_amd_ep_comm_t *c) {
   if (c == nullptr) return 0;
   if (c->side_stream != nullptr) (void)hipStreamSynchronize(c->side_stream);
@@ -217,7 +267,9 @@ extern "C" int tutel_amd_ep_comm_destroy(tutel_amd_ep_comm_t *c) {
     if (c->recv_ev[i] != nullptr) (void)hipEventDestroy(c->recv_ev[i]);
     if (c->done_ev[i] != nullptr) (void)hipEventDestroy(c->done_ev[i]);
   }
-  free(c);
+  if (c->epochs != nullptr) (void)hipFree(c->epochs);
+  if (c->err_host != nullptr) (void)hipHostFree(c->err_host);
+  free(c);  // (the flag segment belongs to the caller: tutel_amd_ep_segment_free)
   return 0;
 }
 
@@ -246,6 +298,7 @@ static int exchange(tutel_amd_ep_comm *c, const void *send, void *recv, size_t b
     TUTEL_REQUIRE(rc == 0, "tutel_amd_ep_forward: the host exchange callback failed (%d)", rc);
     return 0;
   }
+  TUTEL_REQUIRE(c->comm != nullptr, "tutel_amd_ep: this communicator has only the IPC transport (buffers must live in a segment: tutel_amd_ep_ipc_exchange)");
   if ((bytes_per_peer & 1) == 0)
     RCCL_CHECK(g_rccl.AllToAll(send, recv, bytes_per_peer / 2, ncclFloat16, c->comm, st), "ncclAllToAll");
   else
@@ -276,6 +329,7 @@ static int exchange_v(tutel_amd_ep_comm *c, const void *send, void *recv, const 
     TUTEL_REQUIRE(rc == 0, "%s: the host exchange callback failed (%d)", what, rc);
     return 0;
   }
+  TUTEL_REQUIRE(c->comm != nullptr, "%s: this communicator has only the IPC transport", what);
   RCCL_CHECK(g_rccl.GroupStart(), "ncclGroupStart");
   uint64_t ro = 0;
   ncclResult_t bad = ncclSuccess;
@@ -293,8 +347,8 @@ static int exchange_v(tutel_amd_ep_comm *c, const void *send, void *recv, const 
 extern "C" int tutel_amd_ep_all_to_all_v(tutel_amd_ep_comm_t *c, const void *send, void *recv, const uint64_t *send_bytes,
                                          const uint64_t *recv_bytes, tutel_stream_t stream) {
   TUTEL_REQUIRE(c != nullptr && send_bytes != nullptr && recv_bytes != nullptr, "tutel_amd_ep_all_to_all_v: need a communicator and both size arrays");
-  TUTEL_REQUIRE(c->world <= 4096, "tutel_amd_ep_all_to_all_v: world size %d", c->world);
-  uint64_t so[4096], tot_s = 0, tot_r = 0;
+  std::vector<uint64_t> so((size_t)c->world);
+  uint64_t tot_s = 0, tot_r = 0;
   for (int r = 0; r < c->world; ++r) {
     so[r] = tot_s;
     tot_s += send_bytes[r];
@@ -302,14 +356,14 @@ extern "C" int tutel_amd_ep_all_to_all_v(tutel_amd_ep_comm_t *c, const void *sen
   }
   TUTEL_REQUIRE((send != nullptr || tot_s == 0) && (recv != nullptr || tot_r == 0) && (send != recv || tot_s + tot_r == 0),
                 "tutel_amd_ep_all_to_all_v: null or aliased buffers");
-  return exchange_v(c, send, recv, send_bytes, so, recv_bytes, (hipStream_t)stream, "tutel_amd_ep_all_to_all_v");
+  return exchange_v(c, send, recv, send_bytes, so.data(), recv_bytes, (hipStream_t)stream, "tutel_amd_ep_all_to_all_v");
 }
 
 extern "C" int tutel_amd_ep_all_gather_v(tutel_amd_ep_comm_t *c, const void *send, void *recv, const uint64_t *recv_bytes,
                                          tutel_stream_t stream) {
   TUTEL_REQUIRE(c != nullptr && recv_bytes != nullptr, "tutel_amd_ep_all_gather_v: need a communicator and the size array");
-  TUTEL_REQUIRE(c->world <= 4096, "tutel_amd_ep_all_gather_v: world size %d", c->world);
-  uint64_t sb[4096], so[4096], tot_r = 0;
+  std::vector<uint64_t> sb((size_t)c->world), so((size_t)c->world);
+  uint64_t tot_r = 0;
   for (int r = 0; r < c->world; ++r) {
     sb[r] = recv_bytes[c->rank];  // the same bytes to everybody
     so[r] = 0;
@@ -317,8 +371,230 @@ extern "C" int tutel_amd_ep_all_gather_v(tutel_amd_ep_comm_t *c, const void *sen
   }
   TUTEL_REQUIRE((send != nullptr || recv_bytes[c->rank] == 0) && (recv != nullptr || tot_r == 0) && (send != recv || tot_r == 0),
                 "tutel_amd_ep_all_gather_v: null or aliased buffers");
-  return exchange_v(c, send, recv, sb, so, recv_bytes, (hipStream_t)stream, "tutel_amd_ep_all_gather_v");
+  return exchange_v(c, send, recv, sb.data(), so.data(), recv_bytes, (hipStream_t)stream, "tutel_amd_ep_all_gather_v");
 }
+
+// ---- IPC transport ------------------------------------------------------------------------------------------------
+// Replaces the exchange kernels of ncclAllToAll (custom_kernel.cpp:559-579, 627-648: one ncclSend / ncclRecv pair per peer and
+// chunk) by stores of the producing kernels themselves.  Memory model: a producer's stores into a peer's segment become visible
+// at its kernel boundary (end-of-kernel release to system scope); the flag is written by the NEXT kernel on the same stream, so
+// it can never overtake the data; the consumer polls the flag with system-scope loads in a kernel of its own and the consuming
+// kernel starts after that kernel's boundary (start-of-kernel acquire).  No fence inside a bandwidth kernel, no in-kernel spin
+// in a kernel that holds more than one wave.
+//
+// Buffer reuse needs no credits: rank r overwrites rank w's receive array in forward n + 1 only after its own decode of forward
+// n, which waited for w's stage flags of forward n, which w wrote after its GEMMs had read that array; and w overwrites r's
+// return array in forward n + 1 only after its fc1 waited for r's dispatch flag of forward n + 1, which r wrote after its
+// decode of forward n had read the return array.  Every rank calls the same forwards in the same order (SPMD), on one stream
+// at a time per communicator.
+extern "C" int tutel_amd_ep_segment_alloc(size_t bytes, int flag_memory, tutel_amd_ep_segment_t **out, void *handle_out, size_t handle_bytes) {
+  TUTEL_REQUIRE(out != nullptr && bytes >= 1, "tutel_amd_ep_segment_alloc: bad arguments");
+  TUTEL_REQUIRE(handle_out == nullptr || handle_bytes >= sizeof(hipIpcMemHandle_t), "tutel_amd_ep_segment_alloc: the handle needs %zu bytes", sizeof(hipIpcMemHandle_t));
+  tutel_amd_ep_segment *sg = (tutel_amd_ep_segment *)calloc(1, sizeof(tutel_amd_ep_segment));
+  TUTEL_REQUIRE(sg != nullptr, "tutel_amd_ep_segment_alloc: out of memory");
+  sg->bytes = bytes;
+  sg->world = 1;
+  hipError_t e = hipGetDevice(&sg->device);
+  if (e == hipSuccess) {
+    e = hipErrorInvalidValue;
+    // flag words are polled while other agents write them: uncached device memory where the runtime has it (what RCCL uses for
+    // its own peer flags), fine-grained next, plain device memory last (the polls are system-scope loads either way)
+    if (flag_memory) e = hipExtMallocWithFlags(&sg->local, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess && flag_memory) e = hipExtMallocWithFlags(&sg->local, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) e = hipMalloc(&sg->local, bytes);
+  }
+  if (e == hipSuccess && flag_memory) {
+    e = hipMemset(sg->local, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess && handle_out != nullptr) {
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, sg->local);
+    if (e == hipSuccess) memcpy(handle_out, &h, sizeof(h));
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    tutel_set_error("tutel_amd_ep_segment_alloc: %s", hipGetErrorString(e));
+    if (sg->local != nullptr) (void)hipFree(sg->local);
+    free(sg);
+    return (int)e;
+  }
+  sg->peer[0] = sg->local;
+  *out = sg;
+  return 0;
+}
+
+extern "C" int tutel_amd_ep_segment_open(tutel_amd_ep_segment_t *sg, int world, int rank, const void *handles, size_t handle_bytes) {
+  TUTEL_REQUIRE(sg != nullptr && world >= 1 && world <= EP_MAX_PEERS && rank >= 0 && rank < world, "tutel_amd_ep_segment_open: bad world / rank %d / %d (at most %d ranks)", world, rank, EP_MAX_PEERS);
+  TUTEL_REQUIRE(sg->tab_dev == nullptr, "tutel_amd_ep_segment_open: the segment is open already");
+  TUTEL_REQUIRE(world == 1 || (handles != nullptr && handle_bytes >= sizeof(hipIpcMemHandle_t)), "tutel_amd_ep_segment_open: need %d handles", world);
+  sg->world = world;
+  sg->rank = rank;
+  for (int w = 0; w < EP_MAX_PEERS; ++w) sg->peer[w] = nullptr;
+  sg->peer[rank] = sg->local;
+  for (int w = 0; w < world; ++w) {
+    if (w == rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char *)handles + (size_t)w * handle_bytes, sizeof(h));
+    const hipError_t e = hipIpcOpenMemHandle(&sg->peer[w], h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      sg->peer[w] = nullptr;
+      tutel_set_error("tutel_amd_ep_segment_open: hipIpcOpenMemHandle of rank %d's segment failed: %s", w, hipGetErrorString(e));
+      for (int v = 0; v < w; ++v)
+        if (v != rank && sg->peer[v] != nullptr) {
+          (void)hipIpcCloseMemHandle(sg->peer[v]);
+          sg->peer[v] = nullptr;
+        }
+      return (int)e;
+    }
+  }
+  uint64_t tab[EP_MAX_PEERS];
+  for (int w = 0; w < EP_MAX_PEERS; ++w) tab[w] = (uint64_t)(uintptr_t)sg->peer[w < world ? w : rank];
+  HIP_CHECK(hipMalloc((void **)&sg->tab_dev, sizeof(tab)), "hipMalloc");
+  HIP_CHECK(hipMemcpy(sg->tab_dev, tab, sizeof(tab), hipMemcpyHostToDevice), "hipMemcpy");
+  return 0;
+}
+
+extern "C" void *tutel_amd_ep_segment_ptr(const tutel_amd_ep_segment_t *sg, int peer) {
+  if (sg == nullptr) return nullptr;
+  if (peer < 0) return sg->local;
+  return peer < EP_MAX_PEERS ? sg->peer[peer] : nullptr;
+}
+
+// bytes [off, off + bytes) of the LOCAL segment -> `dst` (device), enqueued on `stream`: how host code that owns no tensor over
+// the segment (it is library memory) looks at what the peers stored
+extern "C" int tutel_amd_ep_segment_read(const tutel_amd_ep_segment_t *sg, size_t off, void *dst, size_t bytes, tutel_stream_t stream) {
+  TUTEL_REQUIRE(sg != nullptr && dst != nullptr && off + bytes <= sg->bytes, "tutel_amd_ep_segment_read: out of range");
+  HIP_CHECK(hipMemcpyAsync(dst, (const char *)sg->local + off, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync");
+  return 0;
+}
+
+extern "C" int tutel_amd_ep_segment_free(tutel_amd_ep_segment_t *sg) {
+  if (sg == nullptr) return 0;
+  for (int w = 0; w < sg->world && w < EP_MAX_PEERS; ++w)
+    if (sg->peer[w] != nullptr && sg->peer[w] != sg->local) (void)hipIpcCloseMemHandle(sg->peer[w]);
+  if (sg->tab_dev != nullptr) (void)hipFree(sg->tab_dev);
+  if (sg->local != nullptr) (void)hipFree(sg->local);
+  free(sg);
+  return 0;
+}
+
+#define EP_FLAG_WORDS (2 * EP_FLAG_SLOTS * EP_MAX_PEERS)
+extern "C" size_t tutel_amd_ep_flag_bytes(void) { return (size_t)EP_FLAG_WORDS * sizeof(uint32_t); }
+
+extern "C" int tutel_amd_ep_comm_attach_ipc(tutel_amd_ep_comm_t *c, tutel_amd_ep_segment_t *flags, int timeout_ms) {
+  TUTEL_REQUIRE(c != nullptr && flags != nullptr, "tutel_amd_ep_comm_attach_ipc: null communicator / segment");
+  TUTEL_REQUIRE(c->flag_seg == nullptr, "tutel_amd_ep_comm_attach_ipc: the communicator has its flag segment already");
+  TUTEL_REQUIRE(flags->tab_dev != nullptr && flags->world == c->world && flags->rank == c->rank && flags->bytes >= tutel_amd_ep_flag_bytes(),
+                "tutel_amd_ep_comm_attach_ipc: the flag segment must be opened for this communicator's %d ranks and hold %zu bytes", c->world, tutel_amd_ep_flag_bytes());
+  HIP_CHECK(hipMalloc((void **)&c->epochs, 4 * EP_FLAG_SLOTS * sizeof(uint32_t)), "hipMalloc");
+  HIP_CHECK(hipMemset(c->epochs, 0, 4 * EP_FLAG_SLOTS * sizeof(uint32_t)), "hipMemset");
+  HIP_CHECK(hipHostMalloc((void **)&c->err_host, sizeof(int), hipHostMallocMapped), "hipHostMalloc");
+  *c->err_host = 0;
+  HIP_CHECK(hipHostGetDevicePointer((void **)&c->err_dev, c->err_host, 0), "hipHostGetDevicePointer");
+  HIP_CHECK(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  c->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 20000) * 100000LL;  // wall_clock64: 100 MHz
+  c->flag_seg = flags;
+  return 0;
+}
+
+extern "C" int tutel_amd_ep_comm_has_ipc(const tutel_amd_ep_comm_t *c) { return c != nullptr && c->flag_seg != nullptr; }
+
+// one workgroup, thread (i, w) = (stage, peer): flag[dir][stage0 + i][my rank] of rank w := this rank's next epoch for the slot
+__global__ void ep_signal_kernel(const uint64_t *__restrict__ flag_tab, uint32_t *__restrict__ epochs, int dir, int stage0,
+                                 int nstages, int W, int rank) {
+  const int t = threadIdx.x, i = t / W, w = t % W;
+  const bool on = i < nstages;
+  uint32_t e = 0;
+  if (on) e = epochs[dir * EP_FLAG_SLOTS + stage0 + i] + 1u;
+  __syncthreads();  // every thread of a stage has read the old epoch before one of them writes the new one
+  if (!on) return;
+  __threadfence_system();
+  uint32_t *f = reinterpret_cast<uint32_t *>(flag_tab[w]) + ((size_t)(dir * EP_FLAG_SLOTS + stage0 + i) * EP_MAX_PEERS + rank);
+  __hip_atomic_store(f, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (w == 0) epochs[dir * EP_FLAG_SLOTS + stage0 + i] = e;
+}
+
+// one workgroup, thread (i, w): wait until peer w has signalled this rank's next expected epoch of slot (dir, stage0 + i).
+// Every spin is bounded: after timeout_ticks the thread records which (dir, stage, peer) never arrived and gives up.
+__global__ void ep_wait_kernel(const uint32_t *__restrict__ flags, uint32_t *__restrict__ epochs, int dir, int stage0, int nstages,
+                               int W, int *err, long long timeout_ticks) {
+  const int t = threadIdx.x, i = t / W, w = t % W;
+  const bool on = i < nstages;
+  uint32_t *expect = epochs + 2 * EP_FLAG_SLOTS;
+  uint32_t e = 0;
+  if (on) e = expect[dir * EP_FLAG_SLOTS + stage0 + i] + 1u;
+  __syncthreads();
+  if (!on) return;
+  const uint32_t *f = flags + ((size_t)(dir * EP_FLAG_SLOTS + stage0 + i) * EP_MAX_PEERS + w);
+  const long long t0 = wall_clock64();
+  while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+    __builtin_amdgcn_s_sleep(20);
+    if (wall_clock64() - t0 > timeout_ticks) {
+      __hip_atomic_store(err, ((1 + dir) << 16) | ((stage0 + i) << 8) | w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+  __threadfence_system();
+  if (w == 0) expect[dir * EP_FLAG_SLOTS + stage0 + i] = e;
+}
+
+static int ipc_check(tutel_amd_ep_comm *c, const char *what) {
+  TUTEL_REQUIRE(c != nullptr && c->flag_seg != nullptr, "%s: the communicator has no IPC transport (tutel_amd_ep_comm_attach_ipc)", what);
+  const int err = *(volatile int *)c->err_host;
+  TUTEL_REQUIRE(err == 0, "%s: an earlier exchange timed out waiting for rank %d (%s, stage %d): a peer died or the ranks disagree about the call sequence",
+                what, err & 0xff, (err >> 16) == 1 ? "dispatch" : "combine", (err >> 8) & 0xff);
+  return 0;
+}
+static int ipc_signal(tutel_amd_ep_comm *c, int dir, int stage0, int nstages, hipStream_t st) {
+  hipLaunchKernelGGL(ep_signal_kernel, dim3(1), dim3(nstages * c->world), 0, st, c->flag_seg->tab_dev, c->epochs, dir, stage0, nstages, c->world, c->rank);
+  TUTEL_CHECK_LAUNCH("tutel_amd_ep (signal)");
+  return 0;
+}
+static int ipc_wait(tutel_amd_ep_comm *c, int dir, int stage0, int nstages, hipStream_t st) {
+  hipLaunchKernelGGL(ep_wait_kernel, dim3(1), dim3(nstages * c->world), 0, st, (const uint32_t *)c->flag_seg->local, c->epochs, dir, stage0, nstages,
+                     c->world, c->err_dev, c->timeout_ticks);
+  TUTEL_CHECK_LAUNCH("tutel_amd_ep (wait)");
+  return 0;
+}
+
+// block r of `send` (bytes_per_peer bytes, 16-byte granules) -> rank r's segment at recv_off + <my rank> * bytes_per_peer
+__global__ __launch_bounds__(256) void ep_peer_copy_kernel(const uint4 *__restrict__ send, const uint64_t *__restrict__ tab, long long recv_off,
+                                                          size_t vec_per_peer, int W, int rank) {
+  const size_t n = vec_per_peer * (size_t)W;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
+    const int w = (int)(v / vec_per_peer);
+    const size_t o = v % vec_per_peer;
+    reinterpret_cast<uint4 *>(tab[w] + recv_off)[(size_t)rank * vec_per_peer + o] = send[v];
+  }
+}
+
+// all_to_all_single with equal splits over the IPC transport: `send` is any device buffer of this rank, the result lands at
+// byte offset recv_off of every rank's `seg` ([world][bytes_per_peer]); when the call's work completes on `stream` the
+// received blocks may be read.  The caller keeps two such exchanges into the same offset apart (a barrier, or any exchange
+// in the other direction): there are no credits.
+extern "C" int tutel_amd_ep_ipc_exchange(tutel_amd_ep_comm_t *c, tutel_amd_ep_segment_t *seg, const void *send, size_t bytes_per_peer,
+                                         size_t recv_off, tutel_stream_t stream) {
+  if (ipc_check(c, "tutel_amd_ep_ipc_exchange") != 0) return -1;
+  TUTEL_REQUIRE(seg != nullptr && seg->tab_dev != nullptr && seg->world == c->world && seg->rank == c->rank, "tutel_amd_ep_ipc_exchange: the segment is not open for this communicator");
+  TUTEL_REQUIRE(bytes_per_peer % 16 == 0 && recv_off % 16 == 0 && ((uintptr_t)send % 16) == 0, "tutel_amd_ep_ipc_exchange: 16-byte granules");
+  TUTEL_REQUIRE(recv_off + bytes_per_peer * (size_t)c->world <= seg->bytes, "tutel_amd_ep_ipc_exchange: the blocks do not fit the segment");
+  hipStream_t st = (hipStream_t)stream;
+  StageScope scope(TUTEL_STAGE_OTHER, st);
+  if (bytes_per_peer > 0) {
+    TUTEL_REQUIRE(send != nullptr, "tutel_amd_ep_ipc_exchange: null send buffer");
+    const size_t vpp = bytes_per_peer / 16, n = vpp * (size_t)c->world;
+    const int grid = (int)(n / 256 + 1 > 2048 ? 2048 : n / 256 + 1);
+    hipLaunchKernelGGL(ep_peer_copy_kernel, dim3(grid), dim3(256), 0, st, (const uint4 *)send, seg->tab_dev, (long long)recv_off, vpp, c->world, c->rank);
+    TUTEL_CHECK_LAUNCH("tutel_amd_ep_ipc_exchange");
+  }
+  int rc = ipc_signal(c, 0, EP_MAX_SPLIT, 1, st);
+  if (rc) return rc;
+  return ipc_wait(c, 0, EP_MAX_SPLIT, 1, st);
+}
+
+extern "C" int tutel_amd_ep_ipc_status(tutel_amd_ep_comm_t *c) { return ipc_check(c, "tutel_amd_ep_ipc_status"); }
 
 // ---- stage layouts (== tutel_amd/impls/overlap.py::OverlapPlan) ------------------------------------------------
 extern "C" int tutel_amd_ep_plan(int E, int W, int capacity, int degree, int allow_sliced, tutel_amd_ep_plan_t *out) {
@@ -386,7 +662,8 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     return tutel_amd_fast_decode(a->send, a->dtype, a->idx, a->loc, dec_gates, a->gate_dtype, T, Mo, k, C, E, 0, 0, 1, a->y, cur);
   }
 
-  TUTEL_REQUIRE(a->enc && a->recv && a->hid && a->send && a->back, "tutel_amd_ep_forward: null workspace");
+  const bool ipc = a->peer_seg != nullptr;
+  TUTEL_REQUIRE(a->recv && a->hid && a->back && (ipc || (a->enc && a->send)), "tutel_amd_ep_forward: null workspace");
   TUTEL_REQUIRE(rcnt == nullptr, "tutel_amd_ep_forward: row counts need the fused-encode single-rank route (is_postscore, fuse_encode)");
   const int degree = a->degree < 1 ? 1 : a->degree;
   tutel_amd_ep_plan_t pl;
@@ -395,17 +672,23 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
   const int chunk_rows = pl.sliced ? 0 : cc, expert_slice = pl.sliced ? s : 0;
   int rc;
 
-  {
-    Range r("tutel_amd.fast_encode");
-    rc = tutel_amd_fast_encode(a->x, a->dtype, a->slot_map, enc_gates, a->gate_dtype, T, M, E * C, C, E, chunk_rows, expert_slice, W, a->enc, cur);
-    if (rc) return rc;
-  }
   const size_t msg_in = (size_t)W * rows * M * es, msg_out = (size_t)W * rows * Mo * es;  // bytes per stage
   const size_t hid_stage = (size_t)s * R * H * es;
+  // IPC transport: where the receive / return arrays sit inside every rank's segment (the same offsets on every rank)
+  const tutel_amd_ep_segment *seg = a->peer_seg;
+  long long recv_off = 0, back_off = 0;
+  if (ipc) {
+    if (ipc_check(c, "tutel_amd_ep_forward") != 0) return -1;
+    TUTEL_REQUIRE(seg->tab_dev != nullptr && seg->world == W && seg->rank == c->rank, "tutel_amd_ep_forward: the peer segment is not open for this communicator");
+    recv_off = (const char *)a->recv - (const char *)seg->local;
+    back_off = (const char *)a->back - (const char *)seg->local;
+    TUTEL_REQUIRE(recv_off >= 0 && back_off >= 0 && (size_t)recv_off + degree * msg_in <= seg->bytes && (size_t)back_off + degree * msg_out <= seg->bytes &&
+                      recv_off % 16 == 0 && back_off % 16 == 0,
+                  "tutel_amd_ep_forward: recv / back must lie inside the peer segment");
+  }
   auto stage_gemms = [&](int i, hipStream_t st) -> int {
     // GEMM rows addressed in the raw exchange buffer: expert el of the stage, source rank w, row l -> ((w*s + el)*cc + l)
     const char *recv_i = (const char *)a->recv + (size_t)i * msg_in;
-    char *send_i = (char *)a->send + (size_t)i * msg_out;
     char *hid_i = (char *)a->hid + (size_t)i * hid_stage;
     const int e0 = pl.sliced ? i * s : 0;  // first local expert of the stage
     const char *w1 = (const char *)a->w1 + (size_t)e0 * H * M * es, *w2 = (const char *)a->w2 + (size_t)e0 * H * Mo * es;
@@ -420,10 +703,95 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
       if (r1) return r1;
     }
     Range r("tutel_amd.expert_fc2");
+    if (ipc)  // rows of source rank w go straight to block <my rank> of stage i of rank w's return array
+      return tutel_expert_gemm_peer(hid_i, (int64_t)R * H, 0, R, H, w2, a->w2_kmajor, (int64_t)H * Mo, a->w2_kmajor ? H : Mo, b2, Mo, seg->tab_dev,
+                                    back_off + (long long)(((size_t)i * W + c->rank) * rows * Mo * es), (int64_t)cc * Mo, cc, Mo, s, R, Mo, H, a->dtype,
+                                    TUTEL_ACT_NONE, st);
+    char *send_i = (char *)a->send + (size_t)i * msg_out;
     return tutel_amd_expert_gemm(hid_i, (int64_t)R * H, 0, R, H, w2, a->w2_kmajor, (int64_t)H * Mo, a->w2_kmajor ? H : Mo, b2, Mo, send_i,
                                  (int64_t)cc * Mo, (int64_t)rows * Mo, cc, Mo, s, R, Mo, H, a->dtype, TUTEL_ACT_NONE, nullptr, 1, st);
   };
+  // stage i's bucket rows: plain launch into `enc`, or (IPC) peer stores into the owners' receive arrays
+  auto encode_stage = [&](int i, int nst) -> int {
+    Range r("tutel_amd.fast_encode");
+    EncodePeer pe = {ipc ? seg->tab_dev : nullptr, recv_off, ipc ? c->rank : 0, rows, i * W * rows};
+    return tutel_encode_launch(a->x, a->dtype, a->slot_map, enc_gates, a->gate_dtype, T, M, (i + nst) * W * rows, C, E, chunk_rows, expert_slice, W,
+                               ipc ? nullptr : a->enc, pe, cur);
+  };
 
+  // Forked side streams are joined back on EVERY exit from here on: an early return between a fork and its join would
+  // leave the caller's stream unordered against work still running on a side stream -- and, under HIP-graph capture, an unjoined
+  // fork (capture then fails at hipStreamEndCapture instead of here, with the real error lost).
+  struct ForkGuard {
+    hipStream_t cur;
+    hipStream_t forked[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    void fork(int slot, hipStream_t ks, hipEvent_t join_ev) { forked[slot] = ks; ev[slot] = join_ev; }
+    void joined(int slot) { forked[slot] = nullptr; }
+    ~ForkGuard() {
+      for (int j = 0; j < 2; ++j)
+        if (forked[j] != nullptr && hipEventRecord(ev[j], forked[j]) == hipSuccess) (void)hipStreamWaitEvent(cur, ev[j], 0);
+      tutel_gemm_corun_hint(0);
+    }
+  } guard{cur};
+
+  if (ipc) {
+    // ---- IPC transport: no collective, no send / enc staging arrays.  Per stage: encode (peer stores) -> signal | wait ->
+    // fc1 -> fc2 (peer stores) -> signal; then one wait for every stage's return rows and decode.  With degree > 1 stage
+    // i's GEMMs run on side stream i % 2 while the caller's stream encodes stage i + 1 (its stores are on the links).
+    hipStream_t kss[2] = {cur, cur};
+    if (degree > 1) side_streams_for(c, cur, kss);
+    if (degree == 1) {
+      rc = encode_stage(0, 1);
+      if (rc) return rc;
+      {
+        StageScope sc(TUTEL_STAGE_A2A_DISPATCH, cur);
+        if ((rc = ipc_signal(c, 0, 0, 1, cur)) != 0 || (rc = ipc_wait(c, 0, 0, 1, cur)) != 0) return rc;
+      }
+      rc = stage_gemms(0, cur);
+      if (rc) return rc;
+      StageScope sc(TUTEL_STAGE_A2A_COMBINE, cur);
+      if ((rc = ipc_signal(c, 1, 0, 1, cur)) != 0) return rc;
+    } else {
+      for (int i = 0; i < degree; ++i) {
+        rc = encode_stage(i, 1);
+        if (rc) return rc;
+        {
+          StageScope sc(TUTEL_STAGE_A2A_DISPATCH, cur);
+          if ((rc = ipc_signal(c, 0, i, 1, cur)) != 0) return rc;
+        }
+        HIP_CHECK(hipEventRecord(c->recv_ev[i], cur), "hipEventRecord");
+      }
+      for (int i = 0; i < degree; ++i) {
+        hipStream_t ks = kss[i & 1];
+        HIP_CHECK(hipStreamWaitEvent(ks, c->recv_ev[i], 0), "hipStreamWaitEvent");
+        guard.fork(i & 1, ks, c->done_ev[i]);
+        {
+          StageScope sc(TUTEL_STAGE_A2A_DISPATCH, ks);
+          if ((rc = ipc_wait(c, 0, i, 1, ks)) != 0) return rc;
+        }
+        rc = stage_gemms(i, ks);
+        if (rc) return rc;
+        StageScope sc(TUTEL_STAGE_A2A_COMBINE, ks);
+        if ((rc = ipc_signal(c, 1, i, 1, ks)) != 0) return rc;
+      }
+      for (int j = 0; j < 2; ++j)
+        if (guard.forked[j] != nullptr) {
+          HIP_CHECK(hipEventRecord(guard.ev[j], guard.forked[j]), "hipEventRecord");
+          HIP_CHECK(hipStreamWaitEvent(cur, guard.ev[j], 0), "hipStreamWaitEvent");
+          guard.joined(j);
+        }
+    }
+    {
+      StageScope sc(TUTEL_STAGE_A2A_COMBINE, cur);
+      if ((rc = ipc_wait(c, 1, 0, degree, cur)) != 0) return rc;
+    }
+    Range r("tutel_amd.fast_decode");
+    return tutel_amd_fast_decode(a->back, a->dtype, a->idx, a->loc, dec_gates, a->gate_dtype, T, Mo, k, C, E, chunk_rows, expert_slice, W, a->y, cur);
+  }
+
+  rc = encode_stage(0, degree);
+  if (rc) return rc;
   if (degree == 1 || c == nullptr) {
     // one stream: exchange, GEMMs, exchange per stage, in order (degree 1; or a single rank whose exchange is a copy)
     for (int i = 0; i < degree; ++i) {
@@ -463,12 +831,14 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     for (int i = 0; i < degree; ++i) {
       hipStream_t ks = kss[i & 1];
       HIP_CHECK(hipStreamWaitEvent(ks, c->recv_ev[i], 0), "hipStreamWaitEvent");  // the side stream forks from the caller's
+      guard.fork(0, ks, c->done_ev[i]);
       tutel_gemm_corun_hint(c->comm != nullptr);  // a real collective runs beside these GEMMs (the hosted test exchange is synchronous)
       rc = stage_gemms(i, ks);
       tutel_gemm_corun_hint(0);
       if (rc) return rc;
       HIP_CHECK(hipEventRecord(c->done_ev[i], ks), "hipEventRecord");
       HIP_CHECK(hipStreamWaitEvent(cur, c->done_ev[i], 0), "hipStreamWaitEvent");  // and is joined back
+      guard.joined(0);
       Range r("tutel_amd.all_to_all(combine)");
       rc = exchange(c, (const char *)a->send + (size_t)i * msg_out, (char *)a->back + (size_t)i * msg_out, (size_t)rows * Mo * es, W, cur, TUTEL_STAGE_A2A_COMBINE);
       if (rc) return rc;

@@ -95,8 +95,19 @@ struct GemmArgs {
   bool fits32;                                                // operands addressable with 32-bit byte offsets
   bool rot_on;                                                // K-tile rotation (see launch_gemm)
   const void *mul;                                            // optional epilogue multiplier, D's layout
+  const uint64_t *d_peer; long long d_peer_off;               // optional: rows of source rank w go to d_peer[w] + d_peer_off (bytes)
   int ntm, ntn;
 };
+
+// address of output row m of expert e (elements of 2 bytes).  Plain: D + e*stride_e + (m / rpw)*stride_w + (m % rpw)*ldd.
+// Peer stores (IPC transport of the expert-parallel pipeline, ep.hip): the rows that came from source rank w = m / rpw are
+// written into THAT rank's return buffer, d_peer[w] + d_peer_off, where the second all-to-all would have delivered them.
+__device__ __forceinline__ uint16_t *gemm_out_row(const GemmArgs &p, int e, int m) {
+  const int w = m / p.d_rpw, l = m % p.d_rpw;
+  if (p.d_peer != nullptr)
+    return reinterpret_cast<uint16_t *>(p.d_peer[w] + p.d_peer_off) + (size_t)e * p.d_stride_e + (size_t)l * p.ldd;
+  return reinterpret_cast<uint16_t *>(p.D) + (size_t)e * p.d_stride_e + (size_t)w * p.d_stride_w + (size_t)l * p.ldd;
+}
 
 // ---- epilogue shared by both kernels: lane holds, per accumulator, row m = l31, features
 // 8*rg + 4*kg + 0..3.  D = act(acc + bias) [* mul], rounded once to T; `mul` (optional) has D's
@@ -113,7 +124,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, f32x16 (&acc)[N
     const int m = m0 + wm * 64 + mi * 32 + l31;
     if (m >= row_limit) continue;
     const size_t roff = (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
-    uint16_t *drow = De + roff;
+    uint16_t *drow = p.d_peer != nullptr ? gemm_out_row(p, e, m) : De + roff;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -615,7 +626,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&ac
     const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + row * PITCH + c16 * 16);
     if (m < row_limit && n < p.N) {
       const size_t roff = (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
-      *reinterpret_cast<u32x4 *>(De + roff + n) = val;
+      uint16_t *drow = p.d_peer != nullptr ? gemm_out_row(p, e, m) : De + roff;
+      *reinterpret_cast<u32x4 *>(drow + n) = val;
     }
   }
 }
@@ -1283,13 +1295,15 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
                                      int R, int N, int K, int dtype, int act,
                                      const int32_t *row_counts, int row_align,
                                      const int32_t *a_rows, int a_rows_mod, const void *a_zero,
-                                     const void *mul, tutel_stream_t stream) {
+                                     const void *mul, tutel_stream_t stream, const uint64_t *d_peer = nullptr,
+                                     int64_t d_peer_off = 0) {
   TUTEL_REQUIRE(dtype == TUTEL_BF16 || dtype == TUTEL_F16, "tutel_amd_expert_gemm: dtype must be bf16 or fp16 (got %d)", dtype);
   TUTEL_REQUIRE(E_loc >= 0 && R >= 0 && N >= 1 && K >= 1, "tutel_amd_expert_gemm: bad sizes E_loc=%d R=%d N=%d K=%d", E_loc, R, N, K);
   TUTEL_REQUIRE(K % 64 == 0, "tutel_amd_expert_gemm: K=%d must be a multiple of 64", K);
   TUTEL_REQUIRE(N % 8 == 0, "tutel_amd_expert_gemm: N=%d must be a multiple of 8", N);
   if (E_loc == 0 || R == 0) return 0;
-  TUTEL_REQUIRE(A && W && D, "tutel_amd_expert_gemm: null pointer");
+  TUTEL_REQUIRE(A && W && (D || d_peer), "tutel_amd_expert_gemm: null pointer");
+  TUTEL_REQUIRE(d_peer == nullptr || (mul == nullptr && d_peer_off % 16 == 0), "tutel_amd_expert_gemm: peer stores exclude the gated form");
   TUTEL_REQUIRE(a_rows_per_w >= 1 && d_rows_per_w >= 1, "tutel_amd_expert_gemm: rows_per_w must be >= 1");
   TUTEL_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldd % 4 == 0 && a_stride_e % 8 == 0 && a_stride_w % 8 == 0 &&
                     w_stride_e % 8 == 0 && d_stride_e % 4 == 0 && d_stride_w % 4 == 0 && bias_stride_e % 4 == 0,
@@ -1326,6 +1340,7 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   //     4096^2, 85 -> 79 at 32 x 256 rows).
   a.rot_on = R < GB_BM;
   a.mul = mul;
+  a.d_peer = d_peer; a.d_peer_off = d_peer_off;
   TUTEL_REQUIRE(((uintptr_t)mul % 8) == 0, "tutel_amd_expert_gemm_glu: gating operand must be 8-byte aligned");
   TUTEL_REQUIRE(a_rows == nullptr || (a_rows_mod >= 1 && a_zero != nullptr && ((uintptr_t)a_zero % 16) == 0),
                 "tutel_amd_expert_gemm_gather: need a_rows_mod >= 1 and a 16-byte aligned zero row");
@@ -1354,6 +1369,16 @@ extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t 
   return expert_gemm_impl(A, a_stride_e, a_stride_w, a_rows_per_w, lda, W, w_kmajor, w_stride_e, ldw, bias,
                           bias_stride_e, D, d_stride_e, d_stride_w, d_rows_per_w, ldd, E_loc, R, N, K, dtype, act,
                           row_counts, row_align, nullptr, 0, nullptr, nullptr, stream);
+}
+
+int tutel_expert_gemm_peer(const void *A, int64_t a_stride_e, int64_t a_stride_w, int a_rows_per_w, int lda, const void *W,
+                           int w_kmajor, int64_t w_stride_e, int ldw, const void *bias, int64_t bias_stride_e,
+                           const uint64_t *d_peer, int64_t d_peer_off, int64_t d_stride_e, int d_rows_per_w, int ldd, int E_loc,
+                           int R, int N, int K, int dtype, int act, hipStream_t st) {
+  TUTEL_REQUIRE(d_peer != nullptr, "tutel_expert_gemm_peer: null peer table");
+  return expert_gemm_impl(A, a_stride_e, a_stride_w, a_rows_per_w, lda, W, w_kmajor, w_stride_e, ldw, bias, bias_stride_e, nullptr,
+                          d_stride_e, 0, d_rows_per_w, ldd, E_loc, R, N, K, dtype, act, nullptr, 1, nullptr, 0, nullptr, nullptr,
+                          (tutel_stream_t)st, d_peer, d_peer_off);
 }
 
 extern "C" int tutel_amd_expert_gemm_glu(const void *A, int64_t a_stride_e, int64_t a_stride_w,

@@ -251,7 +251,8 @@ def _native_comm(t, group):
     from . import ep_native
     if not ep_native.ENABLED or not (dist.get_backend(group) == "nccl" or ep_native.HOSTED):
         return None
-    return ep_native.communicator(group, t.device)   # collective on first use; every rank of the group is in this call
+    c = ep_native.communicator(group, t.device)   # collective on first use; every rank of the group is in this call
+    return c if c is not None and c.generic else None
 
 
 def batch_all_to_all_v(datas, partition_sizes, group=None):

@@ -27,14 +27,42 @@ from .. import _lib, ops
 ENABLED = int(os.environ.get("TUTEL_AMD_NATIVE_EP", "1")) != 0
 FAST_PATH = int(os.environ.get("TUTEL_AMD_FAST_PATH", "1")) != 0  # routing + pipeline in one call (tutel_amd_moe_forward)
 HOSTED = int(os.environ.get("TUTEL_AMD_NATIVE_HOSTED", "0")) != 0  # bring-up / tests: native pipeline over a gloo group, exchange staged by the host
+# How the bucket rows travel between the ranks of a node:
+#   "auto"  peer stores over xGMI (IPC transport, csrc/ep.hip) when every rank can map every other rank's segment and the tagged
+#           self-check passes on all of them; RCCL's all-to-all on the library communicator otherwise
+#   "ipc"   the same, and also for process groups that are not on the "nccl" backend (ranks that share one GPU: the tests)
+#   "rccl"  never attach the IPC transport
+TRANSPORT = os.environ.get("TUTEL_AMD_EP_TRANSPORT", "auto").lower()
+IPC_TIMEOUT_MS = int(os.environ.get("TUTEL_AMD_EP_TIMEOUT_MS", "20000"))
 _FORCE_COMM = False  # test hook: run a single rank through a real 1-rank RCCL communicator (staged pipeline, both streams)
-_comms = {}      # id(group) / "world" -> EpComm | False (creation failed: do not retry)
+_comms = {}      # (ranks of the group, device) -> EpComm | False (creation failed: do not retry)
+_groups = {}
 _zero_rows = {}
+
+
+class Segment:
+    """device memory of this rank that every peer has mapped (tutel_amd_ep_segment_*); `ptr` = local base address"""
+
+    def __init__(self, handle, nbytes):
+        self.handle, self.nbytes = handle, nbytes
+        self.ptr = int(_lib.lib().tutel_amd_ep_segment_ptr(handle, -1) or 0)
 
 
 class EpComm:
     def __init__(self, handle, world, rank):
         self.handle, self.world, self.rank = handle, world, rank
+        self.ipc = False       # IPC transport attached (peer stores, no collective on the forward path)
+        self.generic = True    # has an exchange for arbitrary buffers (RCCL or the host callback); False: IPC transport only
+        self.segments = {}     # rank-invariant key -> Segment; kept for the communicator's lifetime (peers hold mappings)
+        self.group = self.device = None
+
+    def segment(self, key, nbytes):
+        """the peer-mapped segment of `key`, at least nbytes large.  COLLECTIVE on a miss: the key and the size must be the same
+        on every rank (they are functions of the model / expert / capacity sizes, never of a rank's own token count)"""
+        sg = self.segments.get(key)
+        if sg is None:
+            sg = self.segments[key] = _open_segment(self, nbytes, False)
+        return sg
 
     def all_to_all(self, out, inp):
         assert out.is_contiguous() and inp.is_contiguous() and out.numel() == inp.numel() and inp.numel() % self.world == 0
@@ -85,6 +113,108 @@ class EpComm:
 
 def _rccl_hint():
     return os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
+
+
+def _agree(v, group, device):
+    """min over the ranks of `group` (all ranks take the same branch afterwards)"""
+    on_dev = dist.get_backend(group) == "nccl"
+    f = torch.tensor([int(v)], dtype=torch.int32, device=device if on_dev else "cpu")
+    dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+    return int(f)
+
+
+def _all_gather_bytes(raw, group, device):
+    """every rank's `raw` (bytes, same length) in rank order"""
+    on_dev = dist.get_backend(group) == "nccl"
+    t = torch.tensor(list(raw), dtype=torch.uint8, device=device if on_dev else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return b"".join(bytes(o.cpu().tolist()) for o in out)
+
+
+def _open_segment(comm, nbytes, flag_memory):
+    """allocate + exchange handles + map every peer's allocation.  Collective; raises on every rank if any rank failed."""
+    L = _lib.lib()
+    hb = _lib.IPC_HANDLE_BYTES
+    handle, raw, ok = ctypes.c_void_p(), (ctypes.c_ubyte * hb)(), 1
+    with torch.cuda.device(comm.device):
+        if L.tutel_amd_ep_segment_alloc(int(nbytes), int(bool(flag_memory)), ctypes.byref(handle), raw, hb) != 0:
+            logging.warning("tutel_amd: rank %d cannot allocate a %d-byte exchange segment (%s)", comm.rank, nbytes, L.tutel_amd_last_error().decode())
+            ok = 0
+        handles = _all_gather_bytes(bytes(raw), comm.group, comm.device)
+        if ok and L.tutel_amd_ep_segment_open(handle, comm.world, comm.rank, handles, hb) != 0:
+            logging.warning("tutel_amd: rank %d cannot map its peers' exchange segments (%s)", comm.rank, L.tutel_amd_last_error().decode())
+            ok = 0
+    if not _agree(ok, comm.group, comm.device):
+        if handle:
+            L.tutel_amd_ep_segment_free(handle)
+        raise _lib.TutelAmdError("tutel_amd: the exchange segment could not be opened on every rank")
+    return Segment(handle, int(nbytes))
+
+
+def _attach_ipc(comm, group, device):
+    """give `comm` the IPC transport (collective).  True when every rank attached it and the tagged exchange delivered the right
+    blocks everywhere; False (on every rank) otherwise -- the communicator then keeps exchanging the way it did."""
+    L = _lib.lib()
+    comm.group, comm.device = group, device
+    if comm.world > 16:
+        return False
+    try:
+        flags = _open_segment(comm, int(L.tutel_amd_ep_flag_bytes()), True)
+    except _lib.TutelAmdError:
+        return False
+    with torch.cuda.device(device):
+        ok = int(L.tutel_amd_ep_comm_attach_ipc(comm.handle, flags.handle, IPC_TIMEOUT_MS) == 0)
+    if not _agree(ok, group, device):
+        return False
+    comm._flags = flags
+    ok = 1
+    try:
+        # self-check through the real kernels (peer stores, signal, wait), twice (the second pass exercises the epoch counters):
+        # block p of my send buffer carries (my rank, p, pass); afterwards block r must carry (r, my rank, pass)
+        n, W, rank = 1024, comm.world, comm.rank
+        seg = _open_segment(comm, W * n * 4, False)
+        comm._selfcheck = seg
+        for rep in range(2):
+            send = (torch.arange(W, device=device, dtype=torch.int32).view(W, 1) + 1000 * rank + 100000 * rep).repeat(1, n).contiguous()
+            with torch.cuda.device(device):
+                _lib.check(L.tutel_amd_ep_ipc_exchange(comm.handle, seg.handle, send.data_ptr(), n * 4, 0, ops._stream()), "tutel_amd_ep_ipc_exchange")
+                torch.cuda.synchronize(device)
+                _lib.check(L.tutel_amd_ep_ipc_status(comm.handle), "tutel_amd_ep_ipc_status")
+                got = torch.empty([W, n], dtype=torch.int32, device=device)
+                _lib.check(L.tutel_amd_ep_segment_read(seg.handle, 0, got.data_ptr(), W * n * 4, ops._stream()), "tutel_amd_ep_segment_read")
+                torch.cuda.synchronize(device)
+            want = (torch.arange(W, device=device, dtype=torch.int32).view(W, 1) * 1000 + rank + 100000 * rep).repeat(1, n)
+            if not torch.equal(got, want):
+                raise _lib.TutelAmdError("tagged peer-store exchange returned wrong blocks")
+            dist.barrier(group=group)   # nobody starts the next pass (or the first forward) before everyone has read this one
+    except Exception as ex:  # noqa: BLE001
+        logging.warning("tutel_amd: the IPC transport failed its self-check on rank %d (%s)", comm.rank, ex)
+        ok = 0
+    if not _agree(ok, group, device):
+        if comm.rank == 0:
+            logging.warning("tutel_amd: IPC transport unavailable; the exchange stays on the communicator's all-to-all")
+        return False
+    comm.ipc = True
+    return True
+
+
+def _create_ipc_only(group, device):
+    """communicator without RCCL and without a host callback: only the IPC transport can carry its exchange"""
+    L = _lib.lib()
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    handle, ok = ctypes.c_void_p(), 1
+    with torch.cuda.device(device):
+        if L.tutel_amd_ep_comm_create_ipc(W, rank, ctypes.byref(handle)) != 0:
+            logging.warning("tutel_amd: %s", L.tutel_amd_last_error().decode())
+            ok = 0
+    if not _agree(ok, group, device):
+        if handle:
+            L.tutel_amd_ep_comm_destroy(handle)
+        return None
+    c = EpComm(handle, W, rank)
+    c.generic = False
+    return c
 
 
 def _create(group, device):
@@ -197,17 +327,43 @@ def _create_hosted(group, device):
     return comm
 
 
+def group_ok(group):
+    """can the native pipeline exchange over `group`?  RCCL needs the "nccl" backend; the hosted test exchange and the IPC
+    transport (TRANSPORT == "ipc") also run over a gloo rendezvous"""
+    return dist.is_initialized() and (dist.get_backend(group) == "nccl" or HOSTED or TRANSPORT == "ipc")
+
+
+def _group_key(group):
+    """cache key of a process group: its member ranks (id(group) can be reused after garbage collection)"""
+    if group is None:
+        return "world"
+    try:
+        return tuple(dist.get_process_group_ranks(group))
+    except Exception:  # noqa: BLE001
+        return id(group)
+
+
 def communicator(group, device):
     """EpComm of `group` (created on first use; collective), or None when the native path is unavailable."""
-    key = id(group) if group is not None else "world"
-    c = _comms.get(key)
-    if c is None:
-        if HOSTED and dist.get_backend(group) != "nccl":
-            c = _create_hosted(group, device)
+    key = (_group_key(group), str(device))
+    ent = _comms.get(key)
+    if ent is None:
+        if dist.get_backend(group) != "nccl":
+            c = _create_hosted(group, device) if HOSTED else (_create_ipc_only(group, device) if TRANSPORT == "ipc" else None)
+            if c is not None and TRANSPORT == "ipc" and not _attach_ipc(c, group, device) and not HOSTED:
+                c = None   # an IPC-only communicator without its transport cannot exchange anything
         else:
-            c = _create(group, device) or False
-        _comms[key] = c
-    return c or None
+            c = _create(group, device)
+            if TRANSPORT != "rccl":
+                if c is None:
+                    c = _create_ipc_only(group, device)
+                    if c is not None and not _attach_ipc(c, group, device):
+                        c = None
+                else:
+                    _attach_ipc(c, group, device)
+        ent = _comms[key] = c or False
+        _groups[key] = group   # held so that the group's identity cannot be recycled under the key
+    return ent or None
 
 
 def destroy_all():
@@ -215,7 +371,11 @@ def destroy_all():
     for c in _comms.values():
         if c:
             L.tutel_amd_ep_comm_destroy(c.handle)
+            for sg in list(c.segments.values()) + [getattr(c, "_flags", None), getattr(c, "_selfcheck", None)]:
+                if sg is not None:
+                    L.tutel_amd_ep_segment_free(sg.handle)
     _comms.clear()
+    _groups.clear()
 
 
 def plan(E, W, capacity, degree, allow_sliced=True):
@@ -233,7 +393,7 @@ def usable(layer, x, crit, degree):
     if getattr(layer, "megablocks_size", 0) > 0 and (W > 1 or not layer.is_postscore):
         return False  # row counts ride on the single-rank fused-encode route only
     if W > 1:
-        if not dist.is_initialized() or (dist.get_backend(layer.group) != "nccl" and not HOSTED):
+        if not group_ok(layer.group):
             return False  # gloo rendezvous (ranks sharing a GPU in the tests): host-staged exchange in impls/overlap.py
     return crit[4] % max(degree, 1) == 0 and degree <= 32
 
@@ -249,12 +409,12 @@ def _bucket_tokens(T):
     return 1 << (T - 1).bit_length()
 
 
-def _bucket_capacity(C, T, T_cap):
-    """rows per expert of the bucket: what the capacity grows to when the batch grows to T_cap tokens (the capacity is
-    proportional to the token count, fast_dispatch.py:188-199), rounded up to 32"""
-    C = max(int(C), 1)
-    C = (C * int(T_cap) + max(int(T), 1) - 1) // max(int(T), 1)
-    return (C + 31) // 32 * 32
+def _bucket_capacity(C):
+    """rows per expert of a workspace: the next power of two (at least 32).  A function of the capacity ALONE (scaling
+    it by T_cap / T blew up for ranks with few or no tokens under an agreed capacity -- inequivalent_tokens -- and for T < E), so
+    every rank of a group derives the same value and a workspace is never more than twice the rows any call needs"""
+    C = max(int(C), 32)
+    return 1 << (C - 1).bit_length()
 
 
 class _Workspace:
@@ -282,6 +442,17 @@ class _Workspace:
             self.bufs[name] = t
             setattr(a, name, t.data_ptr())
         buf("hid", E_loc * W * C_cap, H)
+        self.segment = None
+        if comm is not None and comm.ipc:
+            # IPC transport: the receive / return arrays live in a peer-mapped segment (same offsets on every rank); the encode
+            # and send staging arrays do not exist -- the producing kernels store into the peers' arrays directly
+            es = x.element_size()
+            recv_bytes = (E * C_cap * M * es + 255) // 256 * 256
+            sg = comm.segment(("ep", M, Mo, str(dt), E, C_cap), recv_bytes + E * C_cap * Mo * es)
+            a.recv, a.back, a.peer_seg = sg.ptr, sg.ptr + recv_bytes, sg.handle
+            self.segment = sg
+            self.args, self.comm = a, comm
+            return
         buf("send", E * C_cap, Mo)
         if not fuse:
             buf("enc", E * C_cap, M)
@@ -312,7 +483,7 @@ def _workspace(layer, static_key, T, C, make):
             cache.move_to_end(key)
             return ws
     T_cap = _bucket_tokens(T)
-    C_cap = _bucket_capacity(C, T, T_cap)
+    C_cap = _bucket_capacity(C)
     ws = make(T_cap, C_cap)
     cache[(static_key, T_cap, C_cap)] = ws
     layer.__dict__["_ep_workspace_allocations"] = layer.__dict__.get("_ep_workspace_allocations", 0) + 1
@@ -334,7 +505,8 @@ def forward(layer, x, crit, degree):
     if not with_comm:
         degree = 1  # a single rank has nothing to overlap (the reference returns expert_fn(input) there, overlap.py:16-17)
     k = crit.idx2d.shape[0]
-    key = ("ep", x.shape[1], x.dtype, x.device, crit[0], k, degree, bool(layer.is_postscore), ex.fused_activation(), ops._stream(), with_comm)
+    key = ("ep", x.shape[1], x.dtype, x.device, crit[0], k, degree, bool(layer.is_postscore), ex.fused_activation(), ops._stream(), with_comm,
+           bool(comm is not None and comm.ipc))
     ws = _workspace(layer, key, x.shape[0], crit[4], lambda Tc, Cc: _Workspace(layer, x, crit[0], Cc, k, degree, comm, Tc))
     a = ws.args
     a.T, a.capacity = x.shape[0], crit[4]
@@ -413,7 +585,7 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
         capacity = max(capacity, sizes.get(skey, 0))
     for attempt in range(4):
         key = ("moe", x.shape[1], x.dtype, x.device, logits.shape[1], logits.dtype, k, degree, bool(layer.is_postscore),
-               ex.fused_activation(), ops._stream(), with_comm)
+               ex.fused_activation(), ops._stream(), with_comm, bool(comm is not None and comm.ipc))
         ws = _workspace(layer, key, x.shape[0], capacity, lambda Tc, Cc: _MoeWorkspace(layer, x, logits, k, Cc, degree, comm, Tc))
         m = ws.margs
         a = m.ep

@@ -25,6 +25,16 @@ class GraphedForward:
             for _ in range(warmup):
                 layer(self.static_in, **forward_kwargs)
             torch.cuda.synchronize()
+            # W > 1: only the IPC transport (plain kernels + events, epochs counted on the device) replays safely.  Captured RCCL
+            # collectives replay ~200-400 times and then never complete (RCCL 2.26.6 in torch 2.10, profiles/r03_ep_streams.txt):
+            # refuse instead of handing out a graph that hangs (TUTEL_AMD_GRAPH_RCCL=1 overrides, for probing)
+            if getattr(layer, "world_size", 1) > 1:
+                import os
+                from . import ep_native
+                comm = ep_native.communicator(layer.group, example.device) if ep_native.group_ok(layer.group) else None
+                if (comm is None or not comm.ipc) and os.environ.get("TUTEL_AMD_GRAPH_RCCL", "0") != "1":
+                    raise RuntimeError("GraphedForward: an expert-parallel layer can only be captured with the IPC transport "
+                                       "(peer stores; TUTEL_AMD_EP_TRANSPORT=auto|ipc): replaying captured RCCL collectives hangs")
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.static_out = layer(self.static_in, **forward_kwargs)

@@ -250,7 +250,7 @@ class MOELayer(torch.nn.Module):
         if not fusable:
             return "generic"
         native = (allow_native and ep_native.ENABLED and not _FORCE_OVERLAP and degree <= 32 and (degree == 1 or not self.use_2dh)
-                  and (W == 1 or (dist.is_initialized() and (dist.get_backend(self.group) == "nccl" or ep_native.HOSTED))))
+                  and (W == 1 or ep_native.group_ok(self.group)))
         if stage == "before_routing":
             T, E = logits.shape
             k = min(top_k, E)
