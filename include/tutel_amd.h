@@ -76,15 +76,18 @@ int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax, int T, int
                         int normalize_gate, void *scores_out, int32_t *idx, void *gates, void *ws,
                         size_t ws_bytes, int32_t *clear_map, int clear_n, tutel_stream_t stream);
 
-/* tutel_amd_gate_topk (on logits, softmax applied) + tutel_amd_compute_location in ONE launch: the blocks meet at a grid-wide
- * barrier between the two halves (<= 128 blocks, all resident).  Same outputs, bit for bit, as the two calls; l_aux in the
- * logits' dtype.  `sync`: two uint32 words in device memory, ZERO before the first call -- the kernel leaves them zero (so a
- * HIP graph can replay it).  Applies to E <= 128 (and k * tile <= 4096 ids); otherwise returns TUTEL_AMD_ENOTSUP and launches
- * nothing -- the caller then issues the two calls.  Replaces fast_dispatch.py:143-178 in one launch. */
+/* The gate PROJECTION, softmax and top-k in ONE launch: logits = x @ wg^T (gates/top.py:20-22: `self.wg(x)` of a bias-free
+ * nn.Linear in the tokens' dtype) are computed on MFMA inside the top-k kernel, so the [T, E] logits never travel through HBM
+ * between a library GEMM and the routing kernel; everything after the logits is tutel_amd_gate_topk with apply_softmax = 1, bit for
+ * bit.  x [T, ldx] and wg [E, M] are `dtype` (TUTEL_BF16 | TUTEL_F16); the logit of (t, e) is an fp32 sum over M rounded once to
+ * `dtype`, as the nn.Linear's output is -- the ORDER of that fp32 sum is this kernel's (MFMA, 8 / (E / 32) slices of M added in
+ * order), so the last bit of a logit can differ from another GEMM's: `logits_out` (optional, [T, E]) returns what was used.
+ * Applies to E in {32, 64, 128} and M a multiple of 128 * 8 / (E / 32); otherwise returns TUTEL_AMD_ENOTSUP and launches nothing
+ * (the caller projects with a library GEMM and calls tutel_amd_gate_topk).  ws / clear_map as tutel_amd_gate_topk. */
 #define TUTEL_AMD_ENOTSUP 1001
-int tutel_amd_route(const void *logits, int dtype, int T, int E, int k, int normalize_gate, int32_t *idx, void *gates, void *ws,
-                    size_t ws_bytes, int32_t *loc, int32_t *dispatch_count, int32_t *stats, void *l_aux, int capacity,
-                    int32_t *slot_map, uint32_t *sync, tutel_stream_t stream);
+int tutel_amd_gate_proj_topk(const void *x, int ldx, const void *wg, int dtype, int T, int M, int E, int k, int normalize_gate,
+                             void *logits_out, int32_t *idx, void *gates, void *ws, size_t ws_bytes, int32_t *clear_map,
+                             int clear_n, tutel_stream_t stream);
 
 /* idx[k,T] -> loc[k,T] (stable rank of token t among tokens with the same k-th choice, queued
  * after ALL tokens' earlier choices -- fast_dispatch.py:159-171), dispatch_count[E] (:177-178),
@@ -364,7 +367,8 @@ int tutel_amd_ep_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_ep_args_t *a
  * for the common inference configuration -- softmax + top-k + locations + gshard loss (tutel_amd_gate_topk,
  * tutel_amd_compute_location with the capacity known up front, capacity_factor > 0) and then tutel_amd_ep_forward on
  * the routing just computed.  ep.slot_map / idx / loc / gates are OUTPUT buffers here ([E*C], [k,T], [k,T], [k,T] in
- * the logits dtype); ep.gate_dtype is ignored (= logits_dtype).  Dropless routing: see the last fields. */
+ * the logits dtype); ep.gate_dtype is ignored (= logits_dtype).  Dropless routing: see the last fields.  With `gate_w` the
+ * gate projection (gates/top.py:20-22) is part of the call as well. */
 typedef struct {
   tutel_amd_ep_args_t ep;
   const void *logits;        /* [T, num_experts] gate logits */
@@ -383,8 +387,9 @@ typedef struct {
   int capacity_limit, alignment, max_capacity;
   int *capacity_out;         /* host pointer, out: the capacity used (may be NULL when ep.capacity > 0); dropless: the read-back
                               * lands here (pinned memory keeps the copy asynchronous) */
-  uint32_t *route_sync;      /* NULL, or the two zero-initialised words of tutel_amd_route: top-k and locations then run as ONE
-                              * launch where that kernel applies (capacity known up front, E <= 128) */
+  const void *gate_w;        /* NULL, or the gate weight [num_experts, M] in the tokens' dtype (= logits_dtype): the projection then
+                              * runs inside the top-k kernel (tutel_amd_gate_proj_topk) and `logits` is not read (may be NULL) */
+  void *logits_out;          /* with gate_w: optional [T, num_experts] copy of the logits that were used */
 } tutel_amd_moe_args_t;
 #define TUTEL_AMD_EAGAIN 1000
 int tutel_amd_moe_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_moe_args_t *args, tutel_stream_t stream);
@@ -424,8 +429,8 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *                        (automatic: > 128 rows per expert and enough tiles to cover the chip)
  *   TUTEL_OPT_DECODE     fast_decode launch shape: bit 0 = two waves per token, bit 1 = non-temporal stores of the output
  *                        (automatic: 2)
- *   TUTEL_OPT_ROUTING    tutel_amd_moe_forward: 0 / automatic = top-k and location as two launches, 1 = the fused routing kernel
- *                        (tutel_amd_route; measured equal on MI355X, so not the default)
+ *   TUTEL_OPT_ROUTING    gate projection: 0 = library GEMM + tutel_amd_gate_topk, 1 / automatic = inside the top-k kernel
+ *                        (tutel_amd_gate_proj_topk) where that kernel applies
  *   TUTEL_OPT_GEMM_PERSIST  256 x 256 ping-pong kernel, bias operand: 0 = fetched after the K loop, 1 / automatic = before it
  *                        (32 more live registers, its L2 round trip hidden behind the loop)
  *   TUTEL_OPT_EP_STREAMS overlapped pipeline: 1 = every stage's GEMMs on ONE side stream, 2 / automatic = stages alternate between

@@ -179,6 +179,26 @@ def headline_integer_case(seed=0):
     return out
 
 
+def headline_low_precision_gate_case(dts, seed=11):
+    """BASELINE configs[1] with the gate exactly as bench.py runs it (`fp32_gate=False`: a bf16 / fp16 nn.Linear): the reference's
+    own logits, scores and routing at T = 4096, M = 2048, E = 64, k = 2.  Only the gate is built (H = 8 keeps make_problem cheap;
+    the test regenerates x / wg with the same arguments)."""
+    dtype = DT[dts]
+    T, M, H, E, k = 4096, 2048, 8, 64, 2
+    layer, (x, wg, *_rest) = build_reference_layer(T, M, H, E, k, 1.0, dtype, False, True, True, seed)
+    with torch.no_grad():
+        logits = layer.gates[0](x)
+        assert logits.dtype == dtype
+        scores = torch.softmax(logits, dim=1)
+        crit, l_aux = ref_moe.top_k_routing(scores, k, capacity_factor=1.0)
+    return dict(meta=np.array([T, M, H, E, k, seed], dtype=np.int64), dtype=np.array([dts]),
+                in_checksum=np.array([checksum([x, wg])]), logits=np_(logits) if dtype == torch.bfloat16 else logits.view(torch.int16).numpy(),
+                scores=np_(scores) if dtype == torch.bfloat16 else scores.view(torch.int16).numpy(),
+                idx=np.stack([np_(i) for i in crit[1]]).astype(np.int32), loc=np.stack([np_(i) for i in crit[2]]).astype(np.int32),
+                gates=np.stack([(g.view(torch.int16)).numpy() for g in crit[3]]), capacity=np.array([crit[4]]),
+                dispatch_count=np_(crit[5].to(torch.int32)), l_aux=np.array([float(l_aux)]))
+
+
 def train_losses_case(E_loc=2, k=2, steps=4, T=1024, M=256, H=256, seed=5):
     """A short training replay in the style of the reference's golden-loss tests
     (tests/test_tutel.py:94-148 over examples/helloworld.py:126-146): fwd + bwd + SGD, fp32."""
@@ -461,7 +481,14 @@ def check_product_host_logic_against_reference():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--only-headline-gate", action="store_true", help="(re)write only headline_gate_*.npz")
     args = ap.parse_args()
+    if args.only_headline_gate:
+        for dts in ("bfloat16", "float16"):
+            out = headline_low_precision_gate_case(dts)
+            np.savez_compressed(os.path.join(HERE, f"headline_gate_{dts}.npz"), **out)
+            print("wrote headline_gate", dts, int(out["capacity"][0]), float(out["l_aux"][0]))
+        return
     if args.check:
         n = check_oracle_against_reference()
         n += check_product_host_logic_against_reference()
@@ -479,6 +506,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"noisy_{name}.npz"), **out)
         print("wrote noisy", name, float(out["l_aux"][0]))
     np.savez_compressed(os.path.join(HERE, "headline_integers.npz"), **headline_integer_case())
+    for dts in ("bfloat16", "float16"):
+        np.savez_compressed(os.path.join(HERE, f"headline_gate_{dts}.npz"), **headline_low_precision_gate_case(dts))
     # batch-prioritised routing (fast_dispatch.py:138-141,155-157): tokens ranked by -max score get buckets first
     g = torch.Generator().manual_seed(31)
     bpr = {}

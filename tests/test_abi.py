@@ -61,11 +61,17 @@ def test_argument_errors_are_reported_not_enqueued(L):
 
 def test_round3_entry_points_reject_bad_arguments(L):
     from tutel_amd import _lib
-    # one-launch routing: bad dtype is an error; a shape the fused kernel does not take is ENOTSUP (nothing launched, no error text needed)
-    assert L.tutel_amd_route(None, 99, 64, 8, 2, 1, None, None, None, 0, None, None, None, None, 4, None, None, None) not in (0, _lib.ENOTSUP)
+    # gate projection inside the top-k kernel: bad dtype is an error; a shape the kernel does not take is ENOTSUP (nothing launched)
+    assert L.tutel_amd_gate_proj_topk(None, 2048, None, 99, 64, 2048, 64, 2, 1, None, None, None, None, 0, None, 0, None) not in (0, _lib.ENOTSUP)
     assert b"dtype" in L.tutel_amd_last_error()
-    assert L.tutel_amd_route(None, _lib.F32, 64, 256, 2, 1, None, None, None, 0, None, None, None, None, 4, None, None, None) == _lib.ENOTSUP
-    assert L.tutel_amd_route(None, _lib.F32, 64, 8, 2, 1, None, None, None, 0, None, None, None, None, 4, None, None, None) not in (0, _lib.ENOTSUP)  # null pointers
+    assert L.tutel_amd_gate_proj_topk(None, 2048, None, _lib.BF16, 64, 2048, 8, 2, 1, None, None, None, None, 0, None, 0, None) == _lib.ENOTSUP
+    assert L.tutel_amd_gate_proj_topk(None, 2048, None, _lib.F32, 64, 2048, 64, 2, 1, None, None, None, None, 0, None, 0, None) == _lib.ENOTSUP
+    assert L.tutel_amd_gate_proj_topk(None, 2048, None, _lib.BF16, 64, 2048, 64, 2, 1, None, None, None, None, 0, None, 0, None) not in (0, _lib.ENOTSUP)  # null pointers
+    # IPC transport: a communicator without it refuses, segments check their arguments
+    assert L.tutel_amd_ep_ipc_exchange(None, None, None, 16, 0, None) != 0 and b"IPC" in L.tutel_amd_last_error()
+    assert L.tutel_amd_ep_segment_open(None, 2, 0, None, 64) != 0
+    assert L.tutel_amd_ep_comm_create_ipc(17, 0, None) != 0 and L.tutel_amd_ep_comm_has_ipc(None) == 0
+    assert L.tutel_amd_ep_flag_bytes() >= 2 * 33 * 16 * 4
     # variable-size collectives need a communicator
     u64 = (ctypes.c_uint64 * 2)(8, 8)
     assert L.tutel_amd_ep_all_to_all_v(None, None, None, u64, u64, None) != 0 and b"communicator" in L.tutel_amd_last_error()

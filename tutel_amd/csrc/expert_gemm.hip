@@ -384,11 +384,16 @@ __device__ __forceinline__ void glds16(const uint16_t *g, uint16_t *l, bool nt) 
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
-template <typename T, bool W_KMAJOR, int ACT, bool NT, bool ROT>
+// RING (k-major weights): the weight tiles go through a THREE-slot ring and the K loop never drains its DMA -- a counted
+// s_waitcnt vmcnt(4) + bare s_barrier per K-tile instead of __syncthreads (= vmcnt(0) + barrier): the weight tile of K-tile
+// kt + 2 (HBM) is issued two tiles ahead, the token tile of kt + 1 (L2) one tile ahead; 2 x 16 KB + 3 x 16 KB = 80 KB per block,
+// still two blocks per CU.  Same k order, same bits.
+template <typename T, bool W_KMAJOR, int ACT, bool NT, bool ROT, bool RING = false>
 __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArgs p) {
+  static_assert(!RING || W_KMAJOR, "the ring variant is for k-major weights");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [2][GL_STAGE]
-  uint16_t *sW = sA + 2 * GL_STAGE;                   // [2][GL_STAGE]
+  uint16_t *sW = sA + 2 * GL_STAGE;                   // [2][GL_STAGE]  (RING: [3][GL_STAGE])
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -509,6 +514,53 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
         acc[ni][mi] = Mma<T>::run(FW[ni], FA[mi], acc[ni][mi]);                        \
   } while (0)
 
+#define GL_ISSUE_A(KT, BUF)                                                            \
+  do {                                                                                 \
+    int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
+    const size_t ao_ = (size_t)kr_ * GL_BK;                                            \
+    uint16_t *da_ = sA + (BUF) * GL_STAGE + piece0;                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
+  } while (0)
+#define GL_ISSUE_W(KT, BUF)                                                            \
+  do {                                                                                 \
+    int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
+    const size_t wo_ = (size_t)kr_ * w_step;                                           \
+    uint16_t *dw_ = sW + (BUF) * GL_STAGE + piece0;                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, NT); \
+  } while (0)
+
+  if (RING) {
+    // in flight per wave, in issue order, when K-tile kt is awaited: [A(kt) x4] [W(kt+1) x4] -- W(kt) is older than both
+    GL_ISSUE_A(0, 0);
+    GL_ISSUE_W(0, 0);
+    if (nk > 1) GL_ISSUE_W(1, 1);
+    int wslot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int abuf = kt & 1;
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt have landed; every wave is done reading the slots refilled below
+      if (kt + 1 < nk) GL_ISSUE_A(kt + 1, abuf ^ 1);
+      if (kt + 2 < nk) GL_ISSUE_W(kt + 2, wslot == 0 ? 2 : wslot - 1);  // (wslot + 2) % 3
+      const uint16_t *ca = sA + abuf * GL_STAGE, *cw = sW + wslot * GL_STAGE;
+      u32x4 fa[4][2], fw[4][2];
+      GL_LOAD_FRAGS(fa[0], fw[0], 0);
+      GL_LOAD_FRAGS(fa[1], fw[1], 1);
+      GL_LOAD_FRAGS(fa[2], fw[2], 2);
+      GL_LOAD_FRAGS(fa[3], fw[3], 3);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      GL_MMA(fa[0], fw[0]);
+      GL_MMA(fa[1], fw[1]);
+      GL_MMA(fa[2], fw[2]);
+      GL_MMA(fa[3], fw[3]);
+      __builtin_amdgcn_sched_barrier(0);
+      wslot = wslot == 2 ? 0 : wslot + 1;
+    }
+    gemm_epilogue<T, ACT>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
+    return;
+  }
+
   GL_ISSUE(0, 0);
   __syncthreads();  // with a DMA in flight this is vmcnt(0) + barrier: tile 0 is in LDS stage 0
 
@@ -532,6 +584,8 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
     __syncthreads();  // all waves done with stage `buf`; next tile's DMA has landed (vmcnt(0))
   }
 #undef GL_ISSUE
+#undef GL_ISSUE_A
+#undef GL_ISSUE_W
 #undef GL_LOAD_FRAGS
 #undef GL_MMA
 
@@ -650,14 +704,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&ac
 // stage), 2 -> 256 x 128 (one sub-tile; for launches whose 256 x 256 grid would leave CUs idle).
 // BUF: LDS-DMA through buffer descriptors (no VALU on the issue path) and the epilogue through LDS -- the two levers of
 // the ping-pong kernel below that carry over to this lockstep structure (k-major weights, 32-bit addressable operands).
-template <typename T, bool W_KMAJOR, int ACT, int NI, int NS, bool BUF = false>
-__global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs p) {
+// BM = 128 (4 waves, 2 x 2; round 4): the 128-row HBM-bound regime on a 128 x 256 tile -- every row of an expert and TWO of its
+// 128-column weight tiles per block, so the token tile crosses L2 -> LDS once per 256 columns instead of once per 128, on a
+// three-slot ring (3 x 48 KB, two K-tiles = 96 KB of DMA in flight per CU, never drained), one 4-wave block per CU.
+template <typename T, bool W_KMAJOR, int ACT, int NI, int NS, bool BUF = false, int BM = GB_BM>
+__global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) {
+  constexpr int NW = BM / 32;               // waves: (BM / 64) row groups x 2 column groups
   constexpr int NSUB = NI / 2;              // 128-column weight sub-tiles per stage
-  constexpr int WPW = 2 * NSUB;             // weight DMA pieces per wave and stage
+  constexpr int WPW = 16 * NSUB / NW;       // weight DMA pieces per wave and stage
   constexpr int BN = NI * 64;               // block tile columns
+  constexpr int A_STAGE = (BM / 128) * GL_STAGE;  // elements of the [BM][64] token tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [NS][2 * GL_STAGE]      (256 rows x 64 k)
-  uint16_t *sW = sA + NS * 2 * GL_STAGE;              // [NS][NSUB][GL_STAGE]
+  uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [NS][A_STAGE]           (BM rows x 64 k)
+  uint16_t *sW = sA + NS * A_STAGE;                   // [NS][NSUB][GL_STAGE]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -673,7 +732,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
   const int mt = w % p.ntm;
   const int nt = (w / p.ntm) % p.ntn;
   const int e = w / (p.ntm * p.ntn);
-  const int m0 = mt * GB_BM, n0 = nt * BN;
+  const int m0 = mt * BM, n0 = nt * BN;
 
   int row_limit = p.R;
   if (p.row_counts != nullptr) {
@@ -773,7 +832,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
 #define GB_ISSUE(KT, STG)                                                              \
   do {                                                                                 \
     int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
-    uint16_t *da_ = sA + (STG) * 2 * GL_STAGE + piece_a, *dw_ = sW + (STG) * NSUB * GL_STAGE + piece_w; \
+    uint16_t *da_ = sA + (STG) * A_STAGE + piece_a, *dw_ = sW + (STG) * NSUB * GL_STAGE + piece_w; \
     if (BUF) {                                                                         \
       const int ao_ = kr_ * (GL_BK * 2), wo_ = (int)(kr_ * (w_step * 2));              \
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) bdma16<false>(rs_a, a_off[i_], ao_, da_ + i_ * 512); \
@@ -813,7 +872,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_big_kernel(GemmArgs
 
 #define GB_TILE(BUF)                                                                   \
   do {                                                                                 \
-    const uint16_t *ca = sA + (BUF) * 2 * GL_STAGE, *cw = sW + ((BUF) * NSUB + wsub) * GL_STAGE; \
+    const uint16_t *ca = sA + (BUF) * A_STAGE, *cw = sW + ((BUF) * NSUB + wsub) * GL_STAGE; \
     /* two half-tiles: fragments of two k-steps, then their MFMAs; the partner wave on the SIMD runs its MFMAs \
        while this one waits for LDS */                                                 \
     u32x4 fa[2][2], fw[2][NI];                                                         \
@@ -1133,17 +1192,36 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   gemm_epilogue_lds<T, ACT>(p, acc, bias_r, smem + wid * (64 * EP_PITCH), e, m0, n0, wm, wn, lane, row_limit);
 }
 
+// > 64 KB of dynamic LDS needs hipFuncSetAttribute -- once per (kernel, DEVICE): the attribute belongs to the function object
+// of the current device (a per-process flag left every device but the first without it)
+static bool lds_optin(const void *kern, size_t lds) {
+  constexpr int MAXK = 256, MAXD = 64;
+  static const void *seen[MAXK];
+  static uint64_t done[MAXK];  // bit d: device d has the attribute
+  static int n = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXD) dev = -1;
+  int i = 0;
+  for (; i < n; ++i)
+    if (seen[i] == kern) break;
+  if (i < n && dev >= 0 && (done[i] >> dev & 1)) return true;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipGetLastError();
+  if (e != hipSuccess) {
+    tutel_set_error("tutel_amd_expert_gemm: cannot opt in to %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    return false;
+  }
+  if (i == n && n < MAXK) { seen[n] = kern; done[n] = 0; ++n; }
+  if (i < MAXK && dev >= 0) done[i] |= 1ull << dev;
+  return true;
+}
+
 template <typename T, int ACT, bool W_ONCE, bool RAGGED = false, bool EARLY_BIAS = false>
 static int launch_pp_cfg(const GemmArgs &b, hipStream_t st) {
   const size_t lds = (size_t)8 * 64 * EP_PITCH;  // 136 KB: the epilogue staging (8 waves x 64 rows x 272 B) > the two K-tile buffers (128 KB)
   static_assert((size_t)8 * 64 * EP_PITCH >= (size_t)2 * PP_BUF * 2, "LDS request must cover the K-tile buffers");
   auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, RAGGED, EARLY_BIAS>;
-  static bool optin = false;
-  if (!optin) {
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipGetLastError();
-    optin = true;
-  }
+  if (!lds_optin((const void *)kern, lds)) return -1;
   hipLaunchKernelGGL(kern, dim3(b.E_loc * b.ntm * b.ntn), dim3(GB_THREADS), lds, st, b);
   TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
   return 0;
@@ -1164,21 +1242,16 @@ static int launch_pp(const GemmArgs &a, hipStream_t st) {
   return ragged ? launch_pp_cfg<T, ACT, false, true>(b, st) : (early ? launch_pp_cfg<T, ACT, false, false, true>(b, st) : launch_pp_cfg<T, ACT, false>(b, st));
 }
 
-template <typename T, bool KM, int ACT, int NI, int NS = 2, bool BUF = false>
+template <typename T, bool KM, int ACT, int NI, int NS = 2, bool BUF = false, int BM = GB_BM>
 static int launch_big(const GemmArgs &a, hipStream_t st) {
   GemmArgs b = a;
-  b.ntm = (a.R + GB_BM - 1) / GB_BM;
+  b.ntm = (a.R + BM - 1) / BM;
   b.ntn = (a.N + NI * 64 - 1) / (NI * 64);
-  const size_t lds_k = (size_t)NS * (2 + NI / 2) * GL_STAGE * 2, lds_e = BUF ? (size_t)8 * 64 * (NI * 64 + 16) : 0;
+  const size_t lds_k = (size_t)NS * (BM / 128 + NI / 2) * GL_STAGE * 2, lds_e = BUF ? (size_t)(BM / 32) * 64 * (NI * 64 + 16) : 0;
   const size_t lds = lds_k > lds_e ? lds_k : lds_e;
-  auto kern = expert_gemm_big_kernel<T, KM, ACT, NI, NS, BUF>;
-  static bool optin = false;
-  if (!optin) {
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipGetLastError();
-    optin = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(a.E_loc * b.ntm * b.ntn), dim3(GB_THREADS), lds, st, b);
+  auto kern = expert_gemm_big_kernel<T, KM, ACT, NI, NS, BUF, BM>;
+  if (!lds_optin((const void *)kern, lds)) return -1;
+  hipLaunchKernelGGL(kern, dim3(a.E_loc * b.ntm * b.ntn), dim3(BM * 2), lds, st, b);
   TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
   return 0;
 }
@@ -1187,6 +1260,17 @@ template <typename T, bool KM, int ACT>
 static int launch_glds(const GemmArgs &a, int grid, hipStream_t st) {
   hipLaunchKernelGGL((expert_gemm_glds_kernel<T, KM, ACT, true, true>), dim3(grid), dim3(GM_THREADS),
                      (size_t)4 * GL_STAGE * 2, st, a);
+  TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
+  return 0;
+}
+
+// the three-slot weight ring of the 128 x 128 LDS-DMA kernel (k-major weights): 80 KB of LDS per block
+template <typename T, int ACT>
+static int launch_glds_ring(const GemmArgs &a, int grid, hipStream_t st) {
+  const size_t lds = (size_t)5 * GL_STAGE * 2;
+  auto kern = expert_gemm_glds_kernel<T, true, ACT, true, true, true>;
+  if (!lds_optin((const void *)kern, lds)) return -1;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_THREADS), lds, st, a);
   TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
   return 0;
 }
@@ -1222,12 +1306,7 @@ template <typename T, bool KM, int ACT>
 static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
   const size_t lds = gemm_lds_bytes(KM);
   auto kern = expert_gemm_kernel<T, KM, ACT, true, true>;
-  static bool optin = false;  // one flag per instantiation: > 64 KiB of dynamic LDS needs the opt-in
-  if (!optin) {
-    if (lds > 65536) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipGetLastError();
-    optin = true;
-  }
+  if (lds > 65536 && !lds_optin((const void *)kern, lds)) return -1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_THREADS), lds, st, a);
   TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
   return 0;
@@ -1271,7 +1350,11 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
     if (KM && (big == 3 || (big < 0 && a.R > GM_BM && t128 >= 192)))
       return a.fits32 && tutel_get_option(TUTEL_OPT_GEMM_IMPL) != 2 ? launch_big<T, true, ACT, 2, 3, true>(a, st) : launch_big<T, true, ACT, 2, 3>(a, st);
   }
-  const bool use_dma = impl < 0 ? KM : (impl == 1);
+  // round 4 A/B (TUTEL_OPT_GEMM_IMPL): 3 = the three-slot weight ring on the 128 x 128 tile, 4 = the 128 x 256 tile on a three-slot
+  // ring (one 4-wave block per CU); both k-major only, both bit-identical to the others
+  if (KM && impl == 3) return launch_glds_ring<T, ACT>(a, grid, st);
+  if (KM && impl == 4 && a.fits32 && a.N >= 256) return launch_big<T, true, ACT, 4, 3, true, 128>(a, st);
+  const bool use_dma = impl < 0 ? KM : (impl == 1 || impl >= 3);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
   return launch_cfg<T, KM, ACT>(a, grid, st);
 }

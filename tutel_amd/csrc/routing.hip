@@ -239,8 +239,9 @@ __global__ __launch_bounds__(RT_THREADS) void tile_hist_kernel(const int32_t *__
 }
 
 // -------------------------------------------------------------------------------------------
-// K2: locations.  The three phases are device functions over NW waves so that the stand-alone kernel (4 waves) and the fused
-// routing kernel below (16 waves, after its grid-wide barrier) run the same code.
+// K2: locations.  The three phases are device functions over NW waves.  (Round 3 also ran them from inside the top-k kernel
+// behind a hand-rolled grid barrier; measured equal to two launches, and a grid barrier without a residency check is a hang
+// waiting for a partitioned device, so round 4 removed it.)
 // -------------------------------------------------------------------------------------------
 // COH = the fused kernel: data another block of the SAME launch wrote (or will overwrite) moves with device-scope relaxed atomics
 // (sc1 accesses: coherent across the XCDs' L2s without a cache-wide write-back / invalidate -- a device-scope release + acquire
@@ -458,35 +459,112 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
 // -------------------------------------------------------------------------------------------
 #define GQ_LPT 16
 #define GQ_THREADS 1024
-// FUSED: the same block goes on to compute the locations (the whole of location_kernel) after a grid-wide barrier -- top-k,
-// compute_location, the slot map, dispatch counts and the loss in ONE launch.  The barrier needs every block of the grid
-// resident at once: the grid is at most RT_MAX_TILES = 128 blocks (one per CU on a 256-CU part; blocks are dispatched in index
-// order and a spinning block only ever waits for blocks that were dispatched before it or are about to be).  `sync` points to two
-// zero-initialised words: arrivals and departures; the last block to leave resets both, so the words are zero again when the
-// kernel ends (safe to replay from a HIP graph).  Cross-block visibility: everything one block writes and another reads inside
-// the launch (tile histograms, column sums, the slot map's clear and scatter) moves with device-scope relaxed atomics (sc1),
-// see ld_i32 / st_i32 above -- a release / acquire fence pair instead costs 22 us (it writes back / invalidates the whole L2).
-// Measured equal to the two launches (17.8 vs 9.6 + 8.6 us): opt-in, TUTEL_OPT_ROUTING = 1.
-struct FusedLoc {
-  int32_t *loc, *dispatch_count, *stats;
-  void *l_aux;
-  int l_aux_dtype, capacity, ntiles;
-  int32_t *slot_map;
-  unsigned int *sync;
+
+typedef __attribute__((ext_vector_type(16))) float rt_f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 rt_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 rt_f16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t rt_u32x4;
+template <typename T> struct RtMma;
+template <> struct RtMma<bf16_t> {
+  __device__ static __forceinline__ rt_f32x16 run(rt_u32x4 a, rt_u32x4 b, rt_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rt_bf16x8, a), __builtin_bit_cast(rt_bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct RtMma<f16_t> {
+  __device__ static __forceinline__ rt_f32x16 run(rt_u32x4 a, rt_u32x4 b, rt_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rt_f16x8, a), __builtin_bit_cast(rt_f16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct RtMma<float> {  // (never instantiated with NE > 0; keeps the template well-formed)
+  __device__ static __forceinline__ rt_f32x16 run(rt_u32x4, rt_u32x4, rt_f32x16 c) { return c; }
+};
+template <> struct RtMma<double> {
+  __device__ static __forceinline__ rt_f32x16 run(rt_u32x4, rt_u32x4, rt_f32x16 c) { return c; }
 };
 
-template <typename T, int EPQ, bool FUSED>
+// the gate projection of one 64-token pass: wave (th, ne, ks) leaves its 32 x 32 fp32 partial (tokens th*32.., experts ne*32..,
+// K slice ks) in s_part[ks][token][E + 1].  A function of its own, not inlined: inside the top-k kernel's token loop hipcc ran
+// out of the block's 128-VGPR budget and drained its loads every iteration.
+template <typename T, int NE>
+__device__ __attribute__((noinline)) void gate_proj_partials(const T *__restrict__ in, const T *__restrict__ wg, float *s_part, int ts, int Tn,
+                                                             int E, int M, int ldx) {
+  constexpr int KS = 8 / NE;
+  const int EP = E + 1;
+  const int tid = threadIdx.x;
+  const int wid = tid >> 6, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+  const int th = wid & 1, ne = (wid >> 1) % NE, ks = (wid >> 1) / NE;
+  const int klen = M / KS, steps = klen / 16;      // host guarantees M % (16 * KS * 8) == 0: steps is a multiple of 8
+  const uint16_t *xa = reinterpret_cast<const uint16_t *>(in) + (size_t)min(ts + th * 32 + l31, Tn - 1) * ldx + ks * klen + kg * 8;
+  const uint16_t *wa = reinterpret_cast<const uint16_t *>(wg) + (size_t)(ne * 32 + l31) * M + ks * klen + kg * 8;
+  rt_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // three register sets of 2 steps (4 x 16-byte loads each): the loads of the next two batches are issued before the MFMAs
+  // of the current one, so 8-12 loads per wave (128-192 KB per CU with 16 waves) are in flight throughout.  Straight-line
+  // code with scheduling barriers: left alone, hipcc interleaves loads and MFMAs with 3-4 loads in flight; with larger
+  // batches the block's 128-VGPR budget (1024 threads) makes it rotate registers and drain the loads every iteration.
+  rt_u32x4 fa0[2], fb0[2], fa1[2], fb1[2], fa2[2], fb2[2];
+#define GP_LOAD(FA, FB, S0)                                                                    \
+  do {                                                                                     \
+    const int s_ = (S0) < steps ? (S0) : steps - 2;   /* past the end: re-read the last batch, unused */ \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                        \
+      FA[u] = *(const __attribute__((address_space(1))) rt_u32x4 *)(wa + (s_ + u) * 16);   \
+      FB[u] = *(const __attribute__((address_space(1))) rt_u32x4 *)(xa + (s_ + u) * 16);   \
+    }                                                                                      \
+  } while (0)
+#define GP_MMA(FA, FB) do { _Pragma("unroll") for (int u = 0; u < 2; ++u) acc = RtMma<T>::run(FA[u], FB[u], acc); } while (0)
+#define GP_STEP(CUR_A, CUR_B, NXT_A, NXT_B, S0)                                                \
+  do {                                                                                     \
+    GP_LOAD(NXT_A, NXT_B, S0);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    GP_MMA(CUR_A, CUR_B);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  } while (0)
+  GP_LOAD(fa0, fb0, 0);
+  GP_LOAD(fa1, fb1, 2);
+  int s0 = 0;
+  for (; s0 + 6 <= steps; s0 += 6) {   // sets rotate 0 -> 1 -> 2: the batch loaded now is consumed two batches later
+    GP_STEP(fa0, fb0, fa2, fb2, s0 + 4);
+    GP_STEP(fa1, fb1, fa0, fb0, s0 + 6);
+    GP_STEP(fa2, fb2, fa1, fb1, s0 + 8);
+  }
+  // steps is a multiple of 8, so steps % 6 is 2 or 4 (or 0): the remaining batches are in sets 0 (and 1)
+  if (s0 < steps) { GP_MMA(fa0, fb0); s0 += 2; }
+  if (s0 < steps) { GP_MMA(fa1, fb1); s0 += 2; }
+#undef GP_STEP
+#undef GP_LOAD
+#undef GP_MMA
+  // the lane holds, for token th*32 + l31, experts ne*32 + 8*rg + 4*kg + r
+  // (explicit address spaces: through the generic pointers of a non-inlined function these would be FLAT accesses, which count
+  // on both vmcnt and lgkmcnt and made hipcc drain every load before each MFMA batch)
+  __attribute__((address_space(3))) float *pp =
+      (__attribute__((address_space(3))) float *)(s_part + ((size_t)ks * 64 + th * 32 + l31) * EP + ne * 32 + kg * 4);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pp[rg * 8 + r] = acc[rg * 4 + r];
+}
+
+// NE > 0 (round 4): the GATE PROJECTION runs inside this kernel (gates/top.py:20-22 `logits = wg(x)` + moe_layer.py:290 softmax
+// + fast_dispatch.py:146-151 top-k in ONE launch; the [T, E] logits never make an HBM round trip between a library GEMM and
+// this kernel).  NE = E / 32 expert tiles of v_mfma_f32_32x32x16; the block's 16 waves are 2 (32-token halves of the 64-token
+// pass) x NE (32-expert tiles) x KS = 8 / NE slices of the model dimension; every wave streams its fragments straight from
+// global memory (x from HBM, wg from L2: 16 loads in flight per wave, 256 KB per CU) and leaves a 32 x 32 fp32 partial in LDS;
+// the logit of (token, expert) is the sum of its KS partials in slice order, rounded once to T -- what a bf16 / fp16 nn.Linear
+// returns, up to the order of the fp32 sum (the checker is fed these logits, `logits_out`).  in / ldx: the tokens [T, ldx];
+// wg: [E, M] row-major, both of type T.
+template <typename T, int EPQ, int NE>
 __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
-    int clear_n, FusedLoc fl) {
+    int clear_n, const T *__restrict__ wg, int M, int ldx, T *__restrict__ logits_out) {
   using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ES = GQ_LPT * EPQ + 1;                                    // padded row of the score tile
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);                // [k][E]
   float *s_sc = reinterpret_cast<float *>(smem) + (size_t)k * E;      // [64][ES]
-  int32_t *s_idx = reinterpret_cast<int32_t *>(s_sc + 64 * ES);       // FUSED: [k][tile] expert ids of the tile
+  float *s_part = s_sc + 64 * ES;                                     // NE > 0: [KS][64][E + 1] partial logits
 
   const int tid = threadIdx.x, q = tid & (GQ_LPT - 1), tl = tid / GQ_LPT;  // tl = token slot 0..63
   const int b = blockIdx.x;
@@ -495,7 +573,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
   if (clear_map != nullptr) {
     const int per = (clear_n + (int)gridDim.x - 1) / (int)gridDim.x;
     const int c0 = b * per, c1 = min(clear_n, c0 + per);
-    for (int i = c0 + tid; i < c1; i += GQ_THREADS) st_i32<FUSED>(clear_map + i, -1);   // (FUSED: other blocks of this launch fill it)
+    for (int i = c0 + tid; i < c1; i += GQ_THREADS) clear_map[i] = -1;
   }
   for (int i = tid; i < k * E; i += GQ_THREADS) s_hist[i] = 0;
   float colsum = 0.f;  // thread e < E accumulates column e over the tile, in token order
@@ -505,7 +583,27 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     const int t = ts + tl;
     const bool live = t < t1;
     CT v[EPQ];
-    {
+    if constexpr (NE > 0) {
+      constexpr int KS = 8 / NE;
+      const int EP = E + 1;
+      gate_proj_partials<T, NE>(in, wg, s_part, ts, Tn, E, M, ldx);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < EPQ; ++j) {
+        const int e = q * EPQ + j;
+        float sum = 0.f;
+        if (e < E) {
+          sum = s_part[(size_t)tl * EP + e];
+#pragma unroll
+          for (int s2 = 1; s2 < KS; ++s2) sum += s_part[((size_t)s2 * 64 + tl) * EP + e];
+          const T r = Elem<T>::from_f32(sum);
+          if (logits_out != nullptr && live) logits_out[(size_t)t * E + e] = r;
+          v[j] = Elem<T>::to_f32(r);
+        } else {
+          v[j] = -INFINITY;
+        }
+      }
+    } else {
       const T *row = in + (size_t)min(t, Tn - 1) * E + q * EPQ;
 #pragma unroll
       for (int j = 0; j < EPQ; ++j) {
@@ -570,7 +668,6 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       if (c == q) myg = bv;                              // choice c parked on lane c of the row (k <= 16)
       if (q == 0 && live) {
         idx[(size_t)c * Tn + t] = be;
-        if (FUSED) s_idx[c * tile + (t - t0)] = be;
         atomicAdd(&s_hist[c * E + be], 1);
       }
     }
@@ -591,41 +688,8 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     }
     __syncthreads();
   }
-  for (int i = tid; i < k * E; i += GQ_THREADS) st_i32<FUSED>(ws_hist + (size_t)b * k * E + i, s_hist[i]);
-  if (tid < E) st_f32<FUSED>(ws_colsum + (size_t)b * E + tid, colsum);
-  if (!FUSED) return;
-
-  // ---- grid-wide barrier: every tile's histogram (and column sums, and its slice of the cleared slot map) is published.
-  // Everything the blocks exchange goes through device-scope (sc1) accesses, so no cache-wide fence is needed: each wave waits
-  // for its own stores to be acknowledged (workgroup-scope release = s_waitcnt), the block meets, one thread signals.
-  const int ntiles = fl.ntiles;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __syncthreads();
-  if (tid == 0) {
-    __hip_atomic_fetch_add(&fl.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(&fl.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntiles) __builtin_amdgcn_s_sleep(1);
-    // departures: the last block out puts both words back to zero (no block can still be spinning on the arrivals then)
-    const unsigned left = __hip_atomic_fetch_add(&fl.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == (unsigned)ntiles - 1) {
-      __hip_atomic_store(&fl.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&fl.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (compiler + wave ordering; the loads below are sc1 themselves)
-
-  // ---- the location phases (== location_kernel), 16 waves.  LDS: s_cur / s_tot take over the score tile (dead now)
-  int32_t *s_cur = reinterpret_cast<int32_t *>(s_sc);                         // [k][E]
-  int32_t *s_tot = s_cur + (size_t)k * E;                                    // [k][E]
-  float *s_parts = reinterpret_cast<float *>(s_idx + (size_t)k * tile);       // [RT_THREADS] at least
-  __shared__ float s_red[RT_WAVES];
-  __shared__ int s_redi[RT_WAVES];
-  float cs_none[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) cs_none[u] = 0.f;
-  loc_prefix<GQ_THREADS / 64, true>(tid, b, E, k, ntiles, ws_hist, s_cur, s_tot, fl.dispatch_count);
-  loc_rank<GQ_THREADS / 64, true>(tid, t0, t1, Tn, E, k, idx, s_idx, tile, -1, false, s_cur, fl.loc, fl.capacity, fl.slot_map);
-  if (b == 0) loc_finish<GQ_THREADS / 64, true>(tid, Tn, E, k, ntiles, ws_colsum, s_tot, s_parts, s_red, s_redi, cs_none, false, fl.stats, fl.l_aux, fl.l_aux_dtype);
+  for (int i = tid; i < k * E; i += GQ_THREADS) ws_hist[(size_t)b * k * E + i] = s_hist[i];
+  if (tid < E) ws_colsum[(size_t)b * E + tid] = colsum;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -671,15 +735,19 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cumsum_kernel(const int32_t *__
 // -------------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------------
-// the fused routing kernel applies to the small-E layout (E <= 128) while the tile's expert ids fit in LDS
-static bool route_fusable(int Tn, int E, int k) {
-  return E <= 128 && (size_t)k * rt_tile(Tn) * 4 <= 16384;
+// gate projection inside the top-k kernel: which (dtype, E, M) it takes (see gate_topk_quad_kernel, NE > 0)
+static bool gate_proj_ok(int dtype, int E, int M) {
+  if (dtype != TUTEL_BF16 && dtype != TUTEL_F16) return false;
+  if (E != 32 && E != 64 && E != 128) return false;
+  const int ks = 8 / (E / 32);
+  return M >= 128 * ks && M % (128 * ks) == 0;   // every wave's K slice is a whole number of 8-step (128-element) batches
 }
 
 template <typename T>
 static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, int k, int normalize,
                             void *scores_out, int32_t *idx, void *gates, void *ws,
-                            int32_t *clear_map, int clear_n, hipStream_t st, const FusedLoc *fused = nullptr) {
+                            int32_t *clear_map, int clear_n, hipStream_t st, const void *wg = nullptr, int M = 0, int ldx = 0,
+                            void *logits_out = nullptr) {
   const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
@@ -688,31 +756,30 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
     const int epq = (E + GQ_LPT - 1) / GQ_LPT;                 // 1..8
     const int epq_t = epq <= 1 ? 1 : (epq <= 2 ? 2 : (epq <= 4 ? 4 : 8));
     const size_t lds_q = ((size_t)k * E + (size_t)64 * (GQ_LPT * epq_t + 1)) * 4;
-    // fused: + the tile's expert ids [k][tile] + the column-sum parts of the loss [RT_THREADS]
-    const size_t lds_f = lds_q + ((size_t)k * tile + RT_THREADS) * 4;
-    FusedLoc fl = {};
-    if (fused != nullptr) fl = *fused;
-    fl.ntiles = nt;
-#define GQ_LAUNCH(EPQ)                                                                         \
+#define GQ_LAUNCH(EPQ, NE)                                                                     \
     do {                                                                                       \
-      if (fused != nullptr)                                                                    \
-        hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ, true>), dim3(nt), dim3(GQ_THREADS), lds_f, st,  \
-                           (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,      \
-                           idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, fl);                     \
-      else                                                                                     \
-        hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ, false>), dim3(nt), dim3(GQ_THREADS), lds_q, st, \
-                           (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,      \
-                           idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, fl);                     \
+      auto kern_ = gate_topk_quad_kernel<T, EPQ, NE>;                                          \
+      const size_t lds_ = lds_q + ((NE) > 0 ? (size_t)(8 / ((NE) > 0 ? (NE) : 1)) * 64 * (E + 1) * 4 : 0); \
+      if (lds_ > 65536) {                                                                      \
+        (void)hipFuncSetAttribute((const void *)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+        (void)hipGetLastError();                                                               \
+      }                                                                                        \
+      hipLaunchKernelGGL(kern_, dim3(nt), dim3(GQ_THREADS), lds_, st,                          \
+                         (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,        \
+                         idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, (const T *)wg, M, ldx, (T *)logits_out); \
     } while (0)
-    if (epq_t == 1) GQ_LAUNCH(1);
-    else if (epq_t == 2) GQ_LAUNCH(2);
-    else if (epq_t == 4) GQ_LAUNCH(4);
-    else GQ_LAUNCH(8);
+    if (wg != nullptr) {   // (gate_proj_ok: E in {32, 64, 128} -> EPQ = E / 16)
+      if (E == 32) GQ_LAUNCH(2, 1);
+      else if (E == 64) GQ_LAUNCH(4, 2);
+      else GQ_LAUNCH(8, 4);
+    } else if (epq_t == 1) GQ_LAUNCH(1, 0);
+    else if (epq_t == 2) GQ_LAUNCH(2, 0);
+    else if (epq_t == 4) GQ_LAUNCH(4, 0);
+    else GQ_LAUNCH(8, 0);
 #undef GQ_LAUNCH
     TUTEL_CHECK_LAUNCH("tutel_amd_gate_topk");
     return 0;
   }
-  TUTEL_REQUIRE(fused == nullptr, "tutel_amd_route: the fused routing kernel takes E <= 128");
   const int epl = (E + 63) / 64;
 #define GT_LAUNCH(EPL)                                                                          \
   do {                                                                                          \
@@ -758,26 +825,22 @@ extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax,
   return launch_gate_topk<f16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
 }
 
-extern "C" int tutel_amd_route(const void *logits, int dtype, int T, int E, int k, int normalize_gate, int32_t *idx, void *gates,
-                               void *ws, size_t ws_bytes, int32_t *loc, int32_t *dispatch_count, int32_t *stats, void *l_aux,
-                               int capacity, int32_t *slot_map, uint32_t *sync, tutel_stream_t stream) {
-  TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_route: unsupported dtype %d", dtype);
-  TUTEL_REQUIRE(T >= 1 && E >= 1 && k >= 1 && k <= RT_MAX_K && k <= E, "tutel_amd_route: bad sizes T=%d E=%d k=%d", T, E, k);
-  if (!route_fusable(T, E, k)) return TUTEL_AMD_ENOTSUP;  // (not an error: the caller runs tutel_amd_gate_topk + tutel_amd_compute_location)
-  TUTEL_REQUIRE(logits && idx && gates && ws && loc && dispatch_count && sync, "tutel_amd_route: null pointer");
-  TUTEL_REQUIRE(ws_bytes >= tutel_amd_routing_workspace_bytes(T, E, k), "tutel_amd_route: workspace too small");
-  TUTEL_REQUIRE(capacity >= 0 && (slot_map != nullptr || capacity == 0), "tutel_amd_route: a capacity needs a slot map");
-  TUTEL_REQUIRE((long long)k * T < 0x7fffffffLL, "tutel_amd_route: k*T overflows int32");
+extern "C" int tutel_amd_gate_proj_topk(const void *x, int ldx, const void *wg, int dtype, int T, int M, int E, int k, int normalize_gate,
+                                        void *logits_out, int32_t *idx, void *gates, void *ws, size_t ws_bytes, int32_t *clear_map,
+                                        int clear_n, tutel_stream_t stream) {
+  TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_gate_proj_topk: unsupported dtype %d", dtype);
+  TUTEL_REQUIRE(T >= 0 && M >= 1 && E >= 1 && k >= 1 && k <= RT_MAX_K && k <= E && ldx >= M, "tutel_amd_gate_proj_topk: bad sizes T=%d M=%d E=%d k=%d ldx=%d", T, M, E, k, ldx);
+  if (!gate_proj_ok(dtype, E, M)) return TUTEL_AMD_ENOTSUP;  // (not an error: the caller projects with a library GEMM and runs tutel_amd_gate_topk)
+  if (T == 0) return 0;
+  TUTEL_REQUIRE(x && wg && idx && gates && ws, "tutel_amd_gate_proj_topk: null pointer");
+  TUTEL_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wg % 16) == 0 && ldx % 8 == 0, "tutel_amd_gate_proj_topk: rows must be 16-byte aligned");
+  TUTEL_REQUIRE(ws_bytes >= tutel_amd_routing_workspace_bytes(T, E, k), "tutel_amd_gate_proj_topk: workspace too small");
+  TUTEL_REQUIRE(clear_n >= 0 && (clear_map != nullptr || clear_n == 0), "tutel_amd_gate_proj_topk: bad clear_map");
+  if (clear_n == 0) clear_map = nullptr;
   hipStream_t st = (hipStream_t)stream;
   StageScope stage(TUTEL_STAGE_GATE_TOPK, st);
-  FusedLoc fl;
-  fl.loc = loc; fl.dispatch_count = dispatch_count; fl.stats = stats; fl.l_aux = l_aux; fl.l_aux_dtype = dtype;
-  fl.capacity = capacity > 0 ? capacity : 0; fl.slot_map = capacity > 0 ? slot_map : nullptr; fl.sync = sync; fl.ntiles = 0;
-  int32_t *clear = capacity > 0 ? slot_map : nullptr;
-  const int clear_n = capacity > 0 ? E * capacity : 0;
-  if (dtype == TUTEL_F32) return launch_gate_topk<float>(logits, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear, clear_n, st, &fl);
-  if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(logits, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear, clear_n, st, &fl);
-  return launch_gate_topk<f16_t>(logits, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear, clear_n, st, &fl);
+  if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(x, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear_map, clear_n, st, wg, M, ldx, logits_out);
+  return launch_gate_topk<f16_t>(x, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear_map, clear_n, st, wg, M, ldx, logits_out);
 }
 
 extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int k, int hist_ready,

@@ -538,17 +538,15 @@ class _MoeWorkspace(_Workspace):
     """_Workspace + the routing buffers (idx / loc / gates / slot map / per-tile histograms), all reused call after call"""
 
     def __init__(self, layer, x, logits, k, capacity, degree, comm, T_cap):
-        E, T = logits.shape[1], int(T_cap)
+        E, T = logits.shape[1], int(T_cap)   # (logits: the tensor, or a meta tensor of its shape / dtype when the projection is fused)
         dev = x.device
         super().__init__(layer, x, E, capacity, k, degree, comm, T_cap)
         self.idx = torch.empty([k, T], dtype=torch.int32, device=dev)
         self.loc = torch.empty([k, T], dtype=torch.int32, device=dev)
         self.gates = torch.empty([k, T], dtype=logits.dtype, device=dev)
         self.slot_map = torch.empty([E * capacity], dtype=torch.int32, device=dev)
-        # routing scratch for the largest tiling any T takes (<= 128 token tiles, csrc/routing.hip); route_sync: the two words
-        # the fused routing kernel synchronises its blocks on (zero-initialised once, the kernel leaves them zero)
+        # routing scratch for the largest tiling any T takes (<= 128 token tiles, csrc/routing.hip)
         self.ws = torch.empty([max(int(_lib.lib().tutel_amd_routing_workspace_bytes(64 * 128, E, k)), 4)], dtype=torch.uint8, device=dev)
-        self.route_sync = torch.zeros([2], dtype=torch.int32, device=dev)
         self.stats = torch.empty([1], dtype=torch.int32, device=dev)
         # the dropless capacity is read back into this workspace's own pinned word (no process-global slot: ADVICE r2)
         self.cap_host = torch.zeros([1], dtype=torch.int32).pin_memory()
@@ -560,15 +558,33 @@ class _MoeWorkspace(_Workspace):
         m.logits_dtype = ops._DT[logits.dtype]
         m.ws, m.ws_bytes, m.stats = self.ws.data_ptr(), self.ws.numel(), self.stats.data_ptr()
         m.capacity_out = ctypes.pointer(self.cap_c)
-        m.route_sync = self.route_sync.data_ptr()
         self.margs = m
 
 
-def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss, dropless=None, megablocks_size=0):
+def proj_fusable(gate, x):
+    """may the gate projection run inside the top-k kernel (tutel_amd_gate_proj_topk)?  The stock linear gate in the tokens' own
+    bf16 / fp16 dtype, nobody listening on the module (forward hooks would not fire), no gradient wanted, a shape the kernel takes"""
+    from ..gates.top import LinearTopKGate
+    if type(gate) is not LinearTopKGate or gate.fp32_gate or ops.get_option(_lib.OPT_ROUTING) == 0:
+        return False
+    w = gate.wg.weight
+    if gate._forward_hooks or gate._forward_pre_hooks or gate.wg._forward_hooks or gate.wg._forward_pre_hooks:
+        return False
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16) and w.is_contiguous()):
+        return False
+    if torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
+        return False
+    E, M = w.shape
+    return E in (32, 64, 128) and M % (1024 // (E // 32)) == 0 and x.shape[1] == M
+
+
+def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss, dropless=None, megablocks_size=0, gate_w=None):
     """x [T, M], logits [T, E] -> (y [T, M_out], l_aux | None, dispatch_count [E], capacity); None when the native path is
     unavailable.  One C call: softmax + top-k + locations + loss, encode, exchange(s), expert FFN, exchange(s), decode.
     dropless = (capacity_limit, alignment): capacity_factor <= 0 on a single rank -- the capacity is read back inside the call
-    (`capacity` is then only the first guess for the workspace size)."""
+    (`capacity` is then only the first guess for the workspace size).
+    gate_w [E, M]: the gate projection runs inside the call as well (`logits` is then a meta tensor giving shape and dtype);
+    layer._keep_logits (tests): the logits the kernel used are kept as layer.last_logits."""
     ex = layer.experts
     W = layer.world_size
     with_comm = W > 1 or (_FORCE_COMM and dist.is_initialized())
@@ -604,7 +620,14 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
             a.row_counts, a.row_align = cnt.data_ptr(), int(megablocks_size)
         else:
             a.row_counts, a.row_align = None, 1
-        m.logits, m.normalize_gate = logits.data_ptr(), int(bool(normalize_gate))
+        m.normalize_gate = int(bool(normalize_gate))
+        if gate_w is not None:
+            m.logits, m.gate_w, m.logits_out = None, gate_w.data_ptr(), None
+            if getattr(layer, "_keep_logits", False):
+                layer.last_logits = torch.empty(list(logits.shape), dtype=logits.dtype, device=dev)
+                m.logits_out = layer.last_logits.data_ptr()
+        else:
+            m.logits, m.gate_w, m.logits_out = logits.data_ptr(), None, None
         m.dispatch_count = cnt.data_ptr()
         m.l_aux = l_aux.data_ptr() if l_aux is not None else None
         cap_out = ws.cap_c
@@ -621,6 +644,9 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
             continue
         _lib.check(rc, "tutel_amd_moe_forward")
         used = int(cap_out.value) if dropless is not None else int(capacity)
+        if getattr(layer, "_keep_routing", False):   # tests: [k, T] views of the workspace's routing arrays (rows are T apart)
+            n = k * x.shape[0]
+            layer.last_routing = (ws.idx.view(-1)[:n].view(k, -1).clone(), ws.loc.view(-1)[:n].view(k, -1).clone())
         layer.protected_shape = torch.Size([layer.num_local_experts, W * used, ex.output_dim])
         return y, (l_aux[0] if l_aux is not None else None), cnt, used
     raise _lib.TutelAmdError("tutel_amd_moe_forward: the dropless capacity kept growing")

@@ -110,33 +110,26 @@ def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False, l_aux_dtype=
     return loc, cnt, stats, l_aux, smap
 
 
-def route(logits, k, capacity, normalize_gate=True, sync=None):
-    """softmax + top-k + locations + slot map + counts + gshard loss in ONE launch (tutel_amd_route).  Returns
-    (idx [k,T], gates [k,T], loc [k,T], dispatch_count [E], stats [1], l_aux [1], slot_map | None), or None when the
-    fused kernel does not take this shape (E > 128, huge tiles): the caller then uses gate_topk + compute_location.
-    sync: an int32[2] tensor that was ZERO before its first use (reused call after call)."""
-    _dev(logits)
-    assert logits.dim() == 2 and logits.is_contiguous()
-    T, E = logits.shape
+def gate_proj_topk(x, wg, k, normalize_gate=True, want_logits=False, ws=None, clear=None):
+    """x [T, M], wg [E, M] (bf16 / fp16) -> idx [k,T], gates [k,T], ws, logits | None: the gate projection, softmax and top-k in ONE
+    launch (tutel_amd_gate_proj_topk).  Returns None when the kernel does not take the shape (the caller then projects with
+    F.linear and calls gate_topk)."""
+    _dev(x, wg)
+    assert x.dim() == 2 and wg.dim() == 2 and x.shape[1] == wg.shape[1] and x.dtype == wg.dtype
+    x, wg = x.contiguous(), wg.contiguous()
+    (T, M), E = x.shape, wg.shape[0]
     k = min(int(k), E)
-    dev = logits.device
-    if sync is None:
-        sync = torch.zeros([2], dtype=torch.int32, device=dev)
-    idx = torch.empty([k, T], dtype=torch.int32, device=dev)
-    loc = torch.empty_like(idx)
-    gates = torch.empty([k, T], dtype=logits.dtype, device=dev)
-    cnt = torch.empty([E], dtype=torch.int32, device=dev)
-    stats = torch.empty([1], dtype=torch.int32, device=dev)
-    l_aux = torch.empty([1], dtype=logits.dtype, device=dev)
-    smap = torch.empty([E * capacity], dtype=torch.int32, device=dev) if capacity > 0 else None
-    ws = routing_workspace(T, E, k, dev)
-    rc = _lib.lib().tutel_amd_route(_ptr(logits), _code(logits), T, E, k, int(bool(normalize_gate)), _ptr(idx), _ptr(gates), _ptr(ws),
-                                    ws.numel(), _ptr(loc), _ptr(cnt), _ptr(stats), _ptr(l_aux), int(capacity), _ptr(smap), _ptr(sync),
-                                    _stream())
+    idx = torch.empty([k, T], dtype=torch.int32, device=x.device)
+    gates = torch.empty([k, T], dtype=x.dtype, device=x.device)
+    logits = torch.empty([T, E], dtype=x.dtype, device=x.device) if want_logits else None
+    if ws is None:
+        ws = routing_workspace(T, E, k, x.device)
+    rc = _lib.lib().tutel_amd_gate_proj_topk(_ptr(x), M, _ptr(wg), _code(x), T, M, E, k, int(bool(normalize_gate)), _ptr(logits), _ptr(idx),
+                                             _ptr(gates), _ptr(ws), ws.numel(), _ptr(clear), clear.numel() if clear is not None else 0, _stream())
     if rc == _lib.ENOTSUP:
         return None
-    _lib.check(rc, "tutel_amd_route")
-    return idx, gates, loc, cnt, stats, l_aux, smap
+    _lib.check(rc, "tutel_amd_gate_proj_topk")
+    return idx, gates, ws, logits
 
 
 def slot_map(idx, loc, E, capacity):
@@ -286,9 +279,26 @@ def expert_gemm_gather(x, smap, w, bias, w_kmajor, act, R, row_counts=None, row_
     return out
 
 
+_OPT_ENV = {_lib.OPT_GEMM_IMPL: "TUTEL_AMD_GEMM_IMPL", _lib.OPT_GEMM_TILE: "TUTEL_AMD_GEMM_BIG", _lib.OPT_DECODE: "TUTEL_AMD_DECODE",
+            _lib.OPT_ROUTING: "TUTEL_AMD_ROUTING", _lib.OPT_GEMM_PERSIST: "TUTEL_AMD_GEMM_PERSIST", _lib.OPT_EP_STREAMS: "TUTEL_AMD_EP_STREAMS"}
+_opts = {}
+
+
 def set_option(key, value):
     """Tuning knob (_lib.OPT_*): -1 automatic, 0 / 1 forced.  For A/B runs and tests."""
     _lib.check(_lib.lib().tutel_amd_set_option(int(key), int(value)), "tutel_amd_set_option")
+    _opts[int(key)] = int(value)
+
+
+def get_option(key):
+    """the knob's current value as the host code sees it (the library seeds its own copy from the same environment variable)"""
+    import os
+    if int(key) in _opts:
+        return _opts[int(key)]
+    try:
+        return int(os.environ.get(_OPT_ENV[int(key)], "-1"))
+    except ValueError:
+        return -1
 
 
 def probe_tr16():
