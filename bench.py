@@ -12,9 +12,11 @@ reference's `helloworld.py --eval` (helloworld.py:141-146).
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
     per GPU: 4096 tokens (batch 16 x 256) x model_dim 2048, hidden 2048, 64 GLOBAL experts,
     top-2, capacity_factor 1.0 (capacity 128/expert/rank), bf16, ReLU, biases on.
-N > 1: experts are sharded E_loc = 64/N per rank (expert parallel, RCCL all-to-all over xGMI through the
-library's own communicator, a2a_ffn_overlap_degree 2), every rank keeps its own 4096 tokens -> per-GPU work
-is fixed: weak scaling, value = N * 4096 / t.
+N > 1: experts are sharded E_loc = 64/N per rank (expert parallel, a2a_ffn_overlap_degree 2), every rank keeps its own
+4096 tokens -> per-GPU work is fixed: weak scaling, value = N * 4096 / t.  The exchange is the library's IPC transport
+(round 4: fast_encode and the fc2 epilogue store their rows straight into the peers' buffers over xGMI, one flag per
+(direction, stage, peer), no collective on the path) when every rank can map its peers' segments and the tagged
+self-check passes; RCCL's all-to-all on the library communicator otherwise (`config.exchange` says which ran).
 
 Timing: `--settle` untimed initialisation passes (allocator / weight pre-layout / clock state; reported in
 the JSON), W untimed warm-up steps; barrier + synchronize; exactly K steps; synchronize + barrier; MAX over
@@ -24,21 +26,24 @@ step here).  Three more passes of the same K steps follow it, bracketed the same
 every launch (`stages`) -- all live, inside this script, on the same tensors.
 
 `roofline`: the dominant kernel is the fc1 grouped GEMM.  N = 1 (128 rows per expert):
-expert_gemm_glds_kernel<bf16,k-major,relu>, HBM-bound; achieved = algorithmic bytes per launch
+expert_gemm_big_kernel<bf16,k-major,relu,128 x 256 tile on a three-slot LDS-DMA ring> (round 4; rounds 1-3:
+expert_gemm_glds_kernel, 128 x 128), HBM-bound; achieved = algorithmic bytes per launch
 (E_loc*H*M weights + E_loc*R*M tokens + E_loc*R*H hidden out, x2 bytes) / its average duration.
 256 rows or more per expert and launch (N > 1, --tokens 65536): expert_gemm_pp_kernel, MFMA-bound; achieved = flop
 per launch / its average duration.
 `roofline.traffic` / `roofline.frac_rocprof` come from profiles/traffic.json (PMC FETCH_SIZE / WRITE_SIZE passes and the rocprofv3
-kernel-trace average of the same command, written by tools/profile_r03.sh) and are emitted only while the sha256 of
+kernel-trace average of the same command, written by tools/profile_r04.sh) and are emitted only while the sha256 of
 csrc/expert_gemm.hip equals the one stamped there -- otherwise null with the reason.  `decode` and `extra.ep8_rank_gemms` are
 roofline objects of the second / third kernels of interest (fast_decode; the grouped GEMM at the per-rank shapes of an 8-way
 expert-parallel run: one pipeline stage, and the whole rank).
 Launch mode: with capacity_factor > 0 the forward never talks to the host, so the default is to capture it once in a HIP graph
 (tutel_amd.impls.graph.GraphedForward -- kernels, and with N > 1 the RCCL collectives of the library's communicator) and REPLAY
 it per step; `--eager` measures the Python-enqueued forward instead, and the line always carries the other mode beside it
-(`launch_modes`).  If capture fails the script says so on stderr and in the line and runs eager.  N > 1 is timed eager (GPU-bound:
-0.16 ms of host enqueue against >= 0.25 ms of device work per forward) because replaying captured RCCL collectives was seen to
-hang after a few hundred replays with this RCCL build (profiles/r03_ep_streams.txt); `--graph` forces the replay there.
+(`launch_modes`, and `value_eager` at the top level).  If capture fails the script says so on stderr and in the line and runs eager.
+N > 1: the graph is replayed as well when the exchange is the IPC transport (plain kernels and events, epochs counted on the device:
+2000 replays in tests/test_ep_ipc_one_gpu.py; host cost 0.05 ms per forward against 0.16 ms eager); with RCCL on the path the
+forward is timed eager, because replaying captured RCCL collectives was seen to hang after a few hundred replays with this RCCL
+build (profiles/r03_ep_streams.txt) and GraphedForward refuses to capture them.
 `cpu_baseline`: the CPU oracle (a port of the reference CPU path, oracle/moe_oracle.py) timed on this box's host
 cores on a bounded sample, rank 0, N=1 only, next to the figure BASELINE.md measured with the reference itself.
 Checker code is used here ONLY as that reported baseline; it is never part of the measured GPU path.
@@ -226,11 +231,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # Test hook (not a measurement mode): TUTEL_AMD_BENCH_SHARE_GPU=1 runs every rank on cuda:0 with a gloo
-    # rendezvous and a host-staged all-to-all, so the N > 1 code path of this script can be exercised on a
-    # single-GPU box.  The driver's multi-GPU runs use one GPU per rank over RCCL.
+    # rendezvous and the IPC transport between the rank processes, so the N > 1 code path of this script can be
+    # exercised on a single-GPU box.  The driver's multi-GPU runs use one GPU per rank ("nccl" rendezvous).
     share = os.environ.get("TUTEL_AMD_BENCH_SHARE_GPU", "0") == "1"
     if share:
         local_rank = 0
+        os.environ.setdefault("TUTEL_AMD_EP_TRANSPORT", "ipc")   # processes that share a device can still map each other's segments
     local_rank %= max(1, torch.cuda.device_count())   # a launcher that hands every rank ONE visible device numbers it 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -261,11 +267,10 @@ def main():
     step = (lambda t: layer(t, **fwd_kw)) if fwd_kw else layer
     eager_step = step
     launch, graph_note, graphed = "eager", None, None
-    # N > 1: eager unless --graph is given.  Replaying captured RCCL collectives is not safe to default to with this RCCL build: in
-    # the 1-rank-communicator probe (tools/r3_ep_streams_ab.py, profiles/r03_ep_streams.txt) capture succeeds and the first
-    # ~200 replays run, then a later replay never completes.  The N > 1 forward is GPU-bound eager (0.16 ms of host enqueue per
-    # forward against >= 0.25 ms of device work per rank), so eager is what is timed; N = 1 (no collectives) replays the graph.
-    want_graph = (args.graph or (not args.eager and world == 1)) and args.capacity_factor > 0 and not share
+    # N > 1: the graph is replayed when the exchange is the IPC transport (kernels + events only); GraphedForward refuses to capture
+    # RCCL collectives (replaying them hung after ~200 replays in the 1-rank-communicator probe, profiles/r03_ep_streams.txt) and
+    # the forward is then timed eager -- every rank takes the same branch (the transport is agreed at communicator creation).
+    want_graph = (args.graph or not args.eager) and args.capacity_factor > 0
     if want_graph:
         # same kernels (and, N > 1, the same RCCL collectives on the caller's stream), enqueued by ONE hipGraphLaunch per step:
         # the host cost of a forward drops from ~0.09 (N = 1) / ~0.16 ms (N > 1, degree 2) to one launch, so the step is
@@ -277,10 +282,10 @@ def main():
             with torch.no_grad():
                 graphed = GraphedForward(layer, x, **fwd_kw)
         except Exception as ex:   # noqa: BLE001 -- loud, not silent
-            ok, graph_note = 0, f"HIP-graph capture failed ({type(ex).__name__}: {str(ex)[:200]}); timed eager instead"
+            ok, graph_note = 0, f"HIP-graph capture not used ({type(ex).__name__}: {str(ex)[:200]}); timed eager instead"
             print("bench.py: " + graph_note, file=sys.stderr, flush=True)
         if world > 1:
-            f = torch.tensor([ok], device=dev, dtype=torch.int32)
+            f = torch.tensor([ok], device="cpu" if share else dev, dtype=torch.int32)
             dist.all_reduce(f, op=dist.ReduceOp.MIN)
             if int(f) == 0 and ok:
                 ok, graph_note = 0, "HIP-graph capture failed on another rank; timed eager instead"
@@ -289,9 +294,6 @@ def main():
             step, launch = graphed, "hip-graph replay"
     elif args.capacity_factor <= 0:
         graph_note = "dropless routing reads the capacity back to the host every step: not capturable, eager"
-    elif world > 1 and not share:
-        graph_note = ("N > 1 is timed eager: replaying captured RCCL collectives hung after a few hundred replays in the 1-rank-communicator "
-                      "probe (profiles/r03_ep_streams.txt); --graph forces the replay")
 
     with torch.no_grad():
         for _ in range(args.settle):
@@ -351,7 +353,7 @@ def main():
         have = source_sha()
         if tj.get("expert_gemm_hip_sha256") != have:
             traffic_note = (f"stale: profiles/traffic.json was measured on csrc/expert_gemm.hip sha256 {str(tj.get('expert_gemm_hip_sha256'))[:12]}, "
-                            f"the library was built from {have[:12]} -- re-run tools/profile_r03.sh")
+                            f"the library was built from {have[:12]} -- re-run tools/profile_r04.sh")
         else:
             traffic = tj.get("expert_gemm_fc1_hbm_bytes_per_launch")
             rocprof_us = tj.get("expert_gemm_fc1_avg_us_rocprofv3")
@@ -368,7 +370,7 @@ def main():
                     "avg_launch_us": round(fc1_us, 2), "launches_timed": fc1_n, "fc2_gemm": fc2_obj}
     else:
         gbs = gemm_bytes / fc1_us * 1e-3
-        roofline = {"bound": "hbm", "kernel": f"expert_gemm_glds_kernel<{dname},k-major,relu> (fc1 grouped GEMM, LDS-DMA)",
+        roofline = {"bound": "hbm", "kernel": f"expert_gemm_big_kernel<{dname},k-major,relu,NI=4,NS=3,BUF,BM=128> (fc1 grouped GEMM: 128 x 256 tile, three-slot LDS-DMA ring)",
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_GBs": HBM_ACHIEVABLE_GBS, "traffic": traffic,
                     "traffic_over_algorithmic": round(traffic / gemm_bytes, 4) if traffic else None, "traffic_note": traffic_note,
@@ -402,9 +404,10 @@ def main():
         out = {
             "metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "settle": args.settle,
+            "settle": args.settle, "launch": launch,
+            "value_eager": round(world * T / (other / args.steps), 1) if other is not None else (round(value, 1) if launch == "eager" else None),
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dname, "data": "synthetic" if not share else "synthetic; TEST HOOK: all ranks share one GPU, host-staged all-to-all -- not a measurement",
+            "dtype": dname, "data": "synthetic" if not share else "synthetic; TEST HOOK: all ranks share one GPU (IPC transport between the rank processes) -- not a measurement",
             "step_ms": {"mean_wall": round(ms, 4), "min": round(srt[0], 4), "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4),
                         "per_step": [round(v, 4) for v in per_step],
                         "note": "mean_wall = the timed region / steps (no events inside it); min / median / max / per_step from a second pass "
@@ -421,7 +424,9 @@ def main():
                        "capacity": C, "parallelism": f"ep{world}" if world > 1 else "single-gpu",
                        "a2a_ffn_overlap_degree": overlap, "fp32_gate": bool(args.fp32_gate),
                        "capacity_factor": args.capacity_factor, "megablocks_size": args.megablocks_size, "launch": launch,
-                       "exchange": ("library RCCL communicator (tutel_amd_ep_forward)" if ep_native._comms and any(ep_native._comms.values())
+                       "exchange": (("IPC transport: peer stores over xGMI from fast_encode and the fc2 epilogue, flag kernels, no collective (tutel_amd_ep_forward)"
+                                     if any(c and c.ipc for c in ep_native._comms.values()) else "library RCCL communicator (tutel_amd_ep_forward)")
+                                    if ep_native._comms and any(ep_native._comms.values())
                                     else "torch.distributed all_to_all_single") if world > 1 else "none (single rank)"},
             "roofline": roofline,
             "stages": {"avg_us_per_step": stage_us, "launches_timed": launches,

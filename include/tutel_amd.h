@@ -76,19 +76,6 @@ int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax, int T, int
                         int normalize_gate, void *scores_out, int32_t *idx, void *gates, void *ws,
                         size_t ws_bytes, int32_t *clear_map, int clear_n, tutel_stream_t stream);
 
-/* The gate PROJECTION, softmax and top-k in ONE launch: logits = x @ wg^T (gates/top.py:20-22: `self.wg(x)` of a bias-free
- * nn.Linear in the tokens' dtype) are computed on MFMA inside the top-k kernel, so the [T, E] logits never travel through HBM
- * between a library GEMM and the routing kernel; everything after the logits is tutel_amd_gate_topk with apply_softmax = 1, bit for
- * bit.  x [T, ldx] and wg [E, M] are `dtype` (TUTEL_BF16 | TUTEL_F16); the logit of (t, e) is an fp32 sum over M rounded once to
- * `dtype`, as the nn.Linear's output is -- the ORDER of that fp32 sum is this kernel's (MFMA, 8 / (E / 32) slices of M added in
- * order), so the last bit of a logit can differ from another GEMM's: `logits_out` (optional, [T, E]) returns what was used.
- * Applies to E in {32, 64, 128} and M a multiple of 128 * 8 / (E / 32); otherwise returns TUTEL_AMD_ENOTSUP and launches nothing
- * (the caller projects with a library GEMM and calls tutel_amd_gate_topk).  ws / clear_map as tutel_amd_gate_topk. */
-#define TUTEL_AMD_ENOTSUP 1001
-int tutel_amd_gate_proj_topk(const void *x, int ldx, const void *wg, int dtype, int T, int M, int E, int k, int normalize_gate,
-                             void *logits_out, int32_t *idx, void *gates, void *ws, size_t ws_bytes, int32_t *clear_map,
-                             int clear_n, tutel_stream_t stream);
-
 /* idx[k,T] -> loc[k,T] (stable rank of token t among tokens with the same k-th choice, queued
  * after ALL tokens' earlier choices -- fast_dispatch.py:159-171), dispatch_count[E] (:177-178),
  * stats[0] = max_e dispatch_count[e] (the dropless capacity before the all-reduce, :192),
@@ -367,8 +354,7 @@ int tutel_amd_ep_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_ep_args_t *a
  * for the common inference configuration -- softmax + top-k + locations + gshard loss (tutel_amd_gate_topk,
  * tutel_amd_compute_location with the capacity known up front, capacity_factor > 0) and then tutel_amd_ep_forward on
  * the routing just computed.  ep.slot_map / idx / loc / gates are OUTPUT buffers here ([E*C], [k,T], [k,T], [k,T] in
- * the logits dtype); ep.gate_dtype is ignored (= logits_dtype).  Dropless routing: see the last fields.  With `gate_w` the
- * gate projection (gates/top.py:20-22) is part of the call as well. */
+ * the logits dtype); ep.gate_dtype is ignored (= logits_dtype).  Dropless routing: see the last fields. */
 typedef struct {
   tutel_amd_ep_args_t ep;
   const void *logits;        /* [T, num_experts] gate logits */
@@ -387,11 +373,9 @@ typedef struct {
   int capacity_limit, alignment, max_capacity;
   int *capacity_out;         /* host pointer, out: the capacity used (may be NULL when ep.capacity > 0); dropless: the read-back
                               * lands here (pinned memory keeps the copy asynchronous) */
-  const void *gate_w;        /* NULL, or the gate weight [num_experts, M] in the tokens' dtype (= logits_dtype): the projection then
-                              * runs inside the top-k kernel (tutel_amd_gate_proj_topk) and `logits` is not read (may be NULL) */
-  void *logits_out;          /* with gate_w: optional [T, num_experts] copy of the logits that were used */
 } tutel_amd_moe_args_t;
 #define TUTEL_AMD_EAGAIN 1000
+#define TUTEL_AMD_ENOTSUP 1001 /* reserved: "this entry point does not take the shape, nothing was launched" */
 int tutel_amd_moe_forward(tutel_amd_ep_comm_t *comm, const tutel_amd_moe_args_t *args, tutel_stream_t stream);
 
 /* stage markers: roctx ranges (rocprofv3 --marker-trace); the pipeline above emits tutel_amd.fast_encode /
@@ -423,14 +407,14 @@ int tutel_amd_marks_report(double *delta_us, int n);
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG / TUTEL_AMD_DECODE /
  * TUTEL_AMD_ROUTING / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS seed it once), >= 0 = force.  Every choice computes bit-identical results.
- *   TUTEL_OPT_GEMM_IMPL  128-tile kernels: 0 register-staged, 1 LDS-DMA
+ *   TUTEL_OPT_GEMM_IMPL  kernels of the <= 128-rows-per-expert regime: 0 register-staged 128 x 128, 1 LDS-DMA 128 x 128, 4 the
+ *                        128 x 256 tile on a three-slot LDS-DMA ring (k-major weights; automatic when its grid covers the chip)
  *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
  *                        with a two- / three-slot LDS ring (k-major weights), 4 always the 256 x 256 ping-pong kernel
  *                        (automatic: > 128 rows per expert and enough tiles to cover the chip)
  *   TUTEL_OPT_DECODE     fast_decode launch shape: bit 0 = two waves per token, bit 1 = non-temporal stores of the output
  *                        (automatic: 2)
- *   TUTEL_OPT_ROUTING    gate projection: 0 = library GEMM + tutel_amd_gate_topk, 1 / automatic = inside the top-k kernel
- *                        (tutel_amd_gate_proj_topk) where that kernel applies
+ *   TUTEL_OPT_ROUTING    reserved (round 3's grid-barrier routing kernel, removed in round 4): no effect
  *   TUTEL_OPT_GEMM_PERSIST  256 x 256 ping-pong kernel, bias operand: 0 = fetched after the K loop, 1 / automatic = before it
  *                        (32 more live registers, its L2 round trip hidden behind the loop)
  *   TUTEL_OPT_EP_STREAMS overlapped pipeline: 1 = every stage's GEMMs on ONE side stream, 2 / automatic = stages alternate between

@@ -61,12 +61,6 @@ def test_argument_errors_are_reported_not_enqueued(L):
 
 def test_round3_entry_points_reject_bad_arguments(L):
     from tutel_amd import _lib
-    # gate projection inside the top-k kernel: bad dtype is an error; a shape the kernel does not take is ENOTSUP (nothing launched)
-    assert L.tutel_amd_gate_proj_topk(None, 2048, None, 99, 64, 2048, 64, 2, 1, None, None, None, None, 0, None, 0, None) not in (0, _lib.ENOTSUP)
-    assert b"dtype" in L.tutel_amd_last_error()
-    assert L.tutel_amd_gate_proj_topk(None, 2048, None, _lib.BF16, 64, 2048, 8, 2, 1, None, None, None, None, 0, None, 0, None) == _lib.ENOTSUP
-    assert L.tutel_amd_gate_proj_topk(None, 2048, None, _lib.F32, 64, 2048, 64, 2, 1, None, None, None, None, 0, None, 0, None) == _lib.ENOTSUP
-    assert L.tutel_amd_gate_proj_topk(None, 2048, None, _lib.BF16, 64, 2048, 64, 2, 1, None, None, None, None, 0, None, 0, None) not in (0, _lib.ENOTSUP)  # null pointers
     # IPC transport: a communicator without it refuses, segments check their arguments
     assert L.tutel_amd_ep_ipc_exchange(None, None, None, 16, 0, None) != 0 and b"IPC" in L.tutel_amd_last_error()
     assert L.tutel_amd_ep_segment_open(None, 2, 0, None, 64) != 0
@@ -81,7 +75,7 @@ def test_round3_entry_points_reject_bad_arguments(L):
     assert L.tutel_amd_gate_topk(None, 0, 0, 4, 4097, 1, 1, None, None, None, None, 0, None, 0, None) != 0 and b"4096" in L.tutel_amd_last_error()
     assert L.tutel_amd_gate_topk(None, 0, 0, 4, 4096, 3, 1, None, None, None, None, 0, None, 0, None) != 0 and b"8192" in L.tutel_amd_last_error()
     # options: the round-3 keys exist, unknown keys are refused
-    for key in (_lib.OPT_DECODE, _lib.OPT_ROUTING, _lib.OPT_GEMM_PERSIST, _lib.OPT_EP_STREAMS):
+    for key in (_lib.OPT_DECODE, _lib.OPT_GEMM_PERSIST, _lib.OPT_EP_STREAMS):
         assert L.tutel_amd_set_option(key, -1) == 0
     assert L.tutel_amd_set_option(99, 0) != 0
 

@@ -396,7 +396,7 @@ def test_expert_gemm_kernels_are_bit_identical(kmajor):
         b = torch.randn([E, N], generator=g).bfloat16().cuda()
         outs = []
         try:
-            for impl, tile in ((0, 0), (1, 0), (-1, 1), (-1, 2), (-1, 3), (-1, 4)):
+            for impl, tile in ((0, 0), (1, 0), (4, 0), (-1, 1), (-1, 2), (-1, 3), (-1, 4)):   # (impl 4: round 4's 128 x 256 ring of the 128-row regime)
                 ops.set_option(_lib.OPT_GEMM_IMPL, impl)
                 ops.set_option(_lib.OPT_GEMM_TILE, tile)
                 outs.append(ops.expert_gemm(a, w, b, kmajor, act="gelu"))
@@ -443,13 +443,15 @@ def test_routing_randomized_shapes_vs_oracle(oracle):
             assert torch.equal(dec.cpu(), oracle.fast_decode(oracle.fast_encode(x, crit_o), crit_o)), "decode " + tag
 
 
-def test_routing_limits_fail_loudly_and_the_edges_work(oracle):
+def test_routing_limits_fall_back_loudly_and_the_edges_work(oracle, caplog):
     """The routing kernels hold 1 <= k <= 16, E <= 4096 and k * E <= 8192 (include/tutel_amd.h, INTEGRATION.md "Limits"); the
-    reference's ATen op chain takes any E (fast_dispatch.py:143-148).  Inside the limits -- including their edges -- the
-    result is the oracle's, bit for bit; outside, the call raises with the limit in the message: never a silent fallback to
-    another implementation, never a wrong answer."""
+    reference's ATen op chain takes any E and k (fast_dispatch.py:143-148).  Inside the limits -- including their edges -- the
+    kernels run and the result is the oracle's, bit for bit.  Outside them the C ABI refuses with the limit in the message, and
+    the drop-in API (top_k_routing / the layer) runs the reference's own op chain on the device with a warning -- a user of
+    upstream never meets an exception where upstream ran, and never a silent change of implementation."""
+    import logging
     from tutel import moe
-    from tutel_amd import _lib
+    from tutel_amd import _lib, ops
     g = torch.Generator().manual_seed(3)
     for T, E, k in ((300, 1024, 2), (257, 512, 16), (128, 1024, 8), (200, 2048, 4), (130, 4096, 2), (65, 3000, 1)):   # the edges: E = 4096, k = 16, k * E = 8192
         scores = torch.softmax(torch.randn([T, E], generator=g), dim=1)
@@ -459,49 +461,53 @@ def test_routing_limits_fail_loudly_and_the_edges_work(oracle):
         assert crit[4] == ref[4] and torch.equal(crit[5].cpu(), ref[5]) and abs(float(l_aux) - float(l_ref)) < 1e-5
     for T, E, k, word in ((64, 4097, 2, "4096"), (64, 8192, 1, "4096"), (64, 64, 17, "16"), (64, 1024, 9, "8192"), (64, 4096, 3, "8192")):
         scores = torch.softmax(torch.randn([T, E], generator=g), dim=1).cuda()
-        with pytest.raises(_lib.TutelAmdError) as ei:
-            moe.top_k_routing(scores, k)
+        with pytest.raises(_lib.TutelAmdError) as ei:   # the kernel entry point names its limit
+            ops.gate_topk(scores, k)
         assert word in str(ei.value), str(ei.value)
+    # ... and the API keeps working there: fp32 scores are tie-free, so torch.topk's choice is the oracle's
+    for T, E, k, cf, bpr in ((300, 4097, 2, 1.0, False), (100, 8192, 1, 1.0, False), (200, 64, 17, 1.0, False), (257, 1024, 9, 0.5, False),
+                             (150, 4096, 3, 0.0, False), (300, 5000, 2, 1.0, True)):
+        scores = torch.softmax(torch.randn([T, E], generator=g) * 3, dim=1)
+        with caplog.at_level(logging.WARNING):
+            crit, l_aux = moe.top_k_routing(scores.cuda(), k, capacity_factor=cf, batch_prioritized_routing=bpr)
+        ref, l_ref = oracle.extract_critical(scores, k, cf, batch_prioritized_routing=bpr)
+        tag = (T, E, k, cf, bpr)
+        assert torch.equal(torch.stack(crit[1]).cpu(), torch.stack(ref[1]).to(torch.int32)), tag
+        assert torch.equal(torch.stack(crit[2]).cpu(), torch.stack(ref[2]).to(torch.int32)), tag
+        assert crit[4] == ref[4] and torch.equal(crit[5].cpu(), ref[5]) and abs(float(l_aux) - float(l_ref)) < 1e-5, tag
+        assert torch.allclose(torch.stack(crit[3]).cpu(), torch.stack(ref[3]), rtol=1e-6, atol=1e-7), tag
+        x = torch.randn([T, 48], generator=g)
+        y = moe.fast_decode(moe.fast_encode(x.cuda(), crit), crit)      # the dispatch kernels take any E
+        assert torch.equal(y.cpu(), oracle.fast_decode(oracle.fast_encode(x, ref), ref)), tag
+    assert any("outside the HIP routing kernels' limits" in r.getMessage() for r in caplog.records)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_gate_projection_inside_the_topk_kernel(oracle, dtype):
-    """tutel_amd_gate_proj_topk: logits = x @ wg^T on MFMA inside the top-k kernel (gates/top.py:20-22 + moe_layer.py:290 +
-    fast_dispatch.py:146-151 in one launch).  (a) the logits it used are the nn.Linear's up to the order of the fp32 sum: within one
-    rounding of the dtype of the fp32 product; (b) everything after the logits -- expert ids, gates, tile histograms, score column
-    sums -- equals tutel_amd_gate_topk ON THOSE LOGITS bit for bit, and the integers are the oracle's on those logits; (c) shapes
-    the kernel does not take return None and launch nothing."""
-    from tutel_amd import ops
-    g = torch.Generator().manual_seed(23)
-    bits = torch.int16
-    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
-    for T, M, E, k in ((4096, 2048, 64, 2), (4095, 2048, 64, 2), (100, 512, 64, 1), (8192, 1024, 32, 2), (777, 512, 128, 4),
-                       (20000, 1024, 64, 2), (1, 256, 128, 3), (640, 4096, 64, 2)):
-        x = torch.randn([T, M], generator=g).to(dtype).cuda()
-        wg = (torch.randn([E, M], generator=g) * (2.0 / M ** 0.5)).to(dtype).cuda()
-        cap = k * ((T + E - 1) // E)
-        pre = torch.full([E * cap], 7, dtype=torch.int32, device="cuda")
-        got = ops.gate_proj_topk(x, wg, k, want_logits=True, clear=pre)
-        assert got is not None, (T, M, E, k)
-        idx, gates, ws, logits = got
-        assert bool((pre == -1).all()), "the slot map of the next launch must be cleared"
-        ref = x.float() @ wg.float().t()
-        err = (logits.float() - ref).abs()
-        assert bool((err <= eps * ref.abs() + 1e-6 * M ** 0.5 + eps * 2.0 ** -6).all()), (T, M, E, k, float(err.max()))
-        idx2, gates2, ws2, _ = ops.gate_topk(logits, k, apply_softmax=True)
-        tag = (T, M, E, k)
-        torch.cuda.synchronize()
-        assert torch.equal(idx, idx2) and torch.equal(gates.view(bits), gates2.view(bits)), tag
-        n = int(ops._lib.lib().tutel_amd_routing_workspace_bytes(T, E, k))
-        assert torch.equal(ws[:n], ws2[:n]), (tag, "tile histograms / column sums")
-        # the integers are the oracle's on the scores derived from those logits (softmax is not bit-specified across exp
-        # implementations, so the oracle is given the kernel's scores, as everywhere for 16-bit gates)
-        scores = ops.gate_topk(logits, k, apply_softmax=True, want_scores=True)[3]
-        crit, _ = oracle.extract_critical(scores.cpu(), k, 1.0)
-        assert torch.equal(idx.cpu(), torch.stack(crit[1])), tag
-    # not this kernel's shapes: nothing launched, the caller projects with a library GEMM
-    for T, M, E in ((64, 2048, 8), (64, 2048, 96), (64, 200, 64), (64, 256, 64)):
-        x = torch.randn([T, M], generator=g).to(dtype).cuda()
-        wg = torch.randn([E, M], generator=g).to(dtype).cuda()
-        assert ops.gate_proj_topk(x, wg, 2) is None, (T, M, E)
-    assert ops.gate_proj_topk(torch.randn([64, 2048]).cuda(), torch.randn([64, 2048]).cuda(), 2) is None   # fp32 gates stay on the library
+def test_tutel_ops_names_are_registered(oracle):
+    """torch.ops.tutel_ops.cumsum / sparse_bmm_infer (TORCH_LIBRARY(tutel_ops), custom_kernel.cpp:822-894): user and custom-expert
+    code calls them the way upstream's experts/ffn.py:70-81 does.  Here they run on the C ABI; same semantics."""
+    from tutel import moe  # noqa: F401  (registers the names, like upstream's import of jit_kernels.gating)
+    g = torch.Generator().manual_seed(41)
+    mask = (torch.rand([3000, 130], generator=g) < 0.1).to(torch.int64).cuda()
+    out = torch.ops.tutel_ops.cumsum(mask)
+    assert out.dtype == torch.int32 and torch.equal(out.cpu().long(), torch.cumsum(mask.cpu(), dim=0) - 1)
+    E, R, K, H, s = 5, 96, 128, 192, 4
+    counts = torch.tensor([96, 37, 0, 5, 200], dtype=torch.int32)
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        x = torch.randn([E, R, K], generator=g).to(dtype).cuda()
+        w1 = (torch.randn([E, H, K], generator=g) / K ** 0.5).to(dtype).cuda()     # batched_fc1_w: used transposed
+        w2 = (torch.randn([E, H, K], generator=g) / H ** 0.5).to(dtype).cuda()     # batched_fc2_w: used as stored
+        # exactly upstream's lines (ffn.py:72-77)
+        sparse_groups = torch.div(counts.cuda() + (s - 1), s, rounding_mode="floor")
+        sparse_groups = torch.minimum(sparse_groups, torch.tensor(x.size(1) // s, dtype=torch.int32, device=x.device))
+        y = torch.ops.tutel_ops.sparse_bmm_infer(x, w1, sparse_groups, True, s)
+        y2 = torch.ops.tutel_ops.sparse_bmm_infer(torch.relu(y), w2, sparse_groups, False, s)
+        assert y.shape == (E, R, H) and y2.shape == (E, R, K) and y.dtype == dtype
+        for e in range(E):
+            n = min(R, (int(counts[e]) + s - 1) // s * s)
+            if n == 0:
+                continue
+            r1 = x[e, :n].float() @ w1[e].float().t()
+            tol = 1e-4 if dtype == torch.float32 else 2 ** -6
+            assert float((y[e, :n].float() - r1).abs().max()) <= tol * max(1.0, float(r1.abs().max())), (dtype, e)
+            r2 = torch.relu(y[e, :n]).float() @ w2[e].float()
+            assert float((y2[e, :n].float() - r2).abs().max()) <= tol * max(1.0, float(r2.abs().max())), (dtype, e)

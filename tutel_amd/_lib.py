@@ -27,7 +27,6 @@ SIGNATURES = {
     "tutel_amd_gate_topk": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
     "tutel_amd_compute_location": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "tutel_amd_slot_map": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "tutel_amd_gate_proj_topk": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
     "tutel_amd_cumsum_sub_one": (_i, [_vp, _vp, _i, _i, _vp]),
     "tutel_amd_fast_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "tutel_amd_fast_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -62,8 +61,7 @@ class MoeArgs(ctypes.Structure):
     """tutel_amd_moe_args_t"""
     _fields_ = [("ep", EpArgs), ("logits", _vp), ("logits_dtype", _i), ("normalize_gate", _i), ("ws", _vp), ("ws_bytes", _sz),
                 ("dispatch_count", _vp), ("stats", _vp), ("l_aux", _vp),
-                ("capacity_limit", _i), ("alignment", _i), ("max_capacity", _i), ("capacity_out", ctypes.POINTER(_i)),
-                ("gate_w", _vp), ("logits_out", _vp)]
+                ("capacity_limit", _i), ("alignment", _i), ("max_capacity", _i), ("capacity_out", ctypes.POINTER(_i))]
 
 
 SIGNATURES.update({

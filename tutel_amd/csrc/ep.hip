@@ -854,25 +854,16 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
   TUTEL_REQUIRE(m != nullptr, "tutel_amd_moe_forward: null arguments");
   const tutel_amd_ep_args_t &a = m->ep;
   const int T = a.T, E = a.num_experts, k = a.k;
-  TUTEL_REQUIRE((m->logits != nullptr || m->gate_w != nullptr || T == 0) && m->ws != nullptr && m->dispatch_count != nullptr, "tutel_amd_moe_forward: null pointer");
+  TUTEL_REQUIRE((m->logits != nullptr || T == 0) && m->ws != nullptr && m->dispatch_count != nullptr, "tutel_amd_moe_forward: null pointer");
   TUTEL_REQUIRE(a.slot_map && (T == 0 || (a.idx && a.loc && a.gates)), "tutel_amd_moe_forward: null routing buffers");
   if (T == 0 && c == nullptr) return 0;  // (with a communicator an empty rank still takes part in every exchange, see tutel_amd_ep_forward)
   const bool dropless = a.capacity <= 0;
   TUTEL_REQUIRE(!dropless || (c == nullptr && a.world == 1 && m->stats != nullptr && m->capacity_out != nullptr && m->max_capacity >= 1),
                 "tutel_amd_moe_forward: dropless routing needs a single rank, stats, capacity_out and max_capacity");
   int32_t *smap = const_cast<int32_t *>(a.slot_map);
-  int rc = TUTEL_AMD_ENOTSUP;
-  // gate projection + softmax + top-k in ONE launch (tutel_amd_gate_proj_topk) when the caller hands over the gate weight instead
-  // of projected logits (TUTEL_OPT_ROUTING = 0 forces the library projection + tutel_amd_gate_topk on the host side)
-  if (T > 0 && m->gate_w != nullptr)
-    rc = tutel_amd_gate_proj_topk(a.x, a.M, m->gate_w, m->logits_dtype, T, a.M, E, k, m->normalize_gate, m->logits_out, const_cast<int32_t *>(a.idx),
-                                  const_cast<void *>(a.gates), m->ws, m->ws_bytes, dropless ? nullptr : smap, dropless ? 0 : E * a.capacity, stream);
-  else if (T > 0 || m->gate_w == nullptr)
-    rc = tutel_amd_gate_topk(m->logits, m->logits_dtype, 1, T, E, k, m->normalize_gate, nullptr, const_cast<int32_t *>(a.idx),
-                             const_cast<void *>(a.gates), m->ws, m->ws_bytes, dropless ? nullptr : smap, dropless ? 0 : E * a.capacity, stream);
-  else
-    rc = 0;
-  TUTEL_REQUIRE(rc != TUTEL_AMD_ENOTSUP, "tutel_amd_moe_forward: this gate shape has no in-kernel projection (E in {32, 64, 128}, bf16 / fp16, M a multiple of %d): pass logits", 1024 / (E >= 32 ? E / 32 : 1));
+  int rc;
+  rc = tutel_amd_gate_topk(m->logits, m->logits_dtype, 1, T, E, k, m->normalize_gate, nullptr, const_cast<int32_t *>(a.idx),
+                           const_cast<void *>(a.gates), m->ws, m->ws_bytes, dropless ? nullptr : smap, dropless ? 0 : E * a.capacity, stream);
   if (rc) return rc;
   rc = tutel_amd_compute_location(a.idx, T, E, k, 1, m->ws, m->ws_bytes, const_cast<int32_t *>(a.loc), m->dispatch_count, m->stats,
                                   m->l_aux, m->logits_dtype, dropless ? 0 : a.capacity, dropless ? nullptr : smap, dropless ? 0 : 1, stream);

@@ -384,16 +384,16 @@ __device__ __forceinline__ void glds16(const uint16_t *g, uint16_t *l, bool nt) 
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
-// RING (k-major weights): the weight tiles go through a THREE-slot ring and the K loop never drains its DMA -- a counted
-// s_waitcnt vmcnt(4) + bare s_barrier per K-tile instead of __syncthreads (= vmcnt(0) + barrier): the weight tile of K-tile
-// kt + 2 (HBM) is issued two tiles ahead, the token tile of kt + 1 (L2) one tile ahead; 2 x 16 KB + 3 x 16 KB = 80 KB per block,
-// still two blocks per CU.  Same k order, same bits.
-template <typename T, bool W_KMAJOR, int ACT, bool NT, bool ROT, bool RING = false>
+// (Round 4 gave this kernel a three-slot weight ring with a counted s_waitcnt vmcnt + bare s_barrier instead of the per-K-tile
+// __syncthreads drain, 80 KB per block, still two blocks per CU -- VERDICT r3's proposal.  Measured: 113.1 / 112.9 us against
+// 112.4 / 111.9 us for this two-stage form at the headline shape (profiles/r04_headline_ab.json): with two blocks per CU the other
+// block's tile is in flight whenever this one drains, and the memory system is saturated either way.  Not kept.  What did pay is
+// fewer bytes crossing L2 -> LDS per weight byte: the 128 x 256 tile of expert_gemm_big_kernel<.., BM = 128> below.)
+template <typename T, bool W_KMAJOR, int ACT, bool NT, bool ROT>
 __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArgs p) {
-  static_assert(!RING || W_KMAJOR, "the ring variant is for k-major weights");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t *sA = reinterpret_cast<uint16_t *>(smem);  // [2][GL_STAGE]
-  uint16_t *sW = sA + 2 * GL_STAGE;                   // [2][GL_STAGE]  (RING: [3][GL_STAGE])
+  uint16_t *sW = sA + 2 * GL_STAGE;                   // [2][GL_STAGE]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -514,53 +514,6 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
         acc[ni][mi] = Mma<T>::run(FW[ni], FA[mi], acc[ni][mi]);                        \
   } while (0)
 
-#define GL_ISSUE_A(KT, BUF)                                                            \
-  do {                                                                                 \
-    int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
-    const size_t ao_ = (size_t)kr_ * GL_BK;                                            \
-    uint16_t *da_ = sA + (BUF) * GL_STAGE + piece0;                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
-  } while (0)
-#define GL_ISSUE_W(KT, BUF)                                                            \
-  do {                                                                                 \
-    int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
-    const size_t wo_ = (size_t)kr_ * w_step;                                           \
-    uint16_t *dw_ = sW + (BUF) * GL_STAGE + piece0;                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, NT); \
-  } while (0)
-
-  if (RING) {
-    // in flight per wave, in issue order, when K-tile kt is awaited: [A(kt) x4] [W(kt+1) x4] -- W(kt) is older than both
-    GL_ISSUE_A(0, 0);
-    GL_ISSUE_W(0, 0);
-    if (nk > 1) GL_ISSUE_W(1, 1);
-    int wslot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int abuf = kt & 1;
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt have landed; every wave is done reading the slots refilled below
-      if (kt + 1 < nk) GL_ISSUE_A(kt + 1, abuf ^ 1);
-      if (kt + 2 < nk) GL_ISSUE_W(kt + 2, wslot == 0 ? 2 : wslot - 1);  // (wslot + 2) % 3
-      const uint16_t *ca = sA + abuf * GL_STAGE, *cw = sW + wslot * GL_STAGE;
-      u32x4 fa[4][2], fw[4][2];
-      GL_LOAD_FRAGS(fa[0], fw[0], 0);
-      GL_LOAD_FRAGS(fa[1], fw[1], 1);
-      GL_LOAD_FRAGS(fa[2], fw[2], 2);
-      GL_LOAD_FRAGS(fa[3], fw[3], 3);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      GL_MMA(fa[0], fw[0]);
-      GL_MMA(fa[1], fw[1]);
-      GL_MMA(fa[2], fw[2]);
-      GL_MMA(fa[3], fw[3]);
-      __builtin_amdgcn_sched_barrier(0);
-      wslot = wslot == 2 ? 0 : wslot + 1;
-    }
-    gemm_epilogue<T, ACT>(p, acc, bias_r, e, m0, n0, wm, wn, l31, kg, row_limit);
-    return;
-  }
-
   GL_ISSUE(0, 0);
   __syncthreads();  // with a DMA in flight this is vmcnt(0) + barrier: tile 0 is in LDS stage 0
 
@@ -584,8 +537,6 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
     __syncthreads();  // all waves done with stage `buf`; next tile's DMA has landed (vmcnt(0))
   }
 #undef GL_ISSUE
-#undef GL_ISSUE_A
-#undef GL_ISSUE_W
 #undef GL_LOAD_FRAGS
 #undef GL_MMA
 
@@ -1264,17 +1215,6 @@ static int launch_glds(const GemmArgs &a, int grid, hipStream_t st) {
   return 0;
 }
 
-// the three-slot weight ring of the 128 x 128 LDS-DMA kernel (k-major weights): 80 KB of LDS per block
-template <typename T, int ACT>
-static int launch_glds_ring(const GemmArgs &a, int grid, hipStream_t st) {
-  const size_t lds = (size_t)5 * GL_STAGE * 2;
-  auto kern = expert_gemm_glds_kernel<T, true, ACT, true, true, true>;
-  if (!lds_optin((const void *)kern, lds)) return -1;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(GM_THREADS), lds, st, a);
-  TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
-  return 0;
-}
-
 // -------------------------------------------------------------------------------------------
 // ds_read_b64_tr_b16 permutation probe (self-test)
 // -------------------------------------------------------------------------------------------
@@ -1350,11 +1290,16 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
     if (KM && (big == 3 || (big < 0 && a.R > GM_BM && t128 >= 192)))
       return a.fits32 && tutel_get_option(TUTEL_OPT_GEMM_IMPL) != 2 ? launch_big<T, true, ACT, 2, 3, true>(a, st) : launch_big<T, true, ACT, 2, 3>(a, st);
   }
-  // round 4 A/B (TUTEL_OPT_GEMM_IMPL): 3 = the three-slot weight ring on the 128 x 128 tile, 4 = the 128 x 256 tile on a three-slot
-  // ring (one 4-wave block per CU); both k-major only, both bit-identical to the others
-  if (KM && impl == 3) return launch_glds_ring<T, ACT>(a, grid, st);
-  if (KM && impl == 4 && a.fits32 && a.N >= 256) return launch_big<T, true, ACT, 4, 3, true, 128>(a, st);
-  const bool use_dma = impl < 0 ? KM : (impl == 1 || impl >= 3);
+  // Round 4: all rows of an expert in one M-tile (R <= 128: weight streaming from HBM is the bound) and k-major weights -> the
+  // 128 x 256 tile on a three-slot ring, one 4-wave block per CU: the token tile crosses L2 -> LDS once per 256 columns instead of
+  // once per 128 and 96 KB of DMA are in flight per CU.  Headline shape (64 x 128 rows, 2048^2): fc1 112.4 -> 108.1 us, fc2
+  // 111.9 -> 106.6 us, the forward 264.0 -> 258.4 us, same bits (profiles/r04_headline_ab.json).  Only when the grid still covers
+  // the chip (one 144 KB block per CU): with fewer tiles the 128 x 128 kernel's twice as many blocks keep more CUs busy.
+  // TUTEL_OPT_GEMM_IMPL = 4 forces it (where it applies), 1 forces the 128 x 128 LDS-DMA kernel.
+  const bool ring256_ok = KM && a.fits32 && a.N >= 256 && a.R <= GM_BM;
+  if (ring256_ok && (impl == 4 || (impl < 0 && (long long)a.E_loc * ((a.N + 255) / 256) >= 256)))
+    return launch_big<T, true, ACT, 4, 3, true, 128>(a, st);
+  const bool use_dma = impl < 0 ? KM : (impl == 1 || impl == 4);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
   return launch_cfg<T, KM, ACT>(a, grid, st);
 }

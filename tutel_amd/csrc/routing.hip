@@ -460,111 +460,22 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
 #define GQ_LPT 16
 #define GQ_THREADS 1024
 
-typedef __attribute__((ext_vector_type(16))) float rt_f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 rt_bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 rt_f16x8;
-typedef __attribute__((ext_vector_type(4))) uint32_t rt_u32x4;
-template <typename T> struct RtMma;
-template <> struct RtMma<bf16_t> {
-  __device__ static __forceinline__ rt_f32x16 run(rt_u32x4 a, rt_u32x4 b, rt_f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rt_bf16x8, a), __builtin_bit_cast(rt_bf16x8, b), c, 0, 0, 0);
-  }
-};
-template <> struct RtMma<f16_t> {
-  __device__ static __forceinline__ rt_f32x16 run(rt_u32x4 a, rt_u32x4 b, rt_f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rt_f16x8, a), __builtin_bit_cast(rt_f16x8, b), c, 0, 0, 0);
-  }
-};
-template <> struct RtMma<float> {  // (never instantiated with NE > 0; keeps the template well-formed)
-  __device__ static __forceinline__ rt_f32x16 run(rt_u32x4, rt_u32x4, rt_f32x16 c) { return c; }
-};
-template <> struct RtMma<double> {
-  __device__ static __forceinline__ rt_f32x16 run(rt_u32x4, rt_u32x4, rt_f32x16 c) { return c; }
-};
-
-// the gate projection of one 64-token pass: wave (th, ne, ks) leaves its 32 x 32 fp32 partial (tokens th*32.., experts ne*32..,
-// K slice ks) in s_part[ks][token][E + 1].  A function of its own, not inlined: inside the top-k kernel's token loop hipcc ran
-// out of the block's 128-VGPR budget and drained its loads every iteration.
-template <typename T, int NE>
-__device__ __attribute__((noinline)) void gate_proj_partials(const T *__restrict__ in, const T *__restrict__ wg, float *s_part, int ts, int Tn,
-                                                             int E, int M, int ldx) {
-  constexpr int KS = 8 / NE;
-  const int EP = E + 1;
-  const int tid = threadIdx.x;
-  const int wid = tid >> 6, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
-  const int th = wid & 1, ne = (wid >> 1) % NE, ks = (wid >> 1) / NE;
-  const int klen = M / KS, steps = klen / 16;      // host guarantees M % (16 * KS * 8) == 0: steps is a multiple of 8
-  const uint16_t *xa = reinterpret_cast<const uint16_t *>(in) + (size_t)min(ts + th * 32 + l31, Tn - 1) * ldx + ks * klen + kg * 8;
-  const uint16_t *wa = reinterpret_cast<const uint16_t *>(wg) + (size_t)(ne * 32 + l31) * M + ks * klen + kg * 8;
-  rt_f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // three register sets of 2 steps (4 x 16-byte loads each): the loads of the next two batches are issued before the MFMAs
-  // of the current one, so 8-12 loads per wave (128-192 KB per CU with 16 waves) are in flight throughout.  Straight-line
-  // code with scheduling barriers: left alone, hipcc interleaves loads and MFMAs with 3-4 loads in flight; with larger
-  // batches the block's 128-VGPR budget (1024 threads) makes it rotate registers and drain the loads every iteration.
-  rt_u32x4 fa0[2], fb0[2], fa1[2], fb1[2], fa2[2], fb2[2];
-#define GP_LOAD(FA, FB, S0)                                                                    \
-  do {                                                                                     \
-    const int s_ = (S0) < steps ? (S0) : steps - 2;   /* past the end: re-read the last batch, unused */ \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                        \
-      FA[u] = *(const __attribute__((address_space(1))) rt_u32x4 *)(wa + (s_ + u) * 16);   \
-      FB[u] = *(const __attribute__((address_space(1))) rt_u32x4 *)(xa + (s_ + u) * 16);   \
-    }                                                                                      \
-  } while (0)
-#define GP_MMA(FA, FB) do { _Pragma("unroll") for (int u = 0; u < 2; ++u) acc = RtMma<T>::run(FA[u], FB[u], acc); } while (0)
-#define GP_STEP(CUR_A, CUR_B, NXT_A, NXT_B, S0)                                                \
-  do {                                                                                     \
-    GP_LOAD(NXT_A, NXT_B, S0);                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    GP_MMA(CUR_A, CUR_B);                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-  } while (0)
-  GP_LOAD(fa0, fb0, 0);
-  GP_LOAD(fa1, fb1, 2);
-  int s0 = 0;
-  for (; s0 + 6 <= steps; s0 += 6) {   // sets rotate 0 -> 1 -> 2: the batch loaded now is consumed two batches later
-    GP_STEP(fa0, fb0, fa2, fb2, s0 + 4);
-    GP_STEP(fa1, fb1, fa0, fb0, s0 + 6);
-    GP_STEP(fa2, fb2, fa1, fb1, s0 + 8);
-  }
-  // steps is a multiple of 8, so steps % 6 is 2 or 4 (or 0): the remaining batches are in sets 0 (and 1)
-  if (s0 < steps) { GP_MMA(fa0, fb0); s0 += 2; }
-  if (s0 < steps) { GP_MMA(fa1, fb1); s0 += 2; }
-#undef GP_STEP
-#undef GP_LOAD
-#undef GP_MMA
-  // the lane holds, for token th*32 + l31, experts ne*32 + 8*rg + 4*kg + r
-  // (explicit address spaces: through the generic pointers of a non-inlined function these would be FLAT accesses, which count
-  // on both vmcnt and lgkmcnt and made hipcc drain every load before each MFMA batch)
-  __attribute__((address_space(3))) float *pp =
-      (__attribute__((address_space(3))) float *)(s_part + ((size_t)ks * 64 + th * 32 + l31) * EP + ne * 32 + kg * 4);
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pp[rg * 8 + r] = acc[rg * 4 + r];
-}
-
-// NE > 0 (round 4): the GATE PROJECTION runs inside this kernel (gates/top.py:20-22 `logits = wg(x)` + moe_layer.py:290 softmax
-// + fast_dispatch.py:146-151 top-k in ONE launch; the [T, E] logits never make an HBM round trip between a library GEMM and
-// this kernel).  NE = E / 32 expert tiles of v_mfma_f32_32x32x16; the block's 16 waves are 2 (32-token halves of the 64-token
-// pass) x NE (32-expert tiles) x KS = 8 / NE slices of the model dimension; every wave streams its fragments straight from
-// global memory (x from HBM, wg from L2: 16 loads in flight per wave, 256 KB per CU) and leaves a 32 x 32 fp32 partial in LDS;
-// the logit of (token, expert) is the sum of its KS partials in slice order, rounded once to T -- what a bf16 / fp16 nn.Linear
-// returns, up to the order of the fp32 sum (the checker is fed these logits, `logits_out`).  in / ldx: the tokens [T, ldx];
-// wg: [E, M] row-major, both of type T.
-template <typename T, int EPQ, int NE>
+// (Round 4 tried the gate PROJECTION inside this kernel -- x @ wg^T on MFMA with the fragments streamed straight from global memory,
+// 16 waves = 2 token halves x E/32 expert tiles x K slices, partials reduced through LDS: 38.5 us against 15.7 us for the library
+// GEMM + this kernel (profiles/r04_headline_ab.json).  One workgroup per 64-token tile is 64 workgroups, and fragment loads of
+// 32 bytes per row and instruction are bound by the L1 request rate, not by HBM; a coalesced version is the expert GEMM's LDS-DMA
+// pipeline plus a split-K reduction across workgroups, i.e. the library's skinny GEMM again.  Removed.)
+template <typename T, int EPQ>
 __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
-    int clear_n, const T *__restrict__ wg, int M, int ldx, T *__restrict__ logits_out) {
+    int clear_n) {
   using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ES = GQ_LPT * EPQ + 1;                                    // padded row of the score tile
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);                // [k][E]
   float *s_sc = reinterpret_cast<float *>(smem) + (size_t)k * E;      // [64][ES]
-  float *s_part = s_sc + 64 * ES;                                     // NE > 0: [KS][64][E + 1] partial logits
 
   const int tid = threadIdx.x, q = tid & (GQ_LPT - 1), tl = tid / GQ_LPT;  // tl = token slot 0..63
   const int b = blockIdx.x;
@@ -583,27 +494,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     const int t = ts + tl;
     const bool live = t < t1;
     CT v[EPQ];
-    if constexpr (NE > 0) {
-      constexpr int KS = 8 / NE;
-      const int EP = E + 1;
-      gate_proj_partials<T, NE>(in, wg, s_part, ts, Tn, E, M, ldx);
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < EPQ; ++j) {
-        const int e = q * EPQ + j;
-        float sum = 0.f;
-        if (e < E) {
-          sum = s_part[(size_t)tl * EP + e];
-#pragma unroll
-          for (int s2 = 1; s2 < KS; ++s2) sum += s_part[((size_t)s2 * 64 + tl) * EP + e];
-          const T r = Elem<T>::from_f32(sum);
-          if (logits_out != nullptr && live) logits_out[(size_t)t * E + e] = r;
-          v[j] = Elem<T>::to_f32(r);
-        } else {
-          v[j] = -INFINITY;
-        }
-      }
-    } else {
+    {
       const T *row = in + (size_t)min(t, Tn - 1) * E + q * EPQ;
 #pragma unroll
       for (int j = 0; j < EPQ; ++j) {
@@ -735,19 +626,10 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cumsum_kernel(const int32_t *__
 // -------------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------------
-// gate projection inside the top-k kernel: which (dtype, E, M) it takes (see gate_topk_quad_kernel, NE > 0)
-static bool gate_proj_ok(int dtype, int E, int M) {
-  if (dtype != TUTEL_BF16 && dtype != TUTEL_F16) return false;
-  if (E != 32 && E != 64 && E != 128) return false;
-  const int ks = 8 / (E / 32);
-  return M >= 128 * ks && M % (128 * ks) == 0;   // every wave's K slice is a whole number of 8-step (128-element) batches
-}
-
 template <typename T>
 static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, int k, int normalize,
                             void *scores_out, int32_t *idx, void *gates, void *ws,
-                            int32_t *clear_map, int clear_n, hipStream_t st, const void *wg = nullptr, int M = 0, int ldx = 0,
-                            void *logits_out = nullptr) {
+                            int32_t *clear_map, int clear_n, hipStream_t st) {
   const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
@@ -756,26 +638,14 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
     const int epq = (E + GQ_LPT - 1) / GQ_LPT;                 // 1..8
     const int epq_t = epq <= 1 ? 1 : (epq <= 2 ? 2 : (epq <= 4 ? 4 : 8));
     const size_t lds_q = ((size_t)k * E + (size_t)64 * (GQ_LPT * epq_t + 1)) * 4;
-#define GQ_LAUNCH(EPQ, NE)                                                                     \
-    do {                                                                                       \
-      auto kern_ = gate_topk_quad_kernel<T, EPQ, NE>;                                          \
-      const size_t lds_ = lds_q + ((NE) > 0 ? (size_t)(8 / ((NE) > 0 ? (NE) : 1)) * 64 * (E + 1) * 4 : 0); \
-      if (lds_ > 65536) {                                                                      \
-        (void)hipFuncSetAttribute((const void *)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
-        (void)hipGetLastError();                                                               \
-      }                                                                                        \
-      hipLaunchKernelGGL(kern_, dim3(nt), dim3(GQ_THREADS), lds_, st,                          \
-                         (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,        \
-                         idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, (const T *)wg, M, ldx, (T *)logits_out); \
-    } while (0)
-    if (wg != nullptr) {   // (gate_proj_ok: E in {32, 64, 128} -> EPQ = E / 16)
-      if (E == 32) GQ_LAUNCH(2, 1);
-      else if (E == 64) GQ_LAUNCH(4, 2);
-      else GQ_LAUNCH(8, 4);
-    } else if (epq_t == 1) GQ_LAUNCH(1, 0);
-    else if (epq_t == 2) GQ_LAUNCH(2, 0);
-    else if (epq_t == 4) GQ_LAUNCH(4, 0);
-    else GQ_LAUNCH(8, 0);
+#define GQ_LAUNCH(EPQ)                                                                         \
+    hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ>), dim3(nt), dim3(GQ_THREADS), lds_q, st,            \
+                       (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,          \
+                       idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n)
+    if (epq_t == 1) GQ_LAUNCH(1);
+    else if (epq_t == 2) GQ_LAUNCH(2);
+    else if (epq_t == 4) GQ_LAUNCH(4);
+    else GQ_LAUNCH(8);
 #undef GQ_LAUNCH
     TUTEL_CHECK_LAUNCH("tutel_amd_gate_topk");
     return 0;
@@ -823,24 +693,6 @@ extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax,
   if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   return launch_gate_topk<f16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
-}
-
-extern "C" int tutel_amd_gate_proj_topk(const void *x, int ldx, const void *wg, int dtype, int T, int M, int E, int k, int normalize_gate,
-                                        void *logits_out, int32_t *idx, void *gates, void *ws, size_t ws_bytes, int32_t *clear_map,
-                                        int clear_n, tutel_stream_t stream) {
-  TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_gate_proj_topk: unsupported dtype %d", dtype);
-  TUTEL_REQUIRE(T >= 0 && M >= 1 && E >= 1 && k >= 1 && k <= RT_MAX_K && k <= E && ldx >= M, "tutel_amd_gate_proj_topk: bad sizes T=%d M=%d E=%d k=%d ldx=%d", T, M, E, k, ldx);
-  if (!gate_proj_ok(dtype, E, M)) return TUTEL_AMD_ENOTSUP;  // (not an error: the caller projects with a library GEMM and runs tutel_amd_gate_topk)
-  if (T == 0) return 0;
-  TUTEL_REQUIRE(x && wg && idx && gates && ws, "tutel_amd_gate_proj_topk: null pointer");
-  TUTEL_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wg % 16) == 0 && ldx % 8 == 0, "tutel_amd_gate_proj_topk: rows must be 16-byte aligned");
-  TUTEL_REQUIRE(ws_bytes >= tutel_amd_routing_workspace_bytes(T, E, k), "tutel_amd_gate_proj_topk: workspace too small");
-  TUTEL_REQUIRE(clear_n >= 0 && (clear_map != nullptr || clear_n == 0), "tutel_amd_gate_proj_topk: bad clear_map");
-  if (clear_n == 0) clear_map = nullptr;
-  hipStream_t st = (hipStream_t)stream;
-  StageScope stage(TUTEL_STAGE_GATE_TOPK, st);
-  if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(x, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear_map, clear_n, st, wg, M, ldx, logits_out);
-  return launch_gate_topk<f16_t>(x, 1, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear_map, clear_n, st, wg, M, ldx, logits_out);
 }
 
 extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int k, int hist_ready,

@@ -538,7 +538,7 @@ class _MoeWorkspace(_Workspace):
     """_Workspace + the routing buffers (idx / loc / gates / slot map / per-tile histograms), all reused call after call"""
 
     def __init__(self, layer, x, logits, k, capacity, degree, comm, T_cap):
-        E, T = logits.shape[1], int(T_cap)   # (logits: the tensor, or a meta tensor of its shape / dtype when the projection is fused)
+        E, T = logits.shape[1], int(T_cap)
         dev = x.device
         super().__init__(layer, x, E, capacity, k, degree, comm, T_cap)
         self.idx = torch.empty([k, T], dtype=torch.int32, device=dev)
@@ -561,30 +561,11 @@ class _MoeWorkspace(_Workspace):
         self.margs = m
 
 
-def proj_fusable(gate, x):
-    """may the gate projection run inside the top-k kernel (tutel_amd_gate_proj_topk)?  The stock linear gate in the tokens' own
-    bf16 / fp16 dtype, nobody listening on the module (forward hooks would not fire), no gradient wanted, a shape the kernel takes"""
-    from ..gates.top import LinearTopKGate
-    if type(gate) is not LinearTopKGate or gate.fp32_gate or ops.get_option(_lib.OPT_ROUTING) == 0:
-        return False
-    w = gate.wg.weight
-    if gate._forward_hooks or gate._forward_pre_hooks or gate.wg._forward_hooks or gate.wg._forward_pre_hooks:
-        return False
-    if not (x.is_cuda and x.dim() == 2 and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16) and w.is_contiguous()):
-        return False
-    if torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
-        return False
-    E, M = w.shape
-    return E in (32, 64, 128) and M % (1024 // (E // 32)) == 0 and x.shape[1] == M
-
-
-def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss, dropless=None, megablocks_size=0, gate_w=None):
+def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss, dropless=None, megablocks_size=0):
     """x [T, M], logits [T, E] -> (y [T, M_out], l_aux | None, dispatch_count [E], capacity); None when the native path is
     unavailable.  One C call: softmax + top-k + locations + loss, encode, exchange(s), expert FFN, exchange(s), decode.
     dropless = (capacity_limit, alignment): capacity_factor <= 0 on a single rank -- the capacity is read back inside the call
-    (`capacity` is then only the first guess for the workspace size).
-    gate_w [E, M]: the gate projection runs inside the call as well (`logits` is then a meta tensor giving shape and dtype);
-    layer._keep_logits (tests): the logits the kernel used are kept as layer.last_logits."""
+    (`capacity` is then only the first guess for the workspace size)."""
     ex = layer.experts
     W = layer.world_size
     with_comm = W > 1 or (_FORCE_COMM and dist.is_initialized())
@@ -620,14 +601,7 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
             a.row_counts, a.row_align = cnt.data_ptr(), int(megablocks_size)
         else:
             a.row_counts, a.row_align = None, 1
-        m.normalize_gate = int(bool(normalize_gate))
-        if gate_w is not None:
-            m.logits, m.gate_w, m.logits_out = None, gate_w.data_ptr(), None
-            if getattr(layer, "_keep_logits", False):
-                layer.last_logits = torch.empty(list(logits.shape), dtype=logits.dtype, device=dev)
-                m.logits_out = layer.last_logits.data_ptr()
-        else:
-            m.logits, m.gate_w, m.logits_out = logits.data_ptr(), None, None
+        m.logits, m.normalize_gate = logits.data_ptr(), int(bool(normalize_gate))
         m.dispatch_count = cnt.data_ptr()
         m.l_aux = l_aux.data_ptr() if l_aux is not None else None
         cap_out = ws.cap_c

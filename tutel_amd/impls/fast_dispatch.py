@@ -143,6 +143,42 @@ class TutelMoeFastDispatcher:
 fast_dispatcher = TutelMoeFastDispatcher
 
 
+_aten_warned = set()
+
+
+def _routing_limits_exceeded(E, k):
+    """outside the routing kernels' shapes (csrc/routing.hip: per-tile expert histograms live in LDS)"""
+    return E > 4096 or k > 16 or k * E > 8192
+
+
+def _locations_aten(idx2d, E):
+    """the reference's own op chain for the slots (fast_dispatch.py:150,159-171,177-178) -- one-hot masks, k column cumsums
+    (tutel_amd_cumsum_sub_one takes any E), masked row sums -- for expert counts the routing kernels do not take"""
+    k, T = idx2d.shape
+    acc = torch.zeros([E], dtype=torch.int32, device=idx2d.device)
+    locs = []
+    for j in range(k):
+        valid = idx2d[j] >= 0
+        mask = torch.zeros([T, E], dtype=torch.int32, device=idx2d.device)
+        mask.scatter_(1, idx2d[j].clamp(min=0).long().unsqueeze(-1), valid.to(torch.int32).unsqueeze(-1))
+        loc = ops.cumsum_sub_one(mask) + acc.unsqueeze(0)
+        locs.append((loc * mask).sum(dim=1).to(torch.int32))
+        acc = acc + mask.sum(dim=0, dtype=torch.int32)
+    stats = acc.max().reshape(1) if E > 0 else torch.zeros([1], dtype=torch.int32, device=idx2d.device)
+    return torch.stack(locs).contiguous(), acc, stats.to(torch.int32)
+
+
+def _topk_aten(work, k, apply_softmax, normalize_gate):
+    """torch.topk + gather + normalise, op for op as fast_dispatch.py:146-151,173-175 (tie order: torch.topk's, like upstream)"""
+    sc = torch.softmax(work, dim=1) if apply_softmax else work
+    top = torch.topk(sc, k, dim=1).indices
+    gl = [sc.gather(1, top[:, j:j + 1]).squeeze(-1) for j in range(k)]
+    if k > 1 and normalize_gate:
+        denom = torch.clamp(sum(gl), min=torch.finfo(gl[0].dtype).eps)
+        gl = [g / denom for g in gl]
+    return top.t().contiguous().to(torch.int32), torch.stack(gl).contiguous(), sc
+
+
 def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=1.0,
                      batch_prioritized_routing=False, normalize_gate=True, alignment=1, group=None,
                      inequivalent_tokens=False, _logits=None):
@@ -171,16 +207,40 @@ def extract_critical(scores, top_k, loss_fn=losses.gshard_loss, capacity_factor=
     else:
         capacity = 0  # known only after the counts are
 
+    # Shapes past the routing kernels' limits (E > 4096, k > 16, k * E > 8192): upstream's ATen chain takes any E and k
+    # (fast_dispatch.py:145-148), so a drop-in must not raise there -- the same op chain runs on the device instead, loudly (once
+    # per shape).  The C ABI itself still refuses such shapes with an error naming the limit.
+    aten = _routing_limits_exceeded(E, k)
+    if aten and (E, k) not in _aten_warned:
+        _aten_warned.add((E, k))
+        logging.warning("tutel_amd: routing with E = %d, k = %d is outside the HIP routing kernels' limits (E <= 4096, k <= 16, k * E <= 8192): "
+                        "running the reference's ATen op chain on the device instead", E, k)
+
     # the top-k launch also clears the bucket->token map the location launch fills
     pre = None
-    if capacity > 0 and not batch_prioritized_routing:
-        pre = torch.empty([E * capacity], dtype=torch.int32, device=src.device)
-    idx2d, gates2d, ws, scores_k = ops.gate_topk(work.detach(), k, apply_softmax=_logits is not None,
-                                                 normalize_gate=normalize_gate,
-                                                 want_scores=(_logits is not None and (needs_grad or loss_fn not in (None, losses.gshard_loss))),
-                                                 clear=pre)
+    if aten:
+        idx2d, gates2d, scores_k = _topk_aten(work.detach(), k, _logits is not None, normalize_gate)
+        ws = None
+        fused_loss = False
+    else:
+        if capacity > 0 and not batch_prioritized_routing:
+            pre = torch.empty([E * capacity], dtype=torch.int32, device=src.device)
+        idx2d, gates2d, ws, scores_k = ops.gate_topk(work.detach(), k, apply_softmax=_logits is not None,
+                                                     normalize_gate=normalize_gate,
+                                                     want_scores=(_logits is not None and (needs_grad or loss_fn not in (None, losses.gshard_loss))),
+                                                     clear=pre)
 
-    if batch_prioritized_routing:
+    if aten:
+        if batch_prioritized_routing:
+            order = torch.argsort(-scores_k.max(dim=1)[0], stable=True)
+            inv = torch.empty_like(order)
+            inv[order] = torch.arange(T, device=order.device)
+            loc_s, cnt, stats = _locations_aten(idx2d[:, order].contiguous(), E)
+            loc2d = loc_s[:, inv].contiguous()
+        else:
+            loc2d, cnt, stats = _locations_aten(idx2d, E)
+        l_aux_k, smap = None, None
+    elif batch_prioritized_routing:
         # tokens ranked by -max score get their buckets first (fast_dispatch.py:138-141,155-157):
         # run the same stable rank on the importance-sorted order, then undo the permutation.
         sc = scores_k if _logits is not None and scores_k is not None else (work if _logits is None else torch.softmax(work.float(), 1))

@@ -284,7 +284,7 @@ class MOELayer(torch.nn.Module):
         rem = capacity % alignment
         return capacity + ((alignment - rem) if rem > 0 else 0)
 
-    def _run_native_moe(self, x, logits, top_k, cf, degree, alignment, megablocks_size, gate_w=None):
+    def _run_native_moe(self, x, logits, top_k, cf, degree, alignment, megablocks_size):
         T, E = logits.shape
         k = min(top_k, E)
         spe = (T + E - 1) // E
@@ -292,11 +292,10 @@ class MOELayer(torch.nn.Module):
         if cf <= 0:   # dropless: capacity = max expert load, read back inside the native call (fast_dispatch.py:191-199)
             guess = (k * spe * 3 // 2 + 31) // 32 * 32
             res = ep_native.forward_from_logits(self, xc, logits.contiguous(), k, guess, 1, self.normalize_gate, want_loss=True,
-                                                dropless=(k * int(-cf * spe) if cf < 0 else 0, alignment), megablocks_size=megablocks_size,
-                                                gate_w=gate_w)
+                                                dropless=(k * int(-cf * spe) if cf < 0 else 0, alignment), megablocks_size=megablocks_size)
         else:
             res = ep_native.forward_from_logits(self, xc, logits.contiguous(), k, self._static_capacity(T, E, k, cf, alignment), degree,
-                                                self.normalize_gate, want_loss=True, gate_w=gate_w)
+                                                self.normalize_gate, want_loss=True)
         if res is None:   # the library's communicator could not be created: every rank falls back together
             return None
         y, l_aux, cnt, capacity = res
@@ -347,15 +346,6 @@ class MOELayer(torch.nn.Module):
             return self.result_func(y) if self.result_func is not None else y
 
         plan_args = (gate, top_k, cf, degree, alignment, reserve_shape, inequivalent_tokens, megablocks_size, original_dtype)
-        # the stock linear gate in the tokens' dtype: the projection itself can run inside the routing kernel of the one-call path
-        # (tutel_amd_gate_proj_topk) -- the planner only needs the logits' shape and dtype for that decision
-        if x.is_cuda and not torch.is_autocast_enabled() and ep_native.proj_fusable(gate, x):
-            spec = torch.empty([x.shape[0], gate.wg.weight.shape[0]], dtype=x.dtype, device="meta")
-            if self._plan("before_routing", x, spec, *plan_args) == "native_moe":
-                res = self._run_native_moe(x, spec, top_k, cf, degree, alignment, megablocks_size, gate_w=gate.wg.weight)
-                if res is not None:
-                    return finish(*res)
-
         # the gate projection: computed ONCE, autocast off (moe_layer.py:315-323), whatever path consumes it
         if x.is_cuda:
             with torch.autocast("cuda", enabled=False):

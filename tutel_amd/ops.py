@@ -110,28 +110,6 @@ def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False, l_aux_dtype=
     return loc, cnt, stats, l_aux, smap
 
 
-def gate_proj_topk(x, wg, k, normalize_gate=True, want_logits=False, ws=None, clear=None):
-    """x [T, M], wg [E, M] (bf16 / fp16) -> idx [k,T], gates [k,T], ws, logits | None: the gate projection, softmax and top-k in ONE
-    launch (tutel_amd_gate_proj_topk).  Returns None when the kernel does not take the shape (the caller then projects with
-    F.linear and calls gate_topk)."""
-    _dev(x, wg)
-    assert x.dim() == 2 and wg.dim() == 2 and x.shape[1] == wg.shape[1] and x.dtype == wg.dtype
-    x, wg = x.contiguous(), wg.contiguous()
-    (T, M), E = x.shape, wg.shape[0]
-    k = min(int(k), E)
-    idx = torch.empty([k, T], dtype=torch.int32, device=x.device)
-    gates = torch.empty([k, T], dtype=x.dtype, device=x.device)
-    logits = torch.empty([T, E], dtype=x.dtype, device=x.device) if want_logits else None
-    if ws is None:
-        ws = routing_workspace(T, E, k, x.device)
-    rc = _lib.lib().tutel_amd_gate_proj_topk(_ptr(x), M, _ptr(wg), _code(x), T, M, E, k, int(bool(normalize_gate)), _ptr(logits), _ptr(idx),
-                                             _ptr(gates), _ptr(ws), ws.numel(), _ptr(clear), clear.numel() if clear is not None else 0, _stream())
-    if rc == _lib.ENOTSUP:
-        return None
-    _lib.check(rc, "tutel_amd_gate_proj_topk")
-    return idx, gates, ws, logits
-
-
 def slot_map(idx, loc, E, capacity):
     _dev(idx, loc)
     assert idx.dtype == torch.int32 and loc.dtype == torch.int32
