@@ -36,9 +36,10 @@ kernel-trace average of the same command, written by tools/profile_r04.sh) and a
 csrc/expert_gemm.hip equals the one stamped there -- otherwise null with the reason.  `decode` and `extra.ep8_rank_gemms` are
 roofline objects of the second / third kernels of interest (fast_decode; the grouped GEMM at the per-rank shapes of an 8-way
 expert-parallel run: one pipeline stage, and the whole rank).
-Launch mode: with capacity_factor > 0 the forward never talks to the host, so the default is to capture it once in a HIP graph
-(tutel_amd.impls.graph.GraphedForward -- kernels, and with N > 1 the RCCL collectives of the library's communicator) and REPLAY
-it per step; `--eager` measures the Python-enqueued forward instead, and the line always carries the other mode beside it
+Launch mode: N = 1 times the Python-enqueued (eager) forward -- like rounds 1-2, GPU-paced (0.09 ms of host enqueue against
+0.25 ms of device work) -- and, beside it, the same forward captured once in a HIP graph (tutel_amd.impls.graph.GraphedForward) and
+REPLAYED per step (`--graph` makes the replay the timed mode); N > 1 replays the graph by default (`--eager` times eager): the
+line always carries the other mode beside the timed one
 (`launch_modes`, and `value_eager` at the top level).  If capture fails the script says so on stderr and in the line and runs eager.
 N > 1: the graph is replayed as well when the exchange is the IPC transport (plain kernels and events, epochs counted on the device:
 2000 replays in tests/test_ep_ipc_one_gpu.py; host cost 0.05 ms per forward against 0.16 ms eager); with RCCL on the path the
@@ -270,7 +271,12 @@ def main():
     # N > 1: the graph is replayed when the exchange is the IPC transport (kernels + events only); GraphedForward refuses to capture
     # RCCL collectives (replaying them hung after ~200 replays in the 1-rank-communicator probe, profiles/r03_ep_streams.txt) and
     # the forward is then timed eager -- every rank takes the same branch (the transport is agreed at communicator creation).
-    want_graph = (args.graph or not args.eager) and args.capacity_factor > 0
+    # N = 1: eager is the timed mode (comparable with rounds 1-2; and with the round-4 kernels it measured faster than the replay:
+    # 0.2538 vs 0.2612 ms, profiles/r04_bench_line.json -- the host enqueues a forward in ~0.09 ms, the device needs 0.25); the
+    # replay is timed beside it whenever it can be captured (`launch_modes.other`).
+    graph_default = world > 1
+    want_graph = (args.graph or (graph_default and not args.eager)) and args.capacity_factor > 0
+    also_graph = not want_graph and not args.eager and args.capacity_factor > 0 and world == 1
     if want_graph:
         # same kernels (and, N > 1, the same RCCL collectives on the caller's stream), enqueued by ONE hipGraphLaunch per step:
         # the host cost of a forward drops from ~0.09 (N = 1) / ~0.16 ms (N > 1, degree 2) to one launch, so the step is
@@ -307,11 +313,22 @@ def main():
         elapsed, _, _, y = run_timed(step, x, args.steps, world, gate_timer, mode=0, marks=False)
         nb = args.steps
         eager = eager_step
-        other = None
+        other, other_launch = None, None
         if launch != "eager":      # the same K steps, eager, bracketed the same way: reported beside the value
             for _ in range(max(3, args.warmup)):
                 eager(x)
             other, _, _, _ = run_timed(eager, x, args.steps, world, gate_timer, mode=0, marks=False)
+            other_launch = "eager"
+        elif also_graph:           # ... or, when eager is the timed mode, the HIP-graph replay of the same forward beside it
+            try:
+                from tutel_amd.impls.graph import GraphedForward
+                graphed = GraphedForward(layer, x, **fwd_kw)
+                for _ in range(max(3, args.warmup)):
+                    graphed(graphed.static_in)
+                other, _, _, _ = run_timed(graphed, graphed.static_in, args.steps, world, gate_timer, mode=0, marks=False)
+                other_launch = "hip-graph replay"
+            except Exception as ex:   # noqa: BLE001
+                graph_note = f"HIP-graph replay not timed ({type(ex).__name__}: {str(ex)[:160]})"
         _, per_step, _, _ = run_timed(step, x, nb, world, gate_timer, mode=0, marks=True)     # one mark per step: min / median
         run_timed(eager, x, 3, 1, gate_timer, mode=2, marks=False)                            # (fills the event pool)
         _, _, gemms, _ = run_timed(eager, x, nb, world, gate_timer, mode=2, marks=False)      # events around fc1 / fc2: roofline
@@ -405,7 +422,7 @@ def main():
             "metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "settle": args.settle, "launch": launch,
-            "value_eager": round(world * T / (other / args.steps), 1) if other is not None else (round(value, 1) if launch == "eager" else None),
+            "value_eager": round(value, 1) if launch == "eager" else (round(world * T / (other / args.steps), 1) if other is not None else None),
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dname, "data": "synthetic" if not share else "synthetic; TEST HOOK: all ranks share one GPU (IPC transport between the rank processes) -- not a measurement",
             "step_ms": {"mean_wall": round(ms, 4), "min": round(srt[0], 4), "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4),
@@ -436,7 +453,7 @@ def main():
                                "every event record drains the queue"},
             "decode": decode_obj,
             "launch_modes": {"timed": launch, "note": graph_note,
-                             "other": (None if other is None else {"launch": "eager", "ms_per_step": round(other / args.steps * 1e3, 4),
+                             "other": (None if other is None else {"launch": other_launch, "ms_per_step": round(other / args.steps * 1e3, 4),
                                                                    "value": round(world * T / (other / args.steps), 1)})},
             "layer_roofline": {"algorithmic_bytes_per_step": layer_bytes, "achieved_GBs": round(layer_bytes / (ms * 1e-3) * 1e-9, 1),
                                "frac_of_hbm_peak": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),

@@ -654,3 +654,115 @@ def test_helloworld_two_rank_training_losses_match_reference(case):
         if rank == 0:
             assert len(out) == len(case["losses"])
             assert all(abs(g - w) <= 1.5e-3 for g, w in zip(out, case["losses"])), (out, case["losses"])
+
+
+def test_capacity_bucket_depends_on_the_capacity_alone():
+    """the workspace's rows per expert used to be scaled by T_cap / T -- a rank with few or no tokens under an AGREED
+    capacity (inequivalent_tokens) got C * 256 / max(T, 1) rows per expert (C = 128, T = 0: 32768 rows, gigabytes per buffer), and
+    T < E serving shapes over-allocated 64x.  The bucket is a function of the capacity only: every rank derives the same value
+    (the IPC transport's segments rely on that), never more than twice the rows a call needs."""
+    from tutel_amd.impls import ep_native as N
+    for C in (1, 2, 31, 32, 33, 128, 157, 512, 1000, 4096):
+        b = N._bucket_capacity(C)
+        assert b >= max(C, 32) and b < 2 * max(C, 32) and b & (b - 1) == 0, (C, b)
+
+    class Layer:
+        pass
+
+    class WS:
+        def __init__(self, T_cap, C_cap):
+            self.T_cap, self.C_cap = T_cap, C_cap
+    for T in (0, 3, 200, 4096):      # an empty rank, a tiny rank, a mid-size rank under the same agreed capacity
+        lay = Layer()
+        ws = N._workspace(lay, ("cfg",), T, 128, lambda Tc, Cc: WS(Tc, Cc))
+        assert ws.C_cap == 128 and ws.T_cap >= max(T, 1), (T, ws.T_cap, ws.C_cap)
+
+
+class _FakeTensor:
+    """what MOELayer._plan looks at on a tensor (shape / dtype / device kind / grad), without a GPU"""
+
+    def __init__(self, shape, dtype, cuda=True, requires_grad=False):
+        self.shape, self.dtype, self.is_cuda, self.requires_grad = torch.Size(shape), dtype, cuda, requires_grad
+
+    def dim(self):
+        return len(self.shape)
+
+
+# one row per predicate of the planner, flipped alone from the base row (single rank, bf16, eval, capacity known up front).
+# columns: overrides -> (path chosen before routing, path chosen after routing when the one-call path did not take the forward)
+_PLAN_BASE = dict(W=1, degree=1, cf=1.0, x_dtype=torch.bfloat16, logits_dtype=torch.bfloat16, x_cuda=True, reserve=1, can_fuse=True,
+                  autocast=False, logits_grad=False, use_2dh=False, mega=0, group_ok=True, uneq=False, bpr=False, gshard=True,
+                  noise_training=False, E=64, k=2, T=4096, enabled=True, postscore=True, gates2d=True, adaptive_degree=1, alignment=1)
+_PLAN_ROWS = [
+    ("base", {}, "native_moe", "native_ep"),
+    ("experts cannot run on the fused GEMMs (custom / fp32 experts, autograd)", dict(can_fuse=False), "generic", "generic"),
+    ("CPU tensors", dict(x_cuda=False), "generic", "generic"),
+    ("reserve_dims = 2", dict(reserve=2), "generic", "generic"),
+    ("fp32 gate over bf16 experts", dict(logits_dtype=torch.float32), "native_moe", "native_ep"),
+    ("logits in another 16-bit dtype than the tokens", dict(logits_dtype=torch.float16), "generic", "generic"),
+    ("adaptive_r = 0 (all-gathered weights)", dict(adaptive_degree=0), "generic", "generic"),
+    ("autocast", dict(autocast=True), "routed", "native_ep"),
+    ("inequivalent_tokens", dict(uneq=True), "routed", "native_ep"),
+    ("batch-prioritised routing", dict(bpr=True), "routed", "native_ep"),
+    ("load-importance loss", dict(gshard=False), "routed", "native_ep"),
+    ("gate noise in training", dict(noise_training=True), "routed", "native_ep"),
+    ("trainable router (logits require grad)", dict(logits_grad=True), "routed", "native_ep"),
+    ("a trainable router keeps its gates with autograd", dict(logits_grad=True, gates2d=False), "routed", "fused_encode"),
+    ("... and without is_postscore", dict(logits_grad=True, gates2d=False, postscore=False), "routed", "generic"),
+    ("routing past the kernels' limits", dict(E=8192, k=2), "routed", "native_ep"),
+    ("dropless, single rank", dict(cf=0.0), "native_moe", "native_ep"),
+    ("dropless + megablocks", dict(cf=0.0, mega=4), "native_moe", "native_ep"),
+    ("dropless + megablocks, gates applied in encode", dict(cf=0.0, mega=4, postscore=False), "routed", "generic"),
+    ("megablocks with a fixed capacity", dict(mega=4), "routed", "native_ep"),
+    ("capacity not a multiple of the degree", dict(degree=4, T=4160, alignment=1, W=2), "routed", "generic"),
+    ("native pipeline switched off", dict(enabled=False), "routed", "fused_encode"),
+    ("... gates in encode", dict(enabled=False, postscore=False), "routed", "generic"),
+    ("two ranks, degree 1", dict(W=2), "native_moe", "native_ep"),
+    ("two ranks, degree 2", dict(W=2, degree=2, alignment=2), "native_moe", "native_ep"),
+    ("two ranks, dropless (capacity = all-reduce MAX)", dict(W=2, cf=0.0), "routed", "native_ep"),
+    ("two ranks, no exchange the library can drive (gloo rendezvous), degree 1", dict(W=2, group_ok=False), "routed", "generic"),
+    ("two ranks, gloo rendezvous, degree 2", dict(W=2, degree=2, alignment=2, group_ok=False), "routed", "python_overlap"),
+    ("two ranks, 2DH with overlap", dict(W=2, degree=2, alignment=2, use_2dh=True), "routed", "generic"),
+    ("two ranks, 2DH, degree 1", dict(W=2, use_2dh=True), "native_moe", "native_ep"),
+    ("degree beyond the library's event table (32): the Python-orchestrated pipeline takes it", dict(W=2, degree=33, alignment=33), "routed", "python_overlap"),
+]
+
+
+@pytest.mark.parametrize("name,over,before,after", _PLAN_ROWS, ids=[r[0] for r in _PLAN_ROWS])
+def test_planner_table(monkeypatch, name, over, before, after):
+    """MOELayer._plan: (W, degree, capacity factor, dtypes, autocast, grad, 2DH, megablocks, ...) -> the device path, one row per
+    predicate (a 20-term boolean needs a table that enumerates its inputs).  No GPU: the tensors are stand-ins that
+    answer what the planner asks of them."""
+    from tutel_amd.impls import ep_native, moe_layer as ML, communicate as CM
+    from tutel_amd.impls.fast_dispatch import RoutingPlan
+    from tutel import moe
+    c = dict(_PLAN_BASE, **over)
+    M, H = 128, 128
+    layer = moe.moe_layer(gate_type={"type": "top", "k": c["k"], "gate_noise": 1.0 if c["noise_training"] else 0.0}, model_dim=M,
+                          experts={"type": "ffn", "num_experts_per_device": 4, "hidden_size_per_expert": H},
+                          is_postscore=c["postscore"], is_gshard_loss=c["gshard"], batch_prioritized_routing=c["bpr"], use_2dh=c["use_2dh"])
+    layer.train(c["noise_training"])
+    layer.world_size = c["W"]
+    layer.adaptive_degree = c["adaptive_degree"]
+    monkeypatch.setattr(type(layer), "num_global_experts", property(lambda self: c["E"]))
+    monkeypatch.setattr(layer.experts, "can_fuse", lambda x, ctx: c["can_fuse"] and ctx.adaptive_degree != 0)
+    monkeypatch.setattr(ep_native, "ENABLED", c["enabled"])
+    monkeypatch.setattr(ep_native, "group_ok", lambda g: c["group_ok"])
+    monkeypatch.setattr(torch, "is_autocast_enabled", lambda *a: c["autocast"])
+    x = _FakeTensor([c["T"], M], c["x_dtype"], cuda=c["x_cuda"])
+    logits = _FakeTensor([c["T"], c["E"]], c["logits_dtype"], cuda=c["x_cuda"], requires_grad=c["logits_grad"])
+    args = (layer.gates[0], c["k"], c["cf"], c["degree"], c["alignment"], torch.Size([M] * c["reserve"]), c["uneq"], c["mega"], c["x_dtype"])
+    with torch.enable_grad():
+        got_before = layer._plan("before_routing", x, logits, *args)
+    assert got_before == before, (name, got_before)
+    k, T, E = c["k"], 8, c["E"]
+    capacity = layer._static_capacity(c["T"], E, k, c["cf"] if c["cf"] > 0 else 1.0, c["alignment"])
+    if "capacity not a multiple" in name:
+        capacity = 131
+    i32 = torch.zeros([k, T], dtype=torch.int32)
+    gl = None if c["gates2d"] else [torch.zeros([T]) for _ in range(k)]
+    crit = RoutingPlan(E, i32, i32, torch.zeros([k, T]) if c["gates2d"] else None, capacity, torch.zeros([E], dtype=torch.int32),
+                       torch.zeros([E * capacity], dtype=torch.int32), gl)
+    layer.megablocks_size = c["mega"]
+    got_after = layer._plan("after_routing", x, logits, *args, crit=crit)
+    assert got_after == after, (name, got_after)

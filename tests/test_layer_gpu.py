@@ -140,9 +140,10 @@ def test_headline_low_precision_gate_assignment_vs_reference(oracle, dts):
             json.dump(rec, f)
     print(rec)
     assert n_assign <= 256, rec          # ~1.5 % of the 8192 assignments in bf16 (ties), a handful more from logit rounding
-    # where the expert ids agree on EVERY token before t, so do the slots -- checked on the tie-free prefix
+    # where the first-choice expert ids agree on every token before t, so do the first-choice slots (a slot of the second choice is
+    # offset by the first choices' totals over ALL tokens, so one tie anywhere moves it): checked on the tie-free prefix
     first = diff[0] if diff else T
-    assert torch.equal(loc_p.cpu()[:, :first], loc_r[:, :first])
+    assert torch.equal(loc_p.cpu()[0, :first], loc_r[0, :first])
 
 
 NOISY = sorted(glob.glob(os.path.join(GOLD, "noisy_*.npz")))

@@ -1,9 +1,11 @@
-"""Expert parallelism over REAL RCCL (backend "nccl", one process per GPU, all_to_all_single over xGMI).
+"""Expert parallelism between REAL GPUs (backend "nccl" rendezvous, one process per GPU), over BOTH transports of the library:
+"ipc" -- the round-4 exchange, peer stores over xGMI from fast_encode and the fc2 epilogue, flag kernels, no collective -- and
+"rccl" -- ncclAllToAll on the library communicator (the fallback when a rank cannot map its peers' segments).
 
 Auto-enabled when the box exposes >= 2 GPUs (skipped on single-GPU boxes): W = 2 (and 4 / 8 when the
 devices are there), a2a_ffn_overlap_degree 1 and 2, against the oracle's W-rank simulation -- the
 reference's own assertion for this path is overlap-invariance (tests/test_tutel.py:161-176), checked
-here as well (degree 2 output == degree 1 output, bitwise)."""
+here as well (degree 2 output == degree 1 output, bitwise) -- plus, on the IPC transport, 300 HIP-graph replays."""
 import os
 import socket
 
@@ -29,15 +31,17 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, E_loc, q):
+def _worker(rank, world, port, E_loc, transport, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                          LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0", TUTEL_AMD_EP_TRANSPORT=transport)
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import torch.distributed as dist
         from oracle import moe_oracle as O
         from tutel import moe
+        from tutel_amd.impls import ep_native
+        assert ep_native.TRANSPORT == transport
         torch.cuda.set_device(rank)
         dev = torch.device("cuda", rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -65,6 +69,16 @@ def _worker(rank, world, port, E_loc, q):
             for degree in (1, 2, 1, 2):   # repeated: buffer reuse across the two streams must stay safe
                 outs.setdefault(degree, []).append(layer(x, a2a_ffn_overlap_degree=degree).clone())
         torch.cuda.synchronize()
+        comm = ep_native.communicator(layer.group, dev)
+        assert comm is not None and comm.ipc == (transport == "ipc"), f"transport {transport}: communicator ipc={getattr(comm, 'ipc', None)}"
+        if transport == "ipc":   # the captured forward replays (kernels + events only; RCCL collectives are refused by GraphedForward)
+            from tutel_amd.impls.graph import GraphedForward
+            with torch.no_grad():
+                gf = GraphedForward(layer, x, a2a_ffn_overlap_degree=2)
+                for _ in range(300):
+                    yg = gf(x)
+            torch.cuda.synchronize()
+            outs[2].append(yg.clone())
         # capacity = k * ceil(T/E) is even here, so the alignment rule (moe_layer.py:298-301) leaves it alone
         want, crits = O.moe_forward_ep(xs, wg, [w1[r * E_loc:(r + 1) * E_loc] for r in range(world)],
                                        [b1[r * E_loc:(r + 1) * E_loc] for r in range(world)],
@@ -103,14 +117,15 @@ def _worker(rank, world, port, E_loc, q):
         q.put((rank, False, traceback.format_exc()))
 
 
+@pytest.mark.parametrize("transport", ["ipc", "rccl"])
 @pytest.mark.parametrize("world,E_loc", [(2, 4), (2, 3), (4, 2), (8, 8)])
-def test_expert_parallel_over_rccl(world, E_loc):
+def test_expert_parallel_between_gpus(world, E_loc, transport):
     if _ngpu() < world:
         pytest.skip(f"needs {world} GPUs, this box has {_ngpu()}")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, E_loc, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, E_loc, transport, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
