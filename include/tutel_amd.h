@@ -406,7 +406,7 @@ int tutel_amd_marks_report(double *delta_us, int n);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG / TUTEL_AMD_DECODE /
- * TUTEL_AMD_ROUTING / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS seed it once), >= 0 = force.  Every choice computes bit-identical results.
+ * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS seed it once), >= 0 = force.  Every choice computes bit-identical results.
  *   TUTEL_OPT_GEMM_IMPL  kernels of the <= 128-rows-per-expert regime: 0 register-staged 128 x 128, 1 LDS-DMA 128 x 128, 4 the
  *                        128 x 256 tile on a three-slot LDS-DMA ring (k-major weights; automatic when its grid covers the chip)
  *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
@@ -414,7 +414,9 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *                        (automatic: > 128 rows per expert and enough tiles to cover the chip)
  *   TUTEL_OPT_DECODE     fast_decode launch shape: bit 0 = two waves per token, bit 1 = non-temporal stores of the output
  *                        (automatic: 2)
- *   TUTEL_OPT_ROUTING    reserved (round 3's grid-barrier routing kernel, removed in round 4): no effect
+ *   TUTEL_OPT_EP_STAGE_GRID  stage GEMMs of an overlapped pipeline (degree > 1): 1 / automatic = the half-chip 256 x 256 grid where the
+ *                        full one would be one workgroup per CU (two stages run side by side on the two side streams), 0 = the
+ *                        grid the shape would take alone
  *   TUTEL_OPT_GEMM_PERSIST  256 x 256 ping-pong kernel, bias operand: 0 = fetched after the K loop, 1 / automatic = before it
  *                        (32 more live registers, its L2 round trip hidden behind the loop)
  *   TUTEL_OPT_EP_STREAMS overlapped pipeline: 1 = every stage's GEMMs on ONE side stream, 2 / automatic = stages alternate between
@@ -422,7 +424,7 @@ int tutel_amd_marks_report(double *delta_us, int n);
 #define TUTEL_OPT_GEMM_IMPL 0
 #define TUTEL_OPT_GEMM_TILE 1
 #define TUTEL_OPT_DECODE 2
-#define TUTEL_OPT_ROUTING 3
+#define TUTEL_OPT_EP_STAGE_GRID 3
 #define TUTEL_OPT_GEMM_PERSIST 4
 #define TUTEL_OPT_EP_STREAMS 5
 #define TUTEL_OPT_COUNT 6

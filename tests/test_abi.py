@@ -75,7 +75,7 @@ def test_round3_entry_points_reject_bad_arguments(L):
     assert L.tutel_amd_gate_topk(None, 0, 0, 4, 4097, 1, 1, None, None, None, None, 0, None, 0, None) != 0 and b"4096" in L.tutel_amd_last_error()
     assert L.tutel_amd_gate_topk(None, 0, 0, 4, 4096, 3, 1, None, None, None, None, 0, None, 0, None) != 0 and b"8192" in L.tutel_amd_last_error()
     # options: the round-3 keys exist, unknown keys are refused
-    for key in (_lib.OPT_DECODE, _lib.OPT_GEMM_PERSIST, _lib.OPT_EP_STREAMS):
+    for key in (_lib.OPT_DECODE, _lib.OPT_EP_STAGE_GRID, _lib.OPT_GEMM_PERSIST, _lib.OPT_EP_STREAMS):
         assert L.tutel_amd_set_option(key, -1) == 0
     assert L.tutel_amd_set_option(99, 0) != 0
 

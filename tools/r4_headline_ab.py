@@ -145,9 +145,8 @@ def main():
     torch.set_default_dtype(torch.float32)
     for rnd in range(2):
         for impl in (1, 4):
-            for routing in ((0, 1) if hasattr(ops, "gate_proj_topk") else (0,)):
+            for routing in (0,):   # (the measured run also had routing = 1, the removed in-kernel gate projection)
                 ops.set_option(_lib.OPT_GEMM_IMPL, impl)
-                ops.set_option(_lib.OPT_ROUTING, routing)
                 layer.__dict__.pop("_ep_workspaces", None)
                 with torch.no_grad():
                     gf = GraphedForward(layer, x)
@@ -168,7 +167,6 @@ def main():
                 print(key, res["forward"][key], flush=True)
                 del gf
     ops.set_option(_lib.OPT_GEMM_IMPL, -1)
-    ops.set_option(_lib.OPT_ROUTING, -1)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "r4_headline_ab.json"), "w") as f:

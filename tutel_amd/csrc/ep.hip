@@ -770,7 +770,12 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
           StageScope sc(TUTEL_STAGE_A2A_DISPATCH, ks);
           if ((rc = ipc_wait(c, 0, i, 1, ks)) != 0) return rc;
         }
+        // two stages run side by side on the two side streams: a stage GEMM whose full grid would be one workgroup per CU takes
+        // the half-chip 256 x 256 grid instead (launch_gemm, expert_gemm.hip), so that fc1 / fc2 of stage i overlap those of stage
+        // i + 1 rather than queueing behind them block by block
+        tutel_gemm_corun_hint(kss[0] != kss[1] && tutel_get_option(TUTEL_OPT_EP_STAGE_GRID) != 0);
         rc = stage_gemms(i, ks);
+        tutel_gemm_corun_hint(0);
         if (rc) return rc;
         StageScope sc(TUTEL_STAGE_A2A_COMBINE, ks);
         if ((rc = ipc_signal(c, 1, i, 1, ks)) != 0) return rc;
@@ -832,7 +837,7 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
       hipStream_t ks = kss[i & 1];
       HIP_CHECK(hipStreamWaitEvent(ks, c->recv_ev[i], 0), "hipStreamWaitEvent");  // the side stream forks from the caller's
       guard.fork(0, ks, c->done_ev[i]);
-      tutel_gemm_corun_hint(c->comm != nullptr);  // a real collective runs beside these GEMMs (the hosted test exchange is synchronous)
+      tutel_gemm_corun_hint(c->comm != nullptr && tutel_get_option(TUTEL_OPT_EP_STAGE_GRID) != 0);  // a real collective runs beside these GEMMs (the hosted test exchange is synchronous)
       rc = stage_gemms(i, ks);
       tutel_gemm_corun_hint(0);
       if (rc) return rc;

@@ -171,6 +171,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, f32x16 (&acc)[N
   }
 }
 
+// fused fast_encode: the slot-map entries of the lane's 4 token-tile pieces (rows gr[0..3] of expert e), fetched TOGETHER.  Written
+// per piece inside `if (p.a_rows)` branches, hipcc emitted one global load + s_waitcnt vmcnt(0) per piece (and again for the
+// out-of-range test of the buffer-descriptor path): eight dependent L2 round trips in front of the first DMA of every block --
+// about 2 us per block with one block per CU, the 4 us by which fc1 (gather) trailed fc2 at the headline shape.
+__device__ __forceinline__ void gather_rows4(const GemmArgs &p, int e, const int (&gr)[4], int (&q)[4]) {
+  q[0] = q[1] = q[2] = q[3] = 0;
+  if (p.a_rows != nullptr) {
+    const int32_t *m = p.a_rows + (size_t)e * p.R;
+    const int q0 = m[gr[0]], q1 = m[gr[1]], q2 = m[gr[2]], q3 = m[gr[3]];
+    q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
+  }
+}
+
 // streamed-once weight loads may bypass cache allocation (each W byte is read by exactly one CU)
 template <bool NT> __device__ __forceinline__ u32x4 ld16(const uint16_t *p) {
   if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
@@ -424,14 +437,18 @@ __global__ __launch_bounds__(GM_THREADS, 2) void expert_gemm_glds_kernel(GemmArg
   // ---- DMA source pointers: wave `wid` issues pieces j = wid*4 + i (i < 4) of each tile; piece j
   // of a [rows][64k] tile = rows 8j..8j+7 (1 KiB), lane -> (row 8j + lane/8, position lane%8).
   const uint16_t *a_src[4], *w_src[4];
+  int gr4[4], slot4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gr4[i] = min(m0 + 8 * (wid * 4 + i) + (lane >> 3), p.R - 1);
+  gather_rows4(p, e, gr4, slot4);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = 8 * (wid * 4 + i) + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    const int gr = min(m0 + r, p.R - 1);
+    const int gr = gr4[i];
     a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + c * 8;
     if (p.a_rows != nullptr) {  // fused fast_encode: bucket row -> token row of x (or the zero row)
-      const int q = p.a_rows[(size_t)e * p.R + gr];
+      const int q = slot4[i];
       a_src[i] = (q >= 0 ? reinterpret_cast<const uint16_t *>(p.A) + (size_t)(q % p.a_rows_mod) * p.lda
                          : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;
     }
@@ -699,15 +716,19 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
   // DMA sources: token tile pieces j = wid*4 + i (rows 8j..8j+7 of 256); weight pieces g = wid*WPW + i over the
   // NSUB sub-tiles of 16 pieces each
   const uint16_t *a_src[4], *w_src[WPW];
+  int gr4[4], slot4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gr4[i] = min(m0 + 8 * (wid * 4 + i) + (lane >> 3), p.R - 1);
+  gather_rows4(p, e, gr4, slot4);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     {
       const int r = 8 * (wid * 4 + i) + (lane >> 3);
       const int c = (lane & 7) ^ ((r >> 1) & 7);
-      const int gr = min(m0 + r, p.R - 1);
+      const int gr = gr4[i];
       a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + c * 8;
       if (p.a_rows != nullptr) {
-        const int q = p.a_rows[(size_t)e * p.R + gr];
+        const int q = slot4[i];
         a_src[i] = (q >= 0 ? reinterpret_cast<const uint16_t *>(p.A) + (size_t)(q % p.a_rows_mod) * p.lda
                            : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;
       }
@@ -738,7 +759,7 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
       const int r = 8 * (wid * 4 + i) + (lane >> 3);
       const int gr = min(m0 + r, p.R - 1);
       a_off[i] = (int)(unsigned)((const char *)a_src[i] - (const char *)abase);
-      if ((p.a_rows != nullptr && p.a_rows[(size_t)e * p.R + gr] < 0) || m0 + r >= row_limit)
+      if ((p.a_rows != nullptr && slot4[i] < 0) || m0 + r >= row_limit)
         a_off[i] = (int)0x7ffff000u + (((lane & 7) ^ ((r >> 1) & 7)) << 4);  // empty slot / past the row count: out of range -> zeros
     }
 #pragma unroll
@@ -780,21 +801,32 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
   const int npair = NI == 4 ? p.ntn : (p.ntn + 1) >> 1, pair = NI == 4 ? nt : nt >> 1;
   const int rot = p.rot_on ? (int)(((long long)(pair + 3 * e) * nk / npair) % nk) : 0;
 
-#define GB_ISSUE(KT, STG)                                                              \
+#define GB_ISSUE_A(KT, STG)                                                            \
   do {                                                                                 \
     int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
-    uint16_t *da_ = sA + (STG) * A_STAGE + piece_a, *dw_ = sW + (STG) * NSUB * GL_STAGE + piece_w; \
+    uint16_t *da_ = sA + (STG) * A_STAGE + piece_a;                                    \
     if (BUF) {                                                                         \
-      const int ao_ = kr_ * (GL_BK * 2), wo_ = (int)(kr_ * (w_step * 2));              \
+      const int ao_ = kr_ * (GL_BK * 2);                                               \
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) bdma16<false>(rs_a, a_off[i_], ao_, da_ + i_ * 512); \
+    } else {                                                                           \
+      const size_t ao_ = (size_t)kr_ * GL_BK;                                          \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
+    }                                                                                  \
+  } while (0)
+#define GB_ISSUE_W(KT, STG)                                                            \
+  do {                                                                                 \
+    int kr_ = (KT) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_;                            \
+    uint16_t *dw_ = sW + (STG) * NSUB * GL_STAGE + piece_w;                            \
+    if (BUF) {                                                                         \
+      const int wo_ = (int)(kr_ * (w_step * 2));                                       \
       if (w_once) { _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) bdma16<true>(rs_w, w_off[i_], wo_, dw_ + i_ * 512); } \
       else { _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) bdma16<false>(rs_w, w_off[i_], wo_, dw_ + i_ * 512); } \
     } else {                                                                           \
-      const size_t ao_ = (size_t)kr_ * GL_BK, wo_ = (size_t)kr_ * w_step;              \
-      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) glds16(a_src[i_] + ao_, da_ + i_ * 512, false); \
+      const size_t wo_ = (size_t)kr_ * w_step;                                         \
       _Pragma("unroll") for (int i_ = 0; i_ < WPW; ++i_) glds16(w_src[i_] + wo_, dw_ + i_ * 512, w_once); \
     }                                                                                  \
   } while (0)
+#define GB_ISSUE(KT, STG) do { GB_ISSUE_A(KT, STG); GB_ISSUE_W(KT, STG); } while (0)
 #define GB_LOAD_FRAGS(FA, FW, KK)                                                      \
   do {                                                                                 \
     _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                   \
@@ -855,12 +887,22 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
     // DMA ops per wave, landing in order) and a bare s_barrier, which also says every wave is done reading the
     // slot the next issue overwrites.
     constexpr int OPS = 4 + WPW;
+    // prologue: the WEIGHT pieces of the first NS - 1 tiles go out before the token pieces -- with the fused fast_encode the token
+    // addresses come from a slot-map lookup (one more dependent L2 round trip per block), the weight addresses do not, so the HBM
+    // stream starts without waiting for it.  In flight, in issue order: [W(0) .. W(NS-2)] [A(0) .. A(NS-2)]; the first K-tile
+    // needs everything up to A(0), i.e. all but the 4 * (NS - 2) token ops after it (NS = 3: equal to the steady-state count from
+    // the second tile on, where each iteration issues [A, W] of one tile).
+    static_assert(NS <= 3, "the prologue order below is worked out for rings of at most three slots");
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
-      if (t < nk) GB_ISSUE(t, t);
+      if (t < nk) GB_ISSUE_W(t, t);
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+      if (t < nk) GB_ISSUE_A(t, t);
     int kt = 0, slot = 0;
     for (; kt + NS - 1 < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * (NS - 2)) : "memory");
+      if (kt == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * (NS - 2)) : "memory");
       __builtin_amdgcn_s_barrier();
       const int nslot = slot == 0 ? NS - 1 : slot - 1;  // (kt + NS - 1) % NS
       GB_ISSUE(kt + NS - 1, nslot);
@@ -876,6 +918,8 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
   }
 #undef GB_TILE
 #undef GB_ISSUE
+#undef GB_ISSUE_A
+#undef GB_ISSUE_W
 #undef GB_LOAD_FRAGS
 #undef GB_MMA
 
@@ -959,16 +1003,20 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   // with both waves in their memory part.)  Out-of-range offsets return ZEROS into LDS (probed on gfx950,
   // tools/scratch/oob_lds.hip): that is the all-zero row of an empty bucket slot in the fused fast_encode.
   int a_off[4], w_off[4];
+  int gr4[4], slot4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gr4[i] = min(m0 + 8 * ((i >> 1) * 16 + 2 * wid + (i & 1)) + (lane >> 3), p.R - 1);
+  gather_rows4(p, e, gr4, slot4);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int piece = (i >> 1) * 16 + 2 * wid + (i & 1);
     const int r = 8 * piece + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     {
-      const int gr = min(m0 + r, p.R - 1);
+      const int gr = gr4[i];
       size_t off = (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda;  // elements from Ae
       if (p.a_rows != nullptr) {
-        const int q = p.a_rows[(size_t)e * p.R + gr];
+        const int q = slot4[i];
         off = q >= 0 ? (size_t)(q % p.a_rows_mod) * p.lda : (size_t)0x3ffff800u;            // elements from p.A; empty -> out of range
       }
       if (m0 + r >= row_limit) off = (size_t)0x3ffff800u;  // rows past the expert's row count: zeros, no memory traffic
