@@ -239,6 +239,41 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
   }
 }
 
+// any k (k > 16; upstream's ATen chain takes any top-k, fast_dispatch.py:145-148): the same arithmetic with a run-time loop over the
+// choices -- row pointers are recomputed per choice instead of living in registers, loads are not batched.  Not a hot path.
+template <typename T>
+__global__ __launch_bounds__(DP_THREADS) void decode_anyk_kernel(const T *__restrict__ buf, const int32_t *__restrict__ idx,
+                                                                const int32_t *__restrict__ loc, const void *__restrict__ gates,
+                                                                int gate_dtype, int Tn, int M, int k, int capacity, int num_experts,
+                                                                int chunk_rows, int expert_slice, int ep_world, T *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * DP_WAVES;
+  for (int t = wave; t < Tn; t += nwaves) {
+    T *dst = out + (size_t)t * M;
+    for (int i = lane; i < M; i += 64) {
+      float acc = 0.f;
+      for (int j = 0; j < k; ++j) {
+        int e = idx[(size_t)j * Tn + t];
+        const int l = loc[(size_t)j * Tn + t];
+        float f = 0.f;
+        if (l < capacity && e >= 0 && l >= 0) {
+          if (expert_slice > 0) {
+            const int e_loc = num_experts / ep_world, w = e / e_loc, el = e % e_loc;
+            e = ((el / expert_slice) * ep_world + w) * expert_slice + el % expert_slice;
+          }
+          const size_t r = (chunk_rows > 0) ? ((size_t)(l / chunk_rows) * num_experts + e) * chunk_rows + (l % chunk_rows)
+                                            : (size_t)e * capacity + l;
+          const float g = gates ? load_gate(gates, gate_dtype, (size_t)j * Tn + t) : 1.0f;
+          f = mul_rn(g, Elem<T>::to_f32(buf[r * M + i]));
+        }
+        acc = (j == 0) ? f : add_rn(acc, f);
+      }
+      dst[i] = Elem<T>::from_f32(acc);
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------
 // gate gradient: one wave per (choice, token); fp32 accumulate, butterfly reduce.
 // (The reference accumulates serially in the data dtype, custom_kernel.cpp:318-321; a parallel
@@ -378,7 +413,7 @@ extern "C" int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *
                                      int expert_slice, int ep_world, void *out, tutel_stream_t stream) {
   TUTEL_REQUIRE(dtype_ok(dtype), "tutel_amd_fast_decode: unsupported dtype %d", dtype);
   TUTEL_REQUIRE(gates == nullptr || dtype_ok(gate_dtype), "tutel_amd_fast_decode: unsupported gate dtype %d", gate_dtype);
-  TUTEL_REQUIRE(T >= 0 && M >= 1 && k >= 1 && k <= 16 && capacity >= 0, "tutel_amd_fast_decode: bad sizes T=%d M=%d k=%d C=%d", T, M, k, capacity);
+  TUTEL_REQUIRE(T >= 0 && M >= 1 && k >= 1 && capacity >= 0, "tutel_amd_fast_decode: bad sizes T=%d M=%d k=%d C=%d", T, M, k, capacity);
   TUTEL_REQUIRE(chunk_rows >= 0 && (chunk_rows == 0 || (num_experts >= 1 && capacity % chunk_rows == 0)),
                 "tutel_amd_fast_decode: chunk_rows=%d must divide capacity=%d (num_experts=%d)", chunk_rows, capacity, num_experts);
   TUTEL_REQUIRE(expert_slice >= 0 && (expert_slice == 0 || (chunk_rows == 0 && ep_world >= 1 && num_experts >= 1 &&
@@ -395,6 +430,14 @@ extern "C" int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *
   TUTEL_REQUIRE(((uintptr_t)buf % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_amd_fast_decode: buf/out must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   StageScope stage(TUTEL_STAGE_DECODE, st);
+  if (k > 16) {   // past the register-resident kernels' top-k: the run-time-k kernel
+    const int grid = dp_grid(T);
+    if (dtype == TUTEL_F32) hipLaunchKernelGGL(decode_anyk_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, (float *)out);
+    else if (dtype == TUTEL_BF16) hipLaunchKernelGGL(decode_anyk_kernel<bf16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const bf16_t *)buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, (bf16_t *)out);
+    else hipLaunchKernelGGL(decode_anyk_kernel<f16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const f16_t *)buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, (f16_t *)out);
+    TUTEL_CHECK_LAUNCH("tutel_amd_fast_decode");
+    return 0;
+  }
   if (dtype == TUTEL_F32) launch_decode<float>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
   else if (dtype == TUTEL_BF16) launch_decode<bf16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
   else launch_decode<f16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
