@@ -70,6 +70,13 @@ def test_ipc_transport_unequal_or_empty_ranks(tokens):
     _run_ranks(_sweep_worker, 2, (cfg,), timeout=300)
 
 
+def test_ipc_transport_gates_applied_in_encode():
+    """is_postscore=False (fast_dispatch.py:125: the gate multiplies the token on its way INTO the bucket): the peer-store encode takes its
+    gated branch, decode adds plain rows; two ranks, degrees 1 and 2, bf16"""
+    cfg = dict(shape=(512, 128, 192, 2), E_loc=4, dtype="bfloat16", sweep=[(1, 1), (1, 2)], transport="ipc", postscore=False)
+    _run_ranks(_sweep_worker, 2, (cfg,), timeout=300)
+
+
 def test_ipc_transport_degree_sweep_keeps_the_bits():
     """degrees 1..8 over one layer (fp16, 16 local experts): every output vs the oracle at 1e-3 and bit-identical to degree 1
     whenever the stages keep the rows per launch"""

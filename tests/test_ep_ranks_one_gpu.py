@@ -195,7 +195,8 @@ def _sweep_worker(rank, world, port, cfg, q):
         torch.set_default_dtype(dtype)
         layer = moe.moe_layer(gate_type={"type": "top", "k": k, "fp32_gate": True}, model_dim=M,
                               experts={"type": "ffn", "num_experts_per_device": E_loc, "hidden_size_per_expert": H,
-                                       "activation_fn": lambda t: torch.nn.functional.relu(t)}, use_2dh=cfg.get("use_2dh", False))
+                                       "activation_fn": lambda t: torch.nn.functional.relu(t)}, use_2dh=cfg.get("use_2dh", False),
+                              is_postscore=cfg.get("postscore", True))
         torch.set_default_dtype(old)
         with torch.no_grad():
             layer.gates[0].wg.weight.copy_(wg.float())
@@ -221,7 +222,7 @@ def _sweep_worker(rank, world, port, cfg, q):
                 box = [None]
                 if rank == 0:
                     box[0] = O.moe_forward_ep(xs, wg, parts(w1), parts(b1), parts(w2), parts(b2), top_k=k, fp32_gate=True,
-                                              alignment=degree, accum_fp32=True, inequivalent_tokens=uneq)
+                                              alignment=degree, accum_fp32=True, inequivalent_tokens=uneq, is_postscore=cfg.get("postscore", True))
                 dist.broadcast_object_list(box, src=0)
                 wants[degree] = box[0]
             want, crits = wants[degree]
