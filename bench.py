@@ -36,10 +36,10 @@ kernel-trace average of the same command, written by tools/profile_r04.sh) and a
 csrc/expert_gemm.hip equals the one stamped there -- otherwise null with the reason.  `decode` and `extra.ep8_rank_gemms` are
 roofline objects of the second / third kernels of interest (fast_decode; the grouped GEMM at the per-rank shapes of an 8-way
 expert-parallel run: one pipeline stage, and the whole rank).
-Launch mode: N = 1 times the Python-enqueued (eager) forward -- like rounds 1-2, GPU-paced (0.09 ms of host enqueue against
-0.25 ms of device work) -- and, beside it, the same forward captured once in a HIP graph (tutel_amd.impls.graph.GraphedForward) and
-REPLAYED per step (`--graph` makes the replay the timed mode); N > 1 replays the graph by default (`--eager` times eager): the
-line always carries the other mode beside the timed one
+Launch mode: with capacity_factor > 0 the forward never talks to the host, so the default is to capture it once in a HIP graph
+(tutel_amd.impls.graph.GraphedForward) and REPLAY it per step -- as in round 3; `--eager` times the Python-enqueued forward
+instead (GPU-paced as well: 0.09 ms of host enqueue against 0.25 ms of device work; it pays its first forward after the
+synchronize at host pace), and the line always carries the other mode beside the timed one
 (`launch_modes`, and `value_eager` at the top level).  If capture fails the script says so on stderr and in the line and runs eager.
 N > 1: the graph is replayed as well when the exchange is the IPC transport (plain kernels and events, epochs counted on the device:
 2000 replays in tests/test_ep_ipc_one_gpu.py; host cost 0.05 ms per forward against 0.16 ms eager); with RCCL on the path the
@@ -271,12 +271,11 @@ def main():
     # N > 1: the graph is replayed when the exchange is the IPC transport (kernels + events only); GraphedForward refuses to capture
     # RCCL collectives (replaying them hung after ~200 replays in the 1-rank-communicator probe, profiles/r03_ep_streams.txt) and
     # the forward is then timed eager -- every rank takes the same branch (the transport is agreed at communicator creation).
-    # N = 1: eager is the timed mode (comparable with rounds 1-2; and with the round-4 kernels it measured faster than the replay:
-    # 0.2538 vs 0.2612 ms, profiles/r04_bench_line.json -- the host enqueues a forward in ~0.09 ms, the device needs 0.25); the
-    # replay is timed beside it whenever it can be captured (`launch_modes.other`).
-    graph_default = world > 1
-    want_graph = (args.graph or (graph_default and not args.eager)) and args.capacity_factor > 0
-    also_graph = not want_graph and not args.eager and args.capacity_factor > 0 and world == 1
+    # The replay is the timed mode (as in round 3) and the eager forward is timed beside it (`value_eager`, `launch_modes.other`): in
+    # steady state the two cost the same (0.256-0.259 ms per forward on the round-4 boxes), but a 20-step region entered from a
+    # synchronize costs the eager loop its first forward at host pace (0.43-0.44 ms: +8 us on the mean of 20), the replay +1 us.
+    want_graph = (args.graph or not args.eager) and args.capacity_factor > 0
+    also_graph = args.eager and args.capacity_factor > 0 and world == 1
     if want_graph:
         # same kernels (and, N > 1, the same RCCL collectives on the caller's stream), enqueued by ONE hipGraphLaunch per step:
         # the host cost of a forward drops from ~0.09 (N = 1) / ~0.16 ms (N > 1, degree 2) to one launch, so the step is
@@ -315,7 +314,7 @@ def main():
         eager = eager_step
         other, other_launch = None, None
         if launch != "eager":      # the same K steps, eager, bracketed the same way: reported beside the value
-            for _ in range(max(3, args.warmup)):
+            for _ in range(max(3, args.warmup, min(args.settle, 50))):   # (the workspace of the eager stream has not run since the capture)
                 eager(x)
             other, _, _, _ = run_timed(eager, x, args.steps, world, gate_timer, mode=0, marks=False)
             other_launch = "eager"
@@ -323,7 +322,7 @@ def main():
             try:
                 from tutel_amd.impls.graph import GraphedForward
                 graphed = GraphedForward(layer, x, **fwd_kw)
-                for _ in range(max(3, args.warmup)):
+                for _ in range(max(3, args.warmup, min(args.settle, 50))):
                     graphed(graphed.static_in)
                 other, _, _, _ = run_timed(graphed, graphed.static_in, args.steps, world, gate_timer, mode=0, marks=False)
                 other_launch = "hip-graph replay"
