@@ -260,7 +260,7 @@ size_t tutel_amd_ep_flag_bytes(void);
 int tutel_amd_ep_comm_create_ipc(int world, int rank, tutel_amd_ep_comm_t **out);
 /* gives any communicator (RCCL-backed, hosted or IPC-only) the IPC transport: `flags` = an opened flag segment of this
  * communicator's ranks, owned by the caller and kept alive as long as the communicator; timeout_ms bounds every wait for a
- * peer (<= 0: 20 s) -- a wait that times out records which peer and stage never arrived, the forward's output is then
+ * peer (<= 0: 120 s, the order of a collective watchdog) -- a wait that times out records which peer and stage never arrived, the forward's output is then
  * garbage and the NEXT call on the communicator fails with that text (tutel_amd_ep_ipc_status reads it without a call). */
 int tutel_amd_ep_comm_attach_ipc(tutel_amd_ep_comm_t *comm, tutel_amd_ep_segment_t *flags, int timeout_ms);
 int tutel_amd_ep_comm_has_ipc(const tutel_amd_ep_comm_t *comm);

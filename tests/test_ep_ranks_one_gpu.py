@@ -77,7 +77,11 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
         with torch.no_grad():
             y = layer(xs[rank].cuda())
             if native:
-                for _ in range(2):   # cached workspace, events re-recorded: repeated calls must agree bit for bit
+                # cached workspace, events re-recorded, exchange buffers reused: ANOTHER batch in between (every rank its neighbour's
+                # tokens), then the first batch again, twice -- bit for bit the first result, i.e. nothing of the batch in between
+                # was still in a buffer a kernel read (a stale bucket row would go unnoticed if every call carried the same tokens)
+                layer(xs[(rank + 1) % world].cuda())
+                for _ in range(2):
                     assert torch.equal(layer(xs[rank].cuda()), y)
         torch.cuda.synchronize()
         if native == "ipc":
@@ -94,7 +98,7 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
             assert torch.equal(y_hosted, y), "IPC transport and hosted exchange must agree bit for bit"
             _set_transport(ep_native, "ipc")
         if native:
-            assert len(fast_calls) == (4 if native == "ipc" else 3) and any(ep_native._comms.values()), "the native one-call pipeline must be the path taken"
+            assert len(fast_calls) == (5 if native == "ipc" else 4) and any(ep_native._comms.values()), "the native one-call pipeline must be the path taken"
             plans = [ep_native.plan(E, world, int(layer.protected_shape[1]) // world, degree)["sliced"] == 1] if degree > 1 else []
         box = [None]   # rank 0 computes the expectation for every rank (the same CPU GEMMs would otherwise run W times side by side)
         if rank == 0:

@@ -14,7 +14,7 @@ import test_ep_ranks_one_gpu as T  # noqa: E402
 def main():
     cases = ((2, 2, True), (1, 1, True), (2, 1, True), (2, 8, True), (2, 2, False))
     if len(sys.argv) > 1 and sys.argv[1] == "ipc":
-        cases = ((2, 8, "ipc"), (1, 8, "ipc"), (2, 1, "ipc"))   # (2, 8): 64 global experts, degree 2 = the bench's N = 8 configuration
+        cases = ((2, 8, "ipc"), (1, 8, "ipc"), (2, 1, "ipc")) if len(sys.argv) < 3 else ((int(sys.argv[2]), int(sys.argv[3]), "ipc"),)   # (2, 8): 64 global experts, degree 2 = the bench's N = 8 configuration
     for degree, E_loc, native in cases:
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
@@ -25,6 +25,9 @@ def main():
         res = [q.get(timeout=600) for _ in procs]
         for p in procs:
             p.join(timeout=60)
+        for r in sorted(res):
+            if not r[1] and "Connection closed by peer" not in str(r[2]) and "hosted exchange callback failed" not in str(r[2]):
+                print("rank", r[0], "FAILED:\n" + str(r[2]), flush=True)
         print("world 8, degree", degree, "E_loc", E_loc, ("IPC transport" if native == "ipc" else "native one-call pipeline") if native else "python-orchestrated", "->", all(r[1] for r in res), sorted(set(r[2][:60] for r in res))[:2], flush=True)
 
 

@@ -494,7 +494,7 @@ extern "C" int tutel_amd_ep_comm_attach_ipc(tutel_amd_ep_comm_t *c, tutel_amd_ep
   *c->err_host = 0;
   HIP_CHECK(hipHostGetDevicePointer((void **)&c->err_dev, c->err_host, 0), "hipHostGetDevicePointer");
   HIP_CHECK(hipDeviceSynchronize(), "hipDeviceSynchronize");
-  c->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 20000) * 100000LL;  // wall_clock64: 100 MHz
+  c->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 120000) * 100000LL;  // wall_clock64: 100 MHz
   c->flag_seg = flags;
   return 0;
 }

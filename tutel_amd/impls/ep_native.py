@@ -33,7 +33,10 @@ HOSTED = int(os.environ.get("TUTEL_AMD_NATIVE_HOSTED", "0")) != 0  # bring-up / 
 #   "ipc"   the same, and also for process groups that are not on the "nccl" backend (ranks that share one GPU: the tests)
 #   "rccl"  never attach the IPC transport
 TRANSPORT = os.environ.get("TUTEL_AMD_EP_TRANSPORT", "auto").lower()
-IPC_TIMEOUT_MS = int(os.environ.get("TUTEL_AMD_EP_TIMEOUT_MS", "20000"))
+# how long a wait kernel spins for a peer's flag before it gives up and the NEXT call reports which peer never arrived: the order of a
+# collective watchdog (NCCL's default is 10 minutes; 2 minutes here) -- ranks may legitimately be seconds to minutes apart (data loading, a first-call
+# code-object load with eight processes on one box)
+IPC_TIMEOUT_MS = int(os.environ.get("TUTEL_AMD_EP_TIMEOUT_MS", "120000"))
 _FORCE_COMM = False  # test hook: run a single rank through a real 1-rank RCCL communicator (staged pipeline, both streams)
 _comms = {}      # (ranks of the group, device) -> EpComm | False (creation failed: do not retry)
 _groups = {}
