@@ -139,6 +139,61 @@ def _graph_worker(rank, world, port, replays, degree, q):
         q.put((rank, False, traceback.format_exc(), []))
 
 
+def _stress_worker(rank, world, port, degree, n_forwards, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import torch.distributed as dist
+        from oracle import moe_oracle as O
+        from tutel import moe
+        from tutel_amd import _lib
+        from tutel_amd.impls import ep_native
+        _set_transport(ep_native, "ipc")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        T, M, H, k, E_loc = 384, 128, 128, 2, 4
+        E = E_loc * world
+        dtype = torch.bfloat16
+        batches = [O.make_problem(T, M, H, E, dtype=dtype, seed=500 + 10 * b + rank)[0].cuda() for b in range(3)]
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        layer = moe.moe_layer(gate_type={"type": "top", "k": k, "fp32_gate": True}, model_dim=M,
+                              experts={"type": "ffn", "num_experts_per_device": E_loc, "hidden_size_per_expert": H,
+                                       "activation_fn": lambda t: torch.nn.functional.relu(t)},
+                              seeds=(1, rank + 1, 1), a2a_ffn_overlap_degree=degree)
+        torch.set_default_dtype(old)
+        layer = layer.cuda().eval()
+        with torch.no_grad():
+            want = [layer(b).clone() for b in batches]
+            torch.cuda.synchronize()
+            outs = []
+            for i in range(n_forwards):     # no host synchronisation in between: the ranks drift apart as far as the protocol lets them
+                b = (i * 7 + i // 5) % 3
+                outs.append((b, layer(batches[b])))
+                if len(outs) == 50:
+                    torch.cuda.synchronize()
+                    bad = [j for j, (bb, y) in enumerate(outs) if not torch.equal(y, want[bb])]
+                    assert not bad, f"forward {i - 49 + bad[0]}: the result of batch {outs[bad[0]][0]} changed"
+                    outs = []
+        torch.cuda.synchronize()
+        comm = ep_native.communicator(layer.group, torch.device("cuda", 0))
+        _lib.check(_lib.lib().tutel_amd_ep_ipc_status(comm.handle), "tutel_amd_ep_ipc_status")
+        q.put((rank, True, f"{n_forwards} eager forwards over 3 batches", []))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc(), []))
+
+
+@pytest.mark.parametrize("world,degree", [(2, 2), (4, 2), (4, 1)])
+def test_ipc_transport_eager_stress_with_changing_batches(world, degree):
+    """600 eager forwards without host synchronisation, the batch changing from call to call: every result must equal, bit for bit,
+    the first result of its batch -- a bucket row left over from another batch (a flag seen too early, a buffer reused too soon)
+    would show"""
+    _run_ranks(_stress_worker, world, (degree, 600), timeout=600)
+
+
 @pytest.mark.parametrize("degree", [1, 2])
 def test_ipc_transport_2000_graph_replays(degree):
     """replaying captured RCCL collectives hung after ~200 replays.  The IPC transport is plain kernels + events with
