@@ -91,3 +91,13 @@ def test_product_has_no_cpu_path():
             for f in files:
                 if f.endswith((".py", ".hip", ".h")):
                     assert "oracle" not in open(os.path.join(dp, f)).read().lower(), os.path.join(dp, f)
+
+
+def test_header_is_plain_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/tutel_amd.h must compile as C99 on its own (no C++, no HIP or torch headers)"""
+    import subprocess
+    src = tmp_path / "h.c"
+    src.write_text('#include "tutel_amd.h"\nint main(void) { tutel_amd_ep_args_t a; tutel_amd_moe_args_t m; (void)a; (void)m; return (int)TUTEL_AMD_ABI_VERSION - 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "h.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
