@@ -264,6 +264,7 @@ int tutel_amd_ep_comm_create_ipc(int world, int rank, tutel_amd_ep_comm_t **out)
  * garbage and the NEXT call on the communicator fails with that text (tutel_amd_ep_ipc_status reads it without a call). */
 int tutel_amd_ep_comm_attach_ipc(tutel_amd_ep_comm_t *comm, tutel_amd_ep_segment_t *flags, int timeout_ms);
 int tutel_amd_ep_comm_has_ipc(const tutel_amd_ep_comm_t *comm);
+int tutel_amd_ep_ipc_set_timeout(tutel_amd_ep_comm_t *comm, int timeout_ms); /* for the waits enqueued from now on */
 int tutel_amd_ep_ipc_status(tutel_amd_ep_comm_t *comm);
 /* all_to_all_single with equal splits over the IPC transport: block r of `send` (any device buffer, bytes_per_peer bytes,
  * multiple of 16) lands at byte offset recv_off + <my rank> * bytes_per_peer of rank r's `seg`; when the call's work on

@@ -87,6 +87,7 @@ SIGNATURES.update({
     "tutel_amd_ep_comm_create_ipc": (_i, [_i, _i, ctypes.POINTER(_vp)]),
     "tutel_amd_ep_comm_attach_ipc": (_i, [_vp, _vp, _i]),
     "tutel_amd_ep_comm_has_ipc": (_i, [_vp]),
+    "tutel_amd_ep_ipc_set_timeout": (_i, [_vp, _i]),
     "tutel_amd_ep_ipc_status": (_i, [_vp]),
     "tutel_amd_ep_ipc_exchange": (_i, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "tutel_amd_mark": (_i, [_vp]),

@@ -501,6 +501,12 @@ extern "C" int tutel_amd_ep_comm_attach_ipc(tutel_amd_ep_comm_t *c, tutel_amd_ep
 
 extern "C" int tutel_amd_ep_comm_has_ipc(const tutel_amd_ep_comm_t *c) { return c != nullptr && c->flag_seg != nullptr; }
 
+extern "C" int tutel_amd_ep_ipc_set_timeout(tutel_amd_ep_comm_t *c, int timeout_ms) {
+  TUTEL_REQUIRE(c != nullptr && c->flag_seg != nullptr && timeout_ms > 0, "tutel_amd_ep_ipc_set_timeout: need a communicator with the IPC transport and a positive time");
+  c->timeout_ticks = (long long)timeout_ms * 100000LL;
+  return 0;
+}
+
 // one workgroup, thread (i, w) = (stage, peer): flag[dir][stage0 + i][my rank] of rank w := this rank's next epoch for the slot
 __global__ void ep_signal_kernel(const uint64_t *__restrict__ flag_tab, uint32_t *__restrict__ epochs, int dir, int stage0,
                                  int nstages, int W, int rank) {

@@ -171,14 +171,20 @@ def _attach_ipc(comm, group, device):
     if not _agree(ok, group, device):
         return False
     comm._flags = flags
-    ok = 1
+    # self-check through the real kernels (peer stores, signal, wait), twice (the second pass exercises the epoch counters): block p
+    # of my send buffer carries (my rank, p, pass); afterwards block r must carry (r, my rank, pass).  Every pass ends in an
+    # agreement (which is also the barrier that keeps two exchanges into the same offset apart); the ranks are within
+    # milliseconds of each other here, so the waits of the check itself are bounded by 30 s, not by the watchdog-scale default.
+    n, W, rank = 1024, comm.world, comm.rank
     try:
-        # self-check through the real kernels (peer stores, signal, wait), twice (the second pass exercises the epoch counters):
-        # block p of my send buffer carries (my rank, p, pass); afterwards block r must carry (r, my rank, pass)
-        n, W, rank = 1024, comm.world, comm.rank
         seg = _open_segment(comm, W * n * 4, False)
-        comm._selfcheck = seg
-        for rep in range(2):
+    except _lib.TutelAmdError:
+        return False
+    comm._selfcheck = seg
+    L.tutel_amd_ep_ipc_set_timeout(comm.handle, min(30000, IPC_TIMEOUT_MS))
+    for rep in range(2):
+        good = 1
+        try:
             send = (torch.arange(W, device=device, dtype=torch.int32).view(W, 1) + 1000 * rank + 100000 * rep).repeat(1, n).contiguous()
             with torch.cuda.device(device):
                 _lib.check(L.tutel_amd_ep_ipc_exchange(comm.handle, seg.handle, send.data_ptr(), n * 4, 0, ops._stream()), "tutel_amd_ep_ipc_exchange")
@@ -190,14 +196,14 @@ def _attach_ipc(comm, group, device):
             want = (torch.arange(W, device=device, dtype=torch.int32).view(W, 1) * 1000 + rank + 100000 * rep).repeat(1, n)
             if not torch.equal(got, want):
                 raise _lib.TutelAmdError("tagged peer-store exchange returned wrong blocks")
-            dist.barrier(group=group)   # nobody starts the next pass (or the first forward) before everyone has read this one
-    except Exception as ex:  # noqa: BLE001
-        logging.warning("tutel_amd: the IPC transport failed its self-check on rank %d (%s)", comm.rank, ex)
-        ok = 0
-    if not _agree(ok, group, device):
-        if comm.rank == 0:
-            logging.warning("tutel_amd: IPC transport unavailable; the exchange stays on the communicator's all-to-all")
-        return False
+        except Exception as ex:  # noqa: BLE001
+            logging.warning("tutel_amd: the IPC transport failed its self-check on rank %d (%s)", comm.rank, ex)
+            good = 0
+        if not _agree(good, group, device):
+            if comm.rank == 0:
+                logging.warning("tutel_amd: IPC transport unavailable; the exchange stays on the communicator's all-to-all")
+            return False
+    L.tutel_amd_ep_ipc_set_timeout(comm.handle, IPC_TIMEOUT_MS)
     comm.ipc = True
     return True
 
