@@ -409,6 +409,51 @@ def test_expert_gemm_kernels_are_bit_identical(kmajor):
         assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), float(err.max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_ring256_kernel_of_the_128_row_regime(oracle, dtype):
+    """Round 4's kernel of the <= 128-rows-per-expert regime (128 x 256 tile, three-slot LDS-DMA ring, TUTEL_OPT_GEMM_IMPL = 4;
+    automatic when its grid covers the chip, as at the headline shape) against the 128 x 128 LDS-DMA kernel (impl 1), bit for bit, on
+    the argument combinations the layer uses: plain rows, rows gathered through the slot map (fused fast_encode, incl. empty slots),
+    per-expert row counts (megablocks), fewer than 128 rows, N not a multiple of 256, every fused activation, no bias."""
+    from tutel_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(29)
+    try:
+        for E, R, N, K, act, with_bias in ((5, 128, 640, 1024, "relu", True), (3, 100, 512, 512, "gelu", True), (7, 128, 256, 192, "none", False),
+                                           (4, 37, 1024, 256, "silu", True), (64, 128, 2048, 2048, "relu", True)):
+            a = torch.randn([E, R, K], generator=g).to(dtype).cuda()
+            w = ((torch.rand([E, N, K], generator=g) * 2 - 1) / math.sqrt(K)).to(dtype).cuda()
+            b = torch.randn([E, N], generator=g).to(dtype).cuda() if with_bias else None
+            counts = torch.randint(0, R + 1, [E], generator=g, dtype=torch.int32)
+            counts[0] = R
+            T = max(1, E * R // 2)
+            x = torch.randn([T, K], generator=g).to(dtype).cuda()
+            smap = torch.randint(-1, 2 * T, [E * R], generator=g, dtype=torch.int32)      # -1 = empty slot; values >= T: second choice (j*T + t)
+            smap[::5] = -1
+            outs = {}
+            for impl in (1, 4):
+                ops.set_option(_lib.OPT_GEMM_IMPL, impl)
+                plain = ops.expert_gemm(a, w, b, True, act=act)
+                gath = ops.expert_gemm_gather(x, smap.cuda(), w, b, True, act, R)
+                mega = torch.full([E, R, N], 3.0, dtype=dtype, device="cuda")
+                ops.expert_gemm(a, w, b, True, act=act, out=mega, d_layout=(R * N, 0, R, N), row_counts=counts.cuda(), row_align=4)
+                outs[impl] = (plain, gath, mega)
+            tag = (E, R, N, K, act)
+            for u, v in zip(outs[1], outs[4]):
+                assert torch.equal(u, v), tag
+            # and against fp32 arithmetic on the same operands
+            ref = torch.matmul(a.float(), w.float().transpose(1, 2)) + (b.float().unsqueeze(1) if b is not None else 0.0)
+            ref = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, "silu": torch.nn.functional.silu, "none": lambda t: t}[act](ref)
+            err = (outs[4][0].float() - ref).abs()
+            assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), (tag, float(err.max()))
+            # rows past ceil(count / 4) * 4 are left untouched
+            for e in range(E):
+                n = min(R, (int(counts[e]) + 3) // 4 * 4)
+                assert bool((outs[4][2][e, n:] == 3.0).all()) and torch.equal(outs[4][2][e, :n], outs[4][0][e, :n]), (tag, e)
+    finally:
+        ops.set_option(_lib.OPT_GEMM_IMPL, -1)
+
+
 def test_routing_randomized_shapes_vs_oracle(oracle):
     """A seeded sweep of 60 random (T, E, k, capacity_factor, dtype, normalize) problems: top-k, locations,
     dispatch_count, capacity and the encode -> decode round trip against the oracle, bit for bit on every
