@@ -14,7 +14,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from test_ep_ranks_one_gpu import (_ep_fixtures, _fixture_worker, _free_port, _run_ranks, _set_transport, _sweep_worker, _worker)
+from test_ep_ranks_one_gpu import (_ep_fixtures, _fixture_worker, _free_port, _rank_env, _run_ranks, _set_transport, _sweep_worker, _worker)
 
 pytestmark = pytest.mark.gpu
 
@@ -27,8 +27,9 @@ def test_ipc_transport_ranks_sharing_one_gpu(world, degree, E_loc):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, degree, E_loc, q, None, "ipc")) for r in range(world)]
-    for p in procs:
-        p.start()
+    with _rank_env(world):
+        for p in procs:
+            p.start()
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)

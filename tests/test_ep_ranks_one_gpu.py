@@ -3,6 +3,7 @@ all-to-all is staged through host memory (communicate.exchange_equal_split).  Ev
 production multi-GPU code path: the grouped GEMMs addressing the raw exchange buffers (rows_per_w, rank
 strides), the copy-free overlapped pipeline in both its expert-sliced and capacity-chunked form, the
 expert_slice / chunk_rows modes of encode and decode -- against the oracle's W-rank simulation."""
+import contextlib
 import os
 import socket
 
@@ -132,8 +133,9 @@ def test_expert_parallel_ranks_sharing_one_gpu(world, degree, E_loc, native):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, degree, E_loc, q, None, native)) for r in range(world)]
-    for p in procs:
-        p.start()
+    with _rank_env(world):
+        for p in procs:
+            p.start()
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
@@ -259,13 +261,31 @@ def _sweep_worker(rank, world, port, cfg, q):
         q.put((rank, False, traceback.format_exc(), []))
 
 
+@contextlib.contextmanager
+def _rank_env(world):
+    """environment the spawned rank processes inherit.  Four or more HIP processes on ONE device oversubscribe its hardware queues with
+    the runtime's default of 4 normal-priority queues per process (+ the side streams' priority queues): the scheduler then time-slices
+    the queues and a forward of the IPC transport takes 29 ms instead of 0.9 (profiles/r04_bench_ranks_sharing_one_gpu.txt) -- correct,
+    but 30 x slower and at the mercy of the wait bound.  Two queues per process keep W = 4 inside the device's queue slots.  (An
+    artefact of ranks sharing a device; one process per GPU never gets there.)"""
+    old = os.environ.get("GPU_MAX_HW_QUEUES")
+    if world >= 4 and old is None:
+        os.environ["GPU_MAX_HW_QUEUES"] = "2"
+    try:
+        yield
+    finally:
+        if world >= 4 and old is None:
+            os.environ.pop("GPU_MAX_HW_QUEUES", None)
+
+
 def _run_ranks(target, world, args, timeout=900):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
-    for p in procs:
-        p.start()
+    with _rank_env(world):
+        for p in procs:
+            p.start()
     res = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
         p.join(timeout=60)

@@ -20,8 +20,9 @@ def main():
         q = ctx.Queue()
         port = T._free_port()
         procs = [ctx.Process(target=T._worker, args=(r, 8, port, degree, E_loc, q, None, native)) for r in range(8)]
-        for p in procs:
-            p.start()
+        with T._rank_env(8):   # two hardware queues per process: eight default-sized processes oversubscribe the device's queue slots
+            for p in procs:
+                p.start()
         res = [q.get(timeout=600) for _ in procs]
         for p in procs:
             p.join(timeout=60)
