@@ -238,11 +238,12 @@ def main():
     if share:
         local_rank = 0
         os.environ.setdefault("TUTEL_AMD_EP_TRANSPORT", "ipc")   # processes that share a device can still map each other's segments
+    if world > 1:   # before the first HIP call of the process: the ROCm runtime reads it when it initialises (dmabuf IPC handles)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     local_rank %= max(1, torch.cuda.device_count())   # a launcher that hands every rank ONE visible device numbers it 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share:
             dist.init_process_group("gloo")
         else:
