@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 profile collection on the GPU box (run through gpurun from the repo root):  bash tools/profile_r04.sh
+# Round-4 profile collection on the GPU box (run through gpurun from the repo root):  bash tools/profile_r04.sh [quick]
 # Writes rocprofv3 summaries under gpurun_out/prof_r04/ and gpurun_out/prof_r04/traffic.json (stamped with the sha256 of the
 # kernel source it was measured on); the files worth keeping are copied to profiles/ by hand.
 set -x
@@ -50,5 +50,6 @@ json.dump(tj, open(f"{out}/traffic.json", "w"), indent=1)
 print(json.dumps(tj, indent=1))
 PY
 find $OUT -name "*kernel_stats.csv" | head
+[ "$1" = "quick" ] && exit 0   # (re-stamping traffic.json after a source change that leaves the dominant kernel's loop alone)
 # 4. per-rank shapes of the expert-parallel configurations, emulated on one GPU (bench lines only; kernel stats for the 8-expert one)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_ep8shape -- python bench.py --steps 20 --warmup 5 --experts 8 --no_cpu_baseline --no_extra > $OUT/bench_ep8shape.json 2> $OUT/bench_ep8shape.err
