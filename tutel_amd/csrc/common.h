@@ -129,24 +129,6 @@ static inline bool dtype_ok(int dtype) {
 // 16-byte vector of raw bits
 struct __attribute__((aligned(16))) vec16 { uint32_t w[4]; };
 
-// System-scope write-through stores for rows that belong to a PEER (IPC transport, csrc/ep.hip): `global_store ... sc0 sc1` leaves
-// the XCD's L2 as it is issued -- over xGMI when the peer is another device -- instead of sitting there as a dirty line until the
-// end-of-kernel write-back, so a kernel's transfer overlaps with its own execution (the second GEMM's output rows with the tiles
-// still being computed) and the rows' visibility does not hinge on that write-back.  16 bytes cost what a plain store costs.  The
-// compiler's s_waitcnt insertion does not count these (inline assembly): uncounted stores in flight can only make one of its
-// counted waits longer, never shorter (loads return in order among themselves), and nothing here reads what they wrote.
-typedef uint32_t tutel_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st16_sys(void *p, tutel_u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st8_sys(void *p, uint2 v) {
-  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st16_sys(void *p, const vec16 &v) {
-  tutel_u32x4 t = {v.w[0], v.w[1], v.w[2], v.w[3]};
-  st16_sys(p, t);
-}
-
 // unpack / pack 16 bytes <-> fp32 lanes
 template <typename T> struct Vec;
 template <> struct Vec<float> {

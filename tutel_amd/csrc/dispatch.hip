@@ -58,21 +58,18 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
     int q = slot_map[plain];  // wave-uniform
     q = __builtin_amdgcn_readfirstlane(q);
     T *dst = out + (size_t)slot * M;
-    bool sys = false;  // wave-uniform: the row goes to ANOTHER rank -> system-scope write-through vector stores (st16_sys, common.h)
     if (peer.tab != nullptr) {
       // peer stores (csrc/ep.hip, IPC transport): bucket row `slot` of the exchange layout [stage][dst rank][rows] is written
       // straight into the receive buffer of the rank that owns the expert, where an all-to-all would have delivered it:
       // block <my rank> of its [stage][src rank][rows] array.  peer.tab[w] = base of rank w's segment in THIS process.
       const int blk = slot / peer.rows, rem = slot % peer.rows, st = blk / ep_world, w = blk % ep_world;
       dst = reinterpret_cast<T *>(peer.tab[w] + peer.off) + ((size_t)(st * ep_world + peer.rank) * peer.rows + rem) * M;
-      sys = w != peer.rank;
     }
-#define ENC_PUT(D, I, V) do { if (sys) st16_sys((D) + (I), (V)); else (D)[I] = (V); } while (0)
     if (q < 0) {
       if (vec_ok) {
         vec16 z = {{0u, 0u, 0u, 0u}};
         vec16 *d = reinterpret_cast<vec16 *>(dst);
-        for (int i = lane; i < nvec; i += 64) ENC_PUT(d, i, z);
+        for (int i = lane; i < nvec; i += 64) d[i] = z;
       } else {
         for (int i = lane; i < M; i += 64) dst[i] = Elem<T>::from_f32(0.f);
       }
@@ -87,12 +84,9 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
         int i = lane;
         for (; i + 192 < nvec; i += 256) {  // 4 independent 16B loads in flight per lane
           vec16 a = s[i], b = s[i + 64], c = s[i + 128], e = s[i + 192];
-          ENC_PUT(d, i, a); ENC_PUT(d, i + 64, b); ENC_PUT(d, i + 128, c); ENC_PUT(d, i + 192, e);
+          d[i] = a; d[i + 64] = b; d[i + 128] = c; d[i + 192] = e;
         }
-        for (; i < nvec; i += 64) {
-          vec16 a = s[i];
-          ENC_PUT(d, i, a);
-        }
+        for (; i < nvec; i += 64) d[i] = s[i];
       } else {
         for (int i = lane; i < M; i += 64) dst[i] = src[i];
       }
@@ -108,13 +102,12 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
 #pragma unroll
           for (int u = 0; u < VN; ++u) f[u] = mul_rn(g, f[u]);
           Vec<T>::pack(f, v);
-          ENC_PUT(d, i, v);
+          d[i] = v;
         }
       } else {
         for (int i = lane; i < M; i += 64) dst[i] = Elem<T>::from_f32(mul_rn(g, Elem<T>::to_f32(src[i])));
       }
     }
-#undef ENC_PUT
   }
 }
 

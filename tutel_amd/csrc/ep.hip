@@ -376,10 +376,9 @@ extern "C" int tutel_amd_ep_all_gather_v(tutel_amd_ep_comm_t *c, const void *sen
 
 // ---- IPC transport ------------------------------------------------------------------------------------------------
 // Replaces the exchange kernels of ncclAllToAll (custom_kernel.cpp:559-579, 627-648: one ncclSend / ncclRecv pair per peer and
-// chunk) by stores of the producing kernels themselves.  Memory model: a producer's stores into a peer's segment are complete
-// at its kernel boundary -- the 16-byte row stores are system-scope write-through (st16_sys, common.h: acknowledged from the peer's
-// memory, nothing left in this device's L2s), the scalar tails of rows that are not a multiple of 16 bytes are plain stores that
-// the end-of-kernel release writes back; the flag is written by the NEXT kernel on the same stream, so it can never overtake the data; the consumer polls the flag with system-scope loads in a kernel of its own and the consuming
+// chunk) by stores of the producing kernels themselves.  Memory model: a producer's stores into a peer's segment become visible
+// at its kernel boundary (end-of-kernel release to system scope); the flag is written by the NEXT kernel on the same stream, so
+// it can never overtake the data; the consumer polls the flag with system-scope loads in a kernel of its own and the consuming
 // kernel starts after that kernel's boundary (start-of-kernel acquire).  No fence inside a bandwidth kernel, no in-kernel spin
 // in a kernel that holds more than one wave.
 //
@@ -573,14 +572,7 @@ __global__ __launch_bounds__(256) void ep_peer_copy_kernel(const uint4 *__restri
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
     const int w = (int)(v / vec_per_peer);
     const size_t o = v % vec_per_peer;
-    uint4 *dst = reinterpret_cast<uint4 *>(tab[w] + recv_off) + (size_t)rank * vec_per_peer + o;
-    const uint4 x = send[v];
-    if (w != rank) {  // the store flavour of the producing kernels (encode_kernel, the GEMM epilogues): st16_sys, common.h
-      tutel_u32x4 t = {x.x, x.y, x.z, x.w};
-      st16_sys(dst, t);
-    } else {
-      *dst = x;
-    }
+    reinterpret_cast<uint4 *>(tab[w] + recv_off)[(size_t)rank * vec_per_peer + o] = send[v];
   }
 }
 

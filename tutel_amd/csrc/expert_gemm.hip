@@ -165,8 +165,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, f32x16 (&acc)[N
         uint2 ov;
         ov.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
         ov.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-        if (p.d_peer != nullptr) st8_sys(drow + n, ov);  // a peer's row: write-through (common.h)
-        else *reinterpret_cast<uint2 *>(drow + n) = ov;
+        *reinterpret_cast<uint2 *>(drow + n) = ov;
       }
     }
   }
@@ -649,8 +648,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&ac
     const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + row * PITCH + c16 * 16);
     if (m < row_limit && n < p.N) {
       const size_t roff = (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;
-      if (p.d_peer != nullptr) st16_sys(gemm_out_row(p, e, m) + n, val);  // a peer's row: write-through (common.h)
-      else *reinterpret_cast<u32x4 *>(De + roff + n) = val;
+      uint16_t *drow = p.d_peer != nullptr ? gemm_out_row(p, e, m) : De + roff;
+      *reinterpret_cast<u32x4 *>(drow + n) = val;
     }
   }
 }
