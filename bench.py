@@ -12,11 +12,21 @@ reference's `helloworld.py --eval` (helloworld.py:141-146).
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
     per GPU: 4096 tokens (batch 16 x 256) x model_dim 2048, hidden 2048, 64 GLOBAL experts,
     top-2, capacity_factor 1.0 (capacity 128/expert/rank), bf16, ReLU, biases on.
-N > 1: experts are sharded E_loc = 64/N per rank (expert parallel, a2a_ffn_overlap_degree 2), every rank keeps its own
-4096 tokens -> per-GPU work is fixed: weak scaling, value = N * 4096 / t.  The exchange is the library's IPC transport
-(round 4: fast_encode and the fc2 epilogue store their rows straight into the peers' buffers over xGMI, one flag per
-(direction, stage, peer), no collective on the path) when every rank can map its peers' segments and the tagged
-self-check passes; RCCL's all-to-all on the library communicator otherwise (`config.exchange` says which ran).
+N > 1: experts are sharded E_loc = 64/N per rank (expert parallel), every rank keeps its own 4096 tokens -> per-GPU work
+is fixed: weak scaling, value = N * 4096 / t.  `python bench.py --gpus N` WITHOUT a launcher starts itself under
+torch.distributed.run (one process per GPU); under a launcher it takes RANK / WORLD_SIZE from the environment.
+Before anything is timed at N > 1 the script (round 5):
+  * computes reference outputs of three DIFFERENT batches over the torch.distributed path (impls/overlap.py / communicate.py:
+    torch's all_to_all_single on the process group -- no oracle here);
+  * runs every exchange the library has -- "ipc" (peer stores over xGMI from fast_encode and the fc2 epilogue, flag kernels,
+    epoch canaries, no collective), "rccl" (ncclAllToAll on the library's own communicator), "torch" (all_to_all_single on
+    torch's communicator, two HIP streams: north_star's literal configuration) -- at a2a_ffn_overlap_degree 2 and 1: each mode
+    is first a PARITY CANARY (the three batches through that mode, every rank compares with the reference, the verdict is
+    all-reduced) and only then a short timed run; `ep_modes` in the line carries all of them;
+  * `value` is a2a_ffn_overlap_degree 2 (north_star) on the first transport of ipc -> rccl -> torch that is available AND
+    passed its canary -- a transport that fails is reported loudly (stderr + `parity.fell_back_from`) and never timed as
+    the value; `best` names the fastest mode that passed.  The timed path (the HIP-graph replay when the transport allows
+    one) takes the three batches once more before the timed region (`parity`).
 
 Timing: `--settle` untimed initialisation passes (allocator / weight pre-layout / clock state; reported in
 the JSON), W untimed warm-up steps; barrier + synchronize; exactly K steps; synchronize + barrier; MAX over
@@ -52,6 +62,7 @@ Checker code is used here ONLY as that reported baseline; it is never part of th
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -110,7 +121,7 @@ def source_sha():
     return h.hexdigest()
 
 
-def gemm_probe(E_loc, R, M, H, dtype, iters=30):
+def gemm_probe(E_loc, R, M, H, dtype, iters=30):  # noqa: D401
     """the fc1 grouped GEMM (bias + ReLU fused) on random operands at one shape, alternating two weight sets so that the weights
     come from HBM: average launch in us between HIP events around `iters` back-to-back launches"""
     from tutel_amd import ops
@@ -202,6 +213,250 @@ def run_timed(step, x, steps, world, timer_gate, mode=2, marks=True):
     return t1 - t0, per_step, ops.stage_report(), y
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(n, argv):
+    """what `python bench.py --gpus N` execs when no launcher set WORLD_SIZE: the driver's own multi-GPU command line"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_relaunch(args):
+    """--gpus N > 1 without a launcher (no WORLD_SIZE in the environment): start N rank processes of this script under
+    torch.distributed.run and become that launcher (the bare command used to die on an assertion)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    cmd = launcher_command(args.gpus, sys.argv[1:])
+    if os.environ.get("TUTEL_AMD_BENCH_LAUNCH_ECHO") == "1":   # CPU test hook: show the command instead of running it
+        print(json.dumps({"would_exec": cmd}), flush=True)
+        sys.exit(0)
+    share = os.environ.get("TUTEL_AMD_BENCH_SHARE_GPU", "0") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not share:
+        print(f"bench.py: --gpus {args.gpus} but this box exposes {have} GPU(s) (TUTEL_AMD_BENCH_SHARE_GPU=1 runs the ranks on one "
+              f"device as a code-path test, not a measurement)", file=sys.stderr, flush=True)
+        sys.exit(2)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if share and args.gpus >= 4:
+        env.setdefault("GPU_MAX_HW_QUEUES", "2")   # ranks sharing ONE device: stay inside its hardware queue slots (tests/test_ep_ranks_one_gpu.py)
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def parity_of(y, ref):
+    """max |y - ref| and whether the two are the same bits; ok = within one bf16 / fp16 ulp of the reference's scale (the paths run the
+    same kernels in the same order, so the expectation is bitwise equality -- a row of another batch is off by O(scale))"""
+    d = (y.float() - ref.float()).abs()
+    scale = float(ref.float().abs().max())
+    err = float(d.max()) if d.numel() else 0.0
+    fin = bool(torch.isfinite(y.float()).all())
+    return {"max_abs_err": err, "scale": scale, "bitwise": bool(torch.equal(y, ref)), "ok": fin and err <= 2 ** -6 * max(scale, 1e-6)}
+
+
+EP_TRANSPORTS = ("ipc", "rccl", "torch")
+
+
+def configure_ep(layer, transport, degree):
+    """switch the layer's exchange (collective: every rank calls it at the same point).  "torch" = the Python-orchestrated pipeline
+    over torch.distributed (impls/overlap.py); "ipc" / "rccl" = the one-call native pipeline over that transport."""
+    from tutel_amd.impls import ep_native as EN
+    torch.cuda.synchronize()   # nothing of the previous mode may still be running when its segments are unmapped ...
+    dist.barrier()             # ... on ANY rank (peers store into them)
+    EN.set_transport("ipc" if transport == "ipc" else "rccl")
+    EN.ENABLED = transport != "torch"
+    EN.forget_workspaces(layer)
+    layer.a2a_ffn_overlap_degree = degree
+
+
+def ep_transport_running(layer, dev):
+    """which exchange the layer's last forward really used"""
+    from tutel_amd.impls import ep_native as EN
+    if not EN.ENABLED:
+        return "torch"
+    comm = EN.communicator(layer.group, dev) if EN.group_ok(layer.group) else None
+    if comm is None:
+        return "torch"
+    return "ipc" if comm.ipc else ("rccl" if not hasattr(comm, "register") else "hosted")
+
+
+def agree_min(v, share, dev):
+    f = torch.tensor([int(v)], device="cpu" if share else dev, dtype=torch.int32)
+    dist.all_reduce(f, op=dist.ReduceOp.MIN)
+    return int(f)
+
+
+def ep_sweep(layer, batches, world, rank, dev, share, steps, warmup, gate_timer):
+    """reference outputs over torch.distributed, then every (transport, degree): parity canary, short timed run.
+    Returns (list of mode records, reference outputs)."""
+    from tutel_amd.impls import ep_native as EN
+    from tutel_amd.impls.graph import GraphedForward
+    T = batches[0].shape[0] * batches[0].shape[1]
+    with torch.no_grad():
+        configure_ep(layer, "torch", 1)
+        refs = [layer(b).clone() for b in batches]
+        torch.cuda.synchronize()
+    modes = []
+    for transport in EP_TRANSPORTS:
+        for degree in (2, 1):
+            rec = {"transport": transport, "a2a_ffn_overlap_degree": degree, "available": False, "parity": None, "launch": None,
+                   "ms_per_step": None, "value": None, "note": None}
+            ok, step = 1, None
+            try:
+                with torch.no_grad():
+                    configure_ep(layer, transport, degree)
+                    y0 = layer(batches[0])
+                    torch.cuda.synchronize()
+                    running = ep_transport_running(layer, dev)
+                    if running != transport:
+                        rec["note"] = f"not available here (the forward ran over {running})"
+                        ok = 0
+                    else:
+                        rec["available"] = True
+                        ys = [y0.clone()] + [layer(b).clone() for b in batches[1:]] + [layer(batches[0]).clone()]   # ... and the first one again
+                        torch.cuda.synchronize()
+                        EN.ipc_status()
+                        ps = [parity_of(y, refs[i % len(refs)]) for i, y in enumerate(ys)]
+                        rec["parity"] = {"checked": len(ps), "max_abs_err": max(q["max_abs_err"] for q in ps), "bitwise": all(q["bitwise"] for q in ps),
+                                         "ok": all(q["ok"] for q in ps), "reference": "torch.distributed all_to_all_single path, degree 1"}
+                        ok = int(rec["parity"]["ok"])
+            except Exception as ex:   # noqa: BLE001 -- loud, and agreed below
+                rec["note"] = f"{type(ex).__name__}: {str(ex)[:240]}"
+                ok = 0
+            passed = agree_min(ok, share, dev)
+            if rec["available"] and rec["parity"] is not None:
+                rec["parity"]["ok_on_every_rank"] = bool(passed)
+            if not passed:
+                if rec["available"] and rank == 0:
+                    print(f"bench.py: exchange '{transport}' degree {degree} FAILED its parity canary / raised ({rec['note'] or rec['parity']}): not timed",
+                          file=sys.stderr, flush=True)
+                modes.append(rec)
+                continue
+            tok = 1
+            try:
+                with torch.no_grad():
+                    step, rec["launch"] = layer, "eager"
+                    x = batches[0]
+                    if transport == "ipc":   # plain kernels + events: the captured forward replays
+                        try:
+                            g = GraphedForward(layer, batches[0])
+                            step, x, rec["launch"] = g, g.static_in, "hip-graph replay"
+                        except Exception as ex:   # noqa: BLE001
+                            rec["note"] = f"graph capture failed ({type(ex).__name__}: {str(ex)[:120]}); eager"
+                    gk = agree_min(rec["launch"] != "eager", share, dev)
+                    if not gk and rec["launch"] != "eager":
+                        step, x, rec["launch"] = layer, batches[0], "eager"
+                    for _ in range(max(warmup, 10)):
+                        step(x)
+                    el, _, _, _ = run_timed(step, x, steps, world, gate_timer, mode=0, marks=False)
+                    EN.ipc_status()
+            except Exception as ex:   # noqa: BLE001
+                rec["note"] = f"{type(ex).__name__}: {str(ex)[:240]}"
+                tok, el = 0, 0.0
+            tt = torch.tensor([el if tok else 1e9], device="cpu" if share else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if float(tt) < 1e8:
+                rec["ms_per_step"] = round(float(tt) / steps * 1e3, 4)
+                rec["value"] = round(world * T / (float(tt) / steps), 1)
+            step = None
+            modes.append(rec)
+    return modes, refs
+
+
+def rank_pipeline_probe(n, M, H, T, k, dtype, dev, iters=60):
+    """ONE rank's pipeline of an n-way expert-parallel run of this workload, alone on this GPU, through a world-size-1 IPC communicator
+    (the peer is the rank itself: fast_encode and the fc2 epilogue store through the peer table, flags are signalled and awaited as
+    between ranks): E_loc = E / n local experts x n * capacity rows -- a 1-rank layer with E_loc experts over the same T tokens has
+    exactly those GEMM, encode and decode shapes.  Returns ms per forward for degree 1 and 2 (eager wall over `iters` back to back)."""
+    from tutel import moe
+    from tutel_amd.impls import ep_native as EN
+    E_loc = 64 // n
+    torch.set_default_dtype(dtype)
+    try:
+        layer = moe.moe_layer(gate_type={"type": "top", "k": k}, model_dim=M,
+                              experts={"type": "ffn", "num_experts_per_device": E_loc, "hidden_size_per_expert": H,
+                                       "activation_fn": lambda t: torch.nn.functional.relu(t)}).to(dev).eval()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    x = torch.randn([T, M], device=dev).to(dtype)
+    out = {}
+    with torch.no_grad():
+        for degree in (1, 2):
+            EN.forget_workspaces(layer)
+            for _ in range(10):
+                layer(x, a2a_ffn_overlap_degree=degree)
+            torch.cuda.synchronize()
+            comm = EN.communicator(layer.group, dev)
+            assert comm is not None and comm.ipc and comm.world == 1
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                layer(x, a2a_ffn_overlap_degree=degree)
+            torch.cuda.synchronize()
+            out[degree] = (time.perf_counter() - t0) / iters * 1e3
+    del layer
+    return out
+
+
+XGMI_LINK_GBS = 153.0   # per link and direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, one link per peer)
+
+
+def modelled_scaling(M, H, T, E, k, C, dtype, dev):
+    """SURVEY 8(d)'s fallback for the points a one-GPU box cannot measure: per-rank compute MEASURED here at the per-rank shapes + a link
+    time MODEL.  Every number in here is labelled modelled; none of it is `value`."""
+    from tutel_amd.impls import ep_native as EN
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    made_pg = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        made_pg = True
+    old = (EN.HOSTED, EN.TRANSPORT, EN._FORCE_COMM)
+    EN.set_transport("ipc", hosted=False)
+    EN._FORCE_COMM = True
+    points = {}
+    try:
+        for n in (2, 4, 8):
+            t = rank_pipeline_probe(n, M, H, T, k, dtype, dev)
+            per_peer = E * C * M * 2 / n                       # bytes one rank sends to ONE peer per direction (its own link)
+            link_ms = per_peer / (XGMI_LINK_GBS * 1e9) * 1e3   # all n - 1 peers in parallel, one link each
+            serial = t[1] + 2 * link_ms                        # degree 1: nothing hidden
+            half = t[2] + link_ms                              # degree 2: one of the two stages' transfers hidden behind the other's GEMMs, each way
+            best = min(serial, half)
+            points[str(n)] = {"modelled": True, "rank_pipeline_ms_measured": {"degree1": round(t[1], 4), "degree2": round(t[2], 4)},
+                              "per_peer_MB_per_direction": round(per_peer / 1e6, 2), "link_ms_per_direction_model": round(link_ms, 4),
+                              "ms_per_step_model": {"degree1_nothing_hidden": round(serial, 4), "degree2_half_hidden": round(half, 4)},
+                              "tokens_per_s_model": round(n * T / (best * 1e-3), 1)}
+    finally:
+        EN.destroy_all()
+        EN.HOSTED, EN.TRANSPORT, EN._FORCE_COMM = old
+        if made_pg:
+            dist.destroy_process_group()
+    return {"modelled": True, "points": points,
+            "model": "tokens/s(N) = N * T / (one rank's pipeline, MEASURED alone on this GPU through a world-size-1 IPC communicator at E_loc = 64/N experts x "
+                     f"N * {C} rows, + link time), link time per direction = E*C*M*2/N bytes to each peer over its own xGMI link at {XGMI_LINK_GBS} GB/s "
+                     "(MODEL; no link was exercised), degree 1: both directions exposed, degree 2: half of them hidden",
+            "note": "NOT a measurement of a multi-GPU run: the compute legs are measured on one GPU, the exchange is a formula"}
+
+
+def tie_rule(dname):
+    """north_star asks for bit-exact token-to-expert assignment; torch.topk leaves the order of EXACT ties unspecified (and its CPU
+    and GPU kernels differ), so the library pins one: lowest expert index.  How often that differs from the reference's CPU run at
+    this very configuration is measured and committed (tests/test_layer_gpu.py::test_headline_low_precision_gate_assignment_vs_reference)."""
+    path = os.path.join(ROOT, "profiles", f"r04_headline_gate_assignment_{'bfloat16' if dname == 'bf16' else 'float16'}.json")
+    try:
+        d = json.load(open(path))
+        return (f"lowest expert index on exact ties; {d['differing_assignments']} of {d['assignments']} (token, k) assignments on "
+                f"{d['differing_tokens']} tokens differ from the reference's torch.topk (CPU) at this configuration with a {d['dtype']} gate -- "
+                f"every one an exact tie among the reference's own scores ({os.path.relpath(path, ROOT)})")
+    except Exception:   # noqa: BLE001
+        return "lowest expert index on exact ties (torch.topk leaves tie order unspecified)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +481,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="(default when capacity_factor > 0) replay the forward from a captured HIP graph")
     ap.add_argument("--eager", action="store_true", help="time the Python-enqueued forward instead of the HIP-graph replay")
     args = ap.parse_args()
+    maybe_relaunch(args)
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -269,13 +525,37 @@ def main():
     step = (lambda t: layer(t, **fwd_kw)) if fwd_kw else layer
     eager_step = step
     launch, graph_note, graphed = "eager", None, None
+    # ---- N > 1: reference outputs, every exchange x degree through its parity canary and a short timed run, then the choice ----
+    ep_modes, parity, chosen, batches, refs, fell_back = None, None, None, None, None, []
+    if world > 1:
+        ep_native.IPC_TIMEOUT_MS = min(ep_native.IPC_TIMEOUT_MS, 30000)   # a peer that never arrives costs this script 30 s, not the 2-minute watchdog
+        g = torch.Generator().manual_seed(4321 + rank)
+        batches = [x] + [torch.randn([16, T // 16, M], generator=g, dtype=torch.float32).to(dtype).to(dev) for _ in range(2)]
+        ep_modes, refs = ep_sweep(layer, batches, world, rank, dev, share, min(args.steps, 50), args.warmup, gate_timer)
+        by = {(m["transport"], m["a2a_ffn_overlap_degree"]): m for m in ep_modes}
+        for t in EP_TRANSPORTS:
+            m = by.get((t, overlap)) or by[(t, 2)]
+            if m["value"] is not None:
+                chosen = t
+                break
+            if m["available"]:
+                fell_back.append(t)
+        if chosen is None:
+            print("bench.py: NO exchange passed its parity canary -- nothing to time", file=sys.stderr, flush=True)
+            if rank == 0:
+                print(json.dumps({"metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2", "value": None, "n_gpus": world,
+                                  "error": "no exchange passed its parity canary", "ep_modes": ep_modes}), flush=True)
+            sys.exit(3)
+        if fell_back and rank == 0:
+            print(f"bench.py: FELL BACK from {fell_back} to '{chosen}' (parity canary / availability, see ep_modes)", file=sys.stderr, flush=True)
+        configure_ep(layer, chosen, overlap)
     # N > 1: the graph is replayed when the exchange is the IPC transport (kernels + events only); GraphedForward refuses to capture
     # RCCL collectives (replaying them hung after ~200 replays in the 1-rank-communicator probe, profiles/r03_ep_streams.txt) and
     # the forward is then timed eager -- every rank takes the same branch (the transport is agreed at communicator creation).
     # The replay is the timed mode (as in round 3) and the eager forward is timed beside it (`value_eager`, `launch_modes.other`): in
     # steady state the two cost the same (0.256-0.259 ms per forward on the round-4 boxes), but a 20-step region entered from a
     # synchronize costs the eager loop its first forward at host pace (0.43-0.44 ms: +8 us on the mean of 20), the replay +1 us.
-    want_graph = (args.graph or not args.eager) and args.capacity_factor > 0
+    want_graph = (args.graph or not args.eager) and args.capacity_factor > 0 and (world == 1 or chosen == "ipc")
     also_graph = args.eager and args.capacity_factor > 0 and world == 1
     if want_graph:
         # same kernels (and, N > 1, the same RCCL collectives on the caller's stream), enqueued by ONE hipGraphLaunch per step:
@@ -301,6 +581,34 @@ def main():
     elif args.capacity_factor <= 0:
         graph_note = "dropless routing reads the capacity back to the host every step: not capturable, eager"
 
+    if world > 1:
+        # the parity canary once more, THROUGH THE TIMED PATH (the graph replay when there is one): three different batches and the
+        # first again, every rank against the torch.distributed reference
+        def canary(fn):
+            with torch.no_grad():
+                ys = [fn(b).clone() for b in batches + [batches[0]]]
+            torch.cuda.synchronize()
+            ep_native.ipc_status()
+            ps = [parity_of(yy, refs[i % len(refs)]) for i, yy in enumerate(ys)]
+            return {"checked": len(ps), "max_abs_err": max(q["max_abs_err"] for q in ps), "bitwise": all(q["bitwise"] for q in ps),
+                    "ok": bool(agree_min(all(q["ok"] for q in ps), share, dev))}
+        parity = canary(step)
+        if not parity["ok"] and launch != "eager":
+            graph_note = "the HIP-graph replay FAILED the parity canary; timed eager instead"
+            print("bench.py: " + graph_note, file=sys.stderr, flush=True)
+            step, launch, x = eager_step, "eager", batches[0]
+            parity = canary(step)
+        parity.update(transport=chosen, launch=launch, fell_back_from=fell_back,
+                      reference="the same forward over torch.distributed (all_to_all_single on the process group, impls/overlap.py), degree 1")
+        if not parity["ok"]:
+            print("bench.py: the timed path FAILED its parity canary -- refusing to report a throughput for wrong tokens", file=sys.stderr, flush=True)
+            if rank == 0:
+                print(json.dumps({"metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2", "value": None, "n_gpus": world,
+                                  "error": "timed path failed its parity canary", "parity": parity, "ep_modes": ep_modes}), flush=True)
+            sys.exit(3)
+        if graphed is not None and step is graphed:
+            graphed.static_in.copy_(batches[0])
+            x = graphed.static_in
     with torch.no_grad():
         for _ in range(args.settle):
             step(x)
@@ -340,6 +648,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, other = float(tt[0]), (float(tt[1]) if other is not None else None)
     assert torch.isfinite(y.float()).all()
+    if world > 1:
+        ep_native.ipc_status()   # an exchange that gave up inside the timed region (its outputs are NaN) must not become a number
 
     C = int(layer.protected_shape[1]) // world  # capacity the layer actually used (dropless: max expert load)
     R = world * C                               # rows per local expert
@@ -416,7 +726,11 @@ def main():
         value = world * T / (elapsed / args.steps)
         # algorithmic bytes of the whole forward on one rank: gate reads x; encode (T + E*C) rows; FFN weights + rows in/out;
         # decode (n_kept + T) rows; all-to-all bytes are link traffic, not HBM, and are listed separately
-        layer_bytes = (T * M + (T + E * C) * M + 2 * E_loc * H * M + 2 * E_loc * R * (M + H) + (min(k * T, E * C) + T) * M) * es
+        # SURVEY 8(d)'s definition: gate T*M; encode (T + E*C)*M; expert FFN weights 2*E_loc*H*M + rows in / out
+        # E_loc*R*(M + M) with the [R, H] intermediate kept ON CHIP; decode (n_kept + T)*M -- 1 257 MB at the headline shape.  (The
+        # two-launch FFN really writes and re-reads `hid`, 2 x 33.5 MB more, mostly through the Infinity Cache: `bytes_moved_two_launch_ffn`.)
+        layer_bytes = (T * M + (T + E * C) * M + 2 * E_loc * H * M + 2 * E_loc * R * M + (min(k * T, E * C) + T) * M) * es
+        moved_bytes = layer_bytes + 2 * E_loc * R * H * es
         srt = sorted(per_step)
         out = {
             "metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2",
@@ -441,10 +755,11 @@ def main():
                        "capacity": C, "parallelism": f"ep{world}" if world > 1 else "single-gpu",
                        "a2a_ffn_overlap_degree": overlap, "fp32_gate": bool(args.fp32_gate),
                        "capacity_factor": args.capacity_factor, "megablocks_size": args.megablocks_size, "launch": launch,
-                       "exchange": (("IPC transport: peer stores over xGMI from fast_encode and the fc2 epilogue, flag kernels, no collective (tutel_amd_ep_forward)"
-                                     if any(c and c.ipc for c in ep_native._comms.values()) else "library RCCL communicator (tutel_amd_ep_forward)")
-                                    if ep_native._comms and any(ep_native._comms.values())
-                                    else "torch.distributed all_to_all_single") if world > 1 else "none (single rank)"},
+                       "exchange": {"ipc": "IPC transport: peer stores over xGMI from fast_encode and the fc2 epilogue, flag kernels, epoch canaries, no collective (tutel_amd_ep_forward)",
+                                    "rccl": "ncclAllToAll on the library's RCCL communicator (tutel_amd_ep_forward)",
+                                    "torch": "torch.distributed all_to_all_single on a communication stream, GEMMs on the caller's (impls/overlap.py)",
+                                    None: "none (single rank)"}[chosen],
+                       "tie_rule": tie_rule(dname)},
             "roofline": roofline,
             "stages": {"avg_us_per_step": stage_us, "launches_timed": launches,
                        "sum_us": round(sum(stage_us.values()), 2),
@@ -455,10 +770,21 @@ def main():
             "launch_modes": {"timed": launch, "note": graph_note,
                              "other": (None if other is None else {"launch": other_launch, "ms_per_step": round(other / args.steps * 1e3, 4),
                                                                    "value": round(world * T / (other / args.steps), 1)})},
-            "layer_roofline": {"algorithmic_bytes_per_step": layer_bytes, "achieved_GBs": round(layer_bytes / (ms * 1e-3) * 1e-9, 1),
+            "layer_roofline": {"algorithmic_bytes_per_step": layer_bytes, "bytes_moved_two_launch_ffn": moved_bytes,
+                               "definition": "SURVEY 8(d): gate + encode + FFN (weights + rows in / out, hidden on chip) + decode",
+                               "achieved_GBs": round(layer_bytes / (ms * 1e-3) * 1e-9, 1),
                                "frac_of_hbm_peak": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
                                "frac_of_hbm_achievable": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_ACHIEVABLE_GBS, 4)},
         }
+        if world > 1:
+            ok_modes = [m for m in ep_modes if m["value"] is not None]
+            bm = max(ok_modes, key=lambda m: m["value"]) if ok_modes else None
+            out["parity"] = parity
+            out["ep_modes"] = ep_modes
+            out["best"] = None if bm is None else {"transport": bm["transport"], "a2a_ffn_overlap_degree": bm["a2a_ffn_overlap_degree"],
+                                                   "value": bm["value"], "ms_per_step": bm["ms_per_step"], "launch": bm["launch"],
+                                                   "note": f"fastest mode that passed its parity canary ({min(args.steps, 50)} timed steps each); `value` is degree "
+                                                           f"{overlap} on '{chosen}' (north_star's configuration), timed over {args.steps} steps"}
         if world == 1 and not args.no_extra and headline:
             # BASELINE configs[2] (same shape, dropless + megablocks): a short secondary measurement, recorded next to the headline one
             lay2 = build_layer(M, H, E_loc, k, rank, 1, dtype, args.fp32_gate, 0.0).to(dev).eval()
@@ -481,11 +807,34 @@ def main():
             out.setdefault("extra", {})["ep8_rank_gemms"] = {
                 "stage_gemm": gemm_probe(4, 1024, M, H, dtype), "full_rank_gemm": gemm_probe(8, 1024, M, H, dtype),
                 "note": "expert_gemm (fc1: bias + ReLU fused) launched alone on one GPU at the shapes an 8-way expert-parallel rank runs; MFMA-bound"}
+            # the same for the expert problems of BASELINE configs[3] / [4] (M = H = 4096; configs[4] is fp16, 16 local experts)
+            out["extra"]["rank_gemms_configs3_4"] = {
+                "configs3_bf16_8x1024x4096x4096": gemm_probe(8, 1024, 4096, 4096, torch.bfloat16, iters=12),
+                "configs4_fp16_16x1024x4096x4096": gemm_probe(16, 1024, 4096, 4096, torch.float16, iters=8),
+                "note": "per-rank fc1 grouped GEMM of the 8-GPU configurations (E_loc experts x W*C = 1024 rows, K = N = 4096), alone on one GPU"}
+            # SURVEY 8(d)'s secondary reading of configs[1]: batch 16 x 4096 tokens = 65 536 tokens through the same layer (2048 rows per expert: MFMA-bound)
+            x65 = torch.randn([16, 4096, M], device=dev).to(dtype)
+            with torch.no_grad():
+                for _ in range(3):
+                    layer(x65)
+                el65, _, _, _ = run_timed(layer, x65, 10, 1, gate_timer, mode=0, marks=False)
+            fl65 = 4.0 * E * int(layer.protected_shape[1]) * M * H
+            out["extra"]["tokens_65536"] = {"workload": "configs[1] read as batch 16 x 4096 tokens (SURVEY 8d secondary point): 65 536 tokens, capacity "
+                                                        f"{int(layer.protected_shape[1])} rows per expert", "value": round(65536 / (el65 / 10), 1), "unit": "tokens/s",
+                                            "ms_per_step": round(el65 / 10 * 1e3, 4), "steps": 10, "launch": "eager",
+                                            "expert_tflops": round(fl65 / (el65 / 10) * 1e-12, 1), "frac_of_mfma_peak": round(fl65 / (el65 / 10) * 1e-12 / MFMA_PEAK_TFLOPS, 4)}
+            del x65
+            try:
+                out["extra"]["modelled_scaling"] = modelled_scaling(M, H, T, E, k, C, dtype, dev)
+            except Exception as ex:   # noqa: BLE001 -- an extra must never cost the line
+                out["extra"]["modelled_scaling"] = {"modelled": True, "error": f"{type(ex).__name__}: {str(ex)[:200]}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, M, H, E, k)
         print(json.dumps(out), flush=True)
     if world > 1:
         ep_native.destroy_all()
+        dist.destroy_process_group()
+    elif dist.is_initialized():
         dist.destroy_process_group()
 
 

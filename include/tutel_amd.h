@@ -272,6 +272,17 @@ int tutel_amd_ep_ipc_status(tutel_amd_ep_comm_t *comm);
  * caller (there are no credits). */
 int tutel_amd_ep_ipc_exchange(tutel_amd_ep_comm_t *comm, tutel_amd_ep_segment_t *seg, const void *send, size_t bytes_per_peer,
                               size_t recv_off, tutel_stream_t stream);
+/* Payload-sized self-check of the transport, device-paced (no host synchronisation between its passes).  Every pass: a writer
+ * kernel stores a tagged pattern of bytes_per_peer bytes into block <my rank> of every rank's `seg` (flavour 0 = plain stores,
+ * what the pipeline uses; 1 = sc1, 2 = sc0 sc1 write-through, 3 = non-temporal: for probing), signal, wait (+ epoch canaries), a
+ * reader kernel compares every 16-byte vector of this rank's `world` blocks and counts mismatches, then an acknowledgement in the
+ * other direction lets the peers overwrite the blocks in the next pass.  side_stream != 0: wait + reader run on a side stream
+ * of the communicator, as the stage GEMMs of the overlapped pipeline do.  mismatch: DEVICE array of two uint64 -- [0] vectors
+ * that differed over all passes, [1] the first offender (source rank << 40 | vector index; all ones = none); read it after
+ * synchronising `stream`.  Collective: every rank calls it with the same arguments.  Replaces nothing in the reference (its
+ * exchange is NCCL's); it is the evidence the peer-store transport asks for before it is trusted on a node. */
+int tutel_amd_ep_ipc_selfcheck(tutel_amd_ep_comm_t *comm, tutel_amd_ep_segment_t *seg, size_t bytes_per_peer, int passes, int flavour,
+                               int side_stream, unsigned long long *mismatch, tutel_stream_t stream);
 
 /* all_to_all_single with equal splits (simple_all_to_all, communicate.py:181-192): block r of `send`
  * (bytes_per_peer bytes) goes to rank r and lands as block <my rank> of its `recv`; enqueued on `stream`. */
@@ -407,7 +418,7 @@ int tutel_amd_marks_report(double *delta_us, int n);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG / TUTEL_AMD_DECODE /
- * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS seed it once), >= 0 = force.  Every choice computes bit-identical results.
+ * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS / TUTEL_AMD_EP_CANARY seed it once), >= 0 = force.  Every choice computes bit-identical results (TUTEL_OPT_EP_CANARY = 2 excepted: it provokes the error it tests).
  *   TUTEL_OPT_GEMM_IMPL  kernels of the <= 128-rows-per-expert regime: 0 register-staged 128 x 128, 1 LDS-DMA 128 x 128, 4 the
  *                        128 x 256 tile on a three-slot LDS-DMA ring (k-major weights; automatic when its grid covers the chip)
  *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
@@ -421,14 +432,19 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *   TUTEL_OPT_GEMM_PERSIST  256 x 256 ping-pong kernel, bias operand: 0 = fetched after the K loop, 1 / automatic = before it
  *                        (32 more live registers, its L2 round trip hidden behind the loop)
  *   TUTEL_OPT_EP_STREAMS overlapped pipeline: 1 = every stage's GEMMs on ONE side stream, 2 / automatic = stages alternate between
- *                        two side streams (the half-chip GEMM grids of two stages run side by side) */
+ *                        two side streams (the half-chip GEMM grids of two stages run side by side)
+ *   TUTEL_OPT_EP_CANARY  IPC transport: epoch canaries behind every exchanged block (1 / automatic = written by the producers and
+ *                        checked by the wait kernels; 0 = off; 2 = TEST INJECTION: this rank publishes the previous epoch, as if
+ *                        its rows had not landed when its flag did -- the peers must report it)
+ */
 #define TUTEL_OPT_GEMM_IMPL 0
 #define TUTEL_OPT_GEMM_TILE 1
 #define TUTEL_OPT_DECODE 2
 #define TUTEL_OPT_EP_STAGE_GRID 3
 #define TUTEL_OPT_GEMM_PERSIST 4
 #define TUTEL_OPT_EP_STREAMS 5
-#define TUTEL_OPT_COUNT 6
+#define TUTEL_OPT_EP_CANARY 6
+#define TUTEL_OPT_COUNT 7
 int tutel_amd_set_option(int key, int value);
 
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------

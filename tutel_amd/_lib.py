@@ -14,7 +14,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
-OPT_GEMM_IMPL, OPT_GEMM_TILE, OPT_DECODE, OPT_EP_STAGE_GRID, OPT_GEMM_PERSIST, OPT_EP_STREAMS = 0, 1, 2, 3, 4, 5
+OPT_GEMM_IMPL, OPT_GEMM_TILE, OPT_DECODE, OPT_EP_STAGE_GRID, OPT_GEMM_PERSIST, OPT_EP_STREAMS, OPT_EP_CANARY = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -90,6 +90,7 @@ SIGNATURES.update({
     "tutel_amd_ep_ipc_set_timeout": (_i, [_vp, _i]),
     "tutel_amd_ep_ipc_status": (_i, [_vp]),
     "tutel_amd_ep_ipc_exchange": (_i, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    "tutel_amd_ep_ipc_selfcheck": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _vp]),
     "tutel_amd_mark": (_i, [_vp]),
     "tutel_amd_marks_reserve": (_i, [_i]),
     "tutel_amd_marks_report": (_i, [ctypes.POINTER(ctypes.c_double), _i]),

@@ -33,11 +33,25 @@ struct StageScope {
 
 // ---- internal entry points shared between translation units (not part of the C ABI) -----------------------------------
 // peer stores of the IPC transport (ep.hip): tab[w] = base address, in this process, of rank w's exchange segment
+// In-band epoch canaries (round 5): EP_NCAN 32-bit words per (direction, stage, source rank) at the end of every exchange
+// segment.  The LAST blocks of a producing kernel store the epoch the following signal kernel will publish into the canary words
+// of every destination rank -- after their row stores, through the same store path -- and the wait kernel, once the flag has
+// arrived, reads them back with system-scope loads: a flag that overtook the rows of its own kernel (the failure the peer-store
+// protocol must never show, and the one a one-GPU lease cannot provoke) leaves canaries of the previous epoch behind and is
+// reported instead of being consumed silently.
+#define EP_NCAN 16
+struct PeerCanary {
+  const uint32_t *epoch;  // device: epochs signalled so far for this (direction, stage); the producer publishes *epoch + 1 (nullptr: off)
+  long long off;          // byte offset, inside every rank's segment, of THIS producer's EP_NCAN words for that (direction, stage)
+  int world;              // destination ranks
+  int stale;              // test injection (TUTEL_OPT_EP_INJECT): publish the OLD epoch, as if the stores had not landed
+};
 struct EncodePeer {
   const uint64_t *tab;  // device array of `world` segment bases (nullptr: plain local output)
   long long off;        // byte offset of the receive array inside every rank's segment
   int rank, rows;       // my rank; bucket rows per (stage, destination rank) block
   int slot0;            // first bucket row of this launch (stages are encoded by separate launches)
+  PeerCanary can;
 };
 int tutel_encode_launch(const void *x, int dtype, const int32_t *slot_map, const void *gates, int gate_dtype, int T, int M,
                         int n_slots, int capacity, int num_experts, int chunk_rows, int expert_slice, int ep_world, void *out,
@@ -47,7 +61,7 @@ int tutel_encode_launch(const void *x, int dtype, const int32_t *slot_map, const
 int tutel_expert_gemm_peer(const void *A, int64_t a_stride_e, int64_t a_stride_w, int a_rows_per_w, int lda, const void *W,
                            int w_kmajor, int64_t w_stride_e, int ldw, const void *bias, int64_t bias_stride_e,
                            const uint64_t *d_peer, int64_t d_peer_off, int64_t d_stride_e, int d_rows_per_w, int ldd, int E_loc,
-                           int R, int N, int K, int dtype, int act, hipStream_t st);
+                           int R, int N, int K, int dtype, int act, const PeerCanary &can, hipStream_t st);
 
 #define TUTEL_REQUIRE(cond, ...)           \
   do {                                     \
@@ -195,4 +209,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// ---- epoch canaries of the IPC transport (see PeerCanary) --------------------------------------------------------------
+// Called by EVERY thread of EVERY block (1-D grid) as the last thing a producing kernel does.  The last min(grid, EP_NCAN)
+// blocks -- dispatched last, finishing last -- publish: after a block-wide barrier (every wave of the block has issued its
+// row stores), thread (w, j) stores the epoch into word j of rank w's canary words when j is this block's share.
+__device__ __forceinline__ void peer_canary_store(const uint64_t *tab, const PeerCanary &c) {
+  if (c.epoch == nullptr) return;
+  const int nb = (int)gridDim.x, nlast = nb < EP_NCAN ? nb : EP_NCAN, back = nb - 1 - (int)blockIdx.x;
+  if (back >= nlast) return;  // block-uniform
+  __syncthreads();
+  const int t = (int)threadIdx.x;
+  if (t >= c.world * EP_NCAN) return;
+  const int w = t / EP_NCAN, j = t % EP_NCAN;
+  if (j % nlast != back) return;
+  const uint32_t e = *c.epoch + (c.stale ? 0u : 1u);
+  reinterpret_cast<uint32_t *>(tab[w] + c.off)[j] = e;
 }

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
       }
     }
   }
+  if (peer.tab != nullptr) peer_canary_store(peer.tab, peer.can);  // IPC transport: epoch canaries behind the rows (common.h)
 }
 
 // -------------------------------------------------------------------------------------------
@@ -366,7 +367,7 @@ extern "C" int tutel_amd_fast_encode(const void *x, int dtype, const int32_t *sl
   if (chunk_rows > 0 || expert_slice > 0)
     TUTEL_REQUIRE((long long)num_experts * capacity == n_slots,
                   "tutel_amd_fast_encode: a bucket order needs n_slots == num_experts * capacity (got %d, %d x %d)", n_slots, num_experts, capacity);
-  EncodePeer none = {nullptr, 0, 0, 1, 0};
+  EncodePeer none = {nullptr, 0, 0, 1, 0, {nullptr, 0, 0, 0}};
   return tutel_encode_launch(x, dtype, slot_map, gates, gate_dtype, T, M, n_slots, capacity, num_experts, chunk_rows, expert_slice,
                              ep_world, out, none, (hipStream_t)stream);
 }

@@ -129,8 +129,9 @@ struct tutel_amd_ep_comm {
 
   // IPC transport (tutel_amd_ep_comm_attach_ipc): flag words in every rank's flag segment, epoch counters, error word
   tutel_amd_ep_segment *flag_seg;  // [2 directions][EP_FLAG_SLOTS][EP_MAX_PEERS] uint32 per rank, peer-mapped
-  uint32_t *epochs;                // device: signalled[2][EP_FLAG_SLOTS] then expected[2][EP_FLAG_SLOTS]
-  int *err_host, *err_dev;         // pinned + mapped: a wait kernel that timed out leaves (1 + dir) << 16 | stage << 8 | peer here
+  uint32_t *epochs;                // device: signalled[2][EP_FLAG_SLOTS], expected[2][EP_FLAG_SLOTS], then ONE error word (see err_word)
+  int *err_host, *err_dev;         // pinned + mapped: a wait kernel that gave up leaves its error code here (ep_err_code)
+  unsigned selfcheck_seq;          // tutel_amd_ep_ipc_selfcheck: calls so far (tags the pattern)
   long long timeout_ticks;         // of the 100 MHz wall clock
 };
 
@@ -143,7 +144,13 @@ struct tutel_amd_ep_segment {
   int world, rank, device;
   void *peer[EP_MAX_PEERS];    // peer[rank] == local; the others come from hipIpcOpenMemHandle
   uint64_t *tab_dev;           // device copy of peer[]: what the peer-store kernels index by destination rank
+  size_t canary_off;           // data segments: byte offset of the epoch canaries behind the user bytes (0: none -- flag segments)
 };
+// epoch canaries (common.h: PeerCanary): uint32 [2 directions][EP_FLAG_SLOTS][EP_MAX_PEERS source ranks][EP_NCAN]
+#define EP_CANARY_WORDS (2 * EP_FLAG_SLOTS * EP_MAX_PEERS * EP_NCAN)
+static inline size_t canary_word(int dir, int slot, int src) { return ((size_t)(dir * EP_FLAG_SLOTS + slot) * EP_MAX_PEERS + src) * EP_NCAN; }
+// what a producer of this rank passes to its kernel for (dir, slot): nullptr epoch = canaries off
+static PeerCanary producer_canary(const tutel_amd_ep_comm *c, const tutel_amd_ep_segment *seg, int dir, int slot);
 
 static bool create_side_streams(tutel_amd_ep_comm *c) {
   int least = 0, greatest = 0;
@@ -401,7 +408,15 @@ extern "C" int tutel_amd_ep_segment_alloc(size_t bytes, int flag_memory, tutel_a
     // its own peer flags), fine-grained next, plain device memory last (the polls are system-scope loads either way)
     if (flag_memory) e = hipExtMallocWithFlags(&sg->local, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess && flag_memory) e = hipExtMallocWithFlags(&sg->local, bytes, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) e = hipMalloc(&sg->local, bytes);
+    if (e != hipSuccess && flag_memory) e = hipMalloc(&sg->local, bytes);
+    if (!flag_memory) {
+      // data segment: the epoch canaries live behind the user bytes, in the SAME allocation (same memory type, same mapping in
+      // every peer) -- they are only meaningful if they travel the way the rows do
+      sg->canary_off = (bytes + 255) / 256 * 256;
+      e = hipMalloc(&sg->local, sg->canary_off + (size_t)EP_CANARY_WORDS * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMemset((char *)sg->local + sg->canary_off, 0, (size_t)EP_CANARY_WORDS * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
   }
   if (e == hipSuccess && flag_memory) {
     e = hipMemset(sg->local, 0, bytes);
@@ -488,8 +503,8 @@ extern "C" int tutel_amd_ep_comm_attach_ipc(tutel_amd_ep_comm_t *c, tutel_amd_ep
   TUTEL_REQUIRE(c->flag_seg == nullptr, "tutel_amd_ep_comm_attach_ipc: the communicator has its flag segment already");
   TUTEL_REQUIRE(flags->tab_dev != nullptr && flags->world == c->world && flags->rank == c->rank && flags->bytes >= tutel_amd_ep_flag_bytes(),
                 "tutel_amd_ep_comm_attach_ipc: the flag segment must be opened for this communicator's %d ranks and hold %zu bytes", c->world, tutel_amd_ep_flag_bytes());
-  HIP_CHECK(hipMalloc((void **)&c->epochs, 4 * EP_FLAG_SLOTS * sizeof(uint32_t)), "hipMalloc");
-  HIP_CHECK(hipMemset(c->epochs, 0, 4 * EP_FLAG_SLOTS * sizeof(uint32_t)), "hipMemset");
+  HIP_CHECK(hipMalloc((void **)&c->epochs, (4 * EP_FLAG_SLOTS + 1) * sizeof(uint32_t)), "hipMalloc");
+  HIP_CHECK(hipMemset(c->epochs, 0, (4 * EP_FLAG_SLOTS + 1) * sizeof(uint32_t)), "hipMemset");
   HIP_CHECK(hipHostMalloc((void **)&c->err_host, sizeof(int), hipHostMallocMapped), "hipHostMalloc");
   *c->err_host = 0;
   HIP_CHECK(hipHostGetDevicePointer((void **)&c->err_dev, c->err_host, 0), "hipHostGetDevicePointer");
@@ -524,56 +539,105 @@ __global__ void ep_signal_kernel(const uint64_t *__restrict__ flag_tab, uint32_t
 
 // one workgroup, thread (i, w): wait until peer w has signalled this rank's next expected epoch of slot (dir, stage0 + i).
 // Every spin is bounded: after timeout_ticks the thread records which (dir, stage, peer) never arrived and gives up.
+// error codes left in the communicator's error words: which wait gave up, and why
+#define EP_ERR_STALE (1 << 24)  // the flag arrived, the epoch canaries of its producer had not: data behind the flag
+__device__ __host__ static inline int ep_err_code(int dir, int stage, int peer, int stale) {
+  return ((1 + dir) << 16) | (stage << 8) | peer | (stale ? EP_ERR_STALE : 0);
+}
+// Every spin is bounded: after timeout_ticks the thread records which (dir, stage, peer) never arrived and gives up.  `canary`
+// (optional): this rank's canary words -- once the flag of (stage, peer) is here, the EP_NCAN words its producer stored behind
+// its rows must carry the same epoch (system-scope loads: what is in memory, not what an L2 still holds).
 __global__ void ep_wait_kernel(const uint32_t *__restrict__ flags, uint32_t *__restrict__ epochs, int dir, int stage0, int nstages,
-                               int W, int *err, long long timeout_ticks) {
+                               int W, int *err, long long timeout_ticks, const uint32_t *__restrict__ canary) {
   const int t = threadIdx.x, i = t / W, w = t % W;
   const bool on = i < nstages;
   uint32_t *expect = epochs + 2 * EP_FLAG_SLOTS;
+  int *err_word = reinterpret_cast<int *>(epochs + 4 * EP_FLAG_SLOTS);  // device copy of the error: what ep_poison_kernel reads
   uint32_t e = 0;
   if (on) e = expect[dir * EP_FLAG_SLOTS + stage0 + i] + 1u;
   __syncthreads();
   if (!on) return;
   const uint32_t *f = flags + ((size_t)(dir * EP_FLAG_SLOTS + stage0 + i) * EP_MAX_PEERS + w);
   const long long t0 = wall_clock64();
+  int bad = 0;
   while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
     __builtin_amdgcn_s_sleep(20);
     if (wall_clock64() - t0 > timeout_ticks) {
-      __hip_atomic_store(err, ((1 + dir) << 16) | ((stage0 + i) << 8) | w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      bad = ep_err_code(dir, stage0 + i, w, 0);
       break;
     }
+  }
+  if (bad == 0 && canary != nullptr) {
+    const uint32_t *cw = canary + ((size_t)(dir * EP_FLAG_SLOTS + stage0 + i) * EP_MAX_PEERS + w) * EP_NCAN;
+    uint32_t diff = 0;
+#pragma unroll
+    for (int j = 0; j < EP_NCAN; ++j) diff |= __hip_atomic_load(cw + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ^ e;
+    if (diff != 0) bad = ep_err_code(dir, stage0 + i, w, 1);
+  }
+  if (bad != 0) {
+    __hip_atomic_store(err, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err_word, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __threadfence_system();
   if (w == 0) expect[dir * EP_FLAG_SLOTS + stage0 + i] = e;
 }
 
+// The result of a forward whose exchange gave up (a peer never arrived, or its rows were behind its flag) is not a result: one
+// workgroup after fast_decode turns it into NaNs, so that no caller can consume it as one (the call itself has long
+// returned 0, and under HIP-graph replay there is no call).  Costs one load when nothing is wrong.
+__global__ __launch_bounds__(1024) void ep_poison_kernel(const uint32_t *__restrict__ epochs, uint32_t *__restrict__ y, size_t n32) {
+  const int err = *reinterpret_cast<const int *>(epochs + 4 * EP_FLAG_SLOTS);
+  if (err == 0) return;
+  for (size_t i = threadIdx.x; i < n32; i += 1024) y[i] = 0x7fc07fc0u;  // NaN as bf16 and as fp16 pairs
+}
+
 static int ipc_check(tutel_amd_ep_comm *c, const char *what) {
   TUTEL_REQUIRE(c != nullptr && c->flag_seg != nullptr, "%s: the communicator has no IPC transport (tutel_amd_ep_comm_attach_ipc)", what);
   const int err = *(volatile int *)c->err_host;
-  TUTEL_REQUIRE(err == 0, "%s: an earlier exchange timed out waiting for rank %d (%s, stage %d): a peer died or the ranks disagree about the call sequence",
+  TUTEL_REQUIRE((err & EP_ERR_STALE) == 0,
+                "%s: an earlier exchange saw rank %d's flag BEFORE the rows it announces (%s, stage %d: epoch canaries behind the flag) -- the peer-store "
+                "transport is not safe on this system, its outputs since then are poisoned (NaN); use TUTEL_AMD_EP_TRANSPORT=rccl",
+                what, err & 0xff, ((err >> 16) & 0xff) == 1 ? "dispatch" : "combine", (err >> 8) & 0xff);
+  TUTEL_REQUIRE(err == 0, "%s: an earlier exchange timed out waiting for rank %d (%s, stage %d): a peer died or the ranks disagree about the call sequence; "
+                "the outputs of the forwards since then are poisoned (NaN)",
                 what, err & 0xff, (err >> 16) == 1 ? "dispatch" : "combine", (err >> 8) & 0xff);
   return 0;
+}
+static PeerCanary producer_canary(const tutel_amd_ep_comm *c, const tutel_amd_ep_segment *seg, int dir, int slot) {
+  PeerCanary pc = {nullptr, 0, 0, 0};
+  if (c == nullptr || seg == nullptr || seg->canary_off == 0 || c->epochs == nullptr || tutel_get_option(TUTEL_OPT_EP_CANARY) == 0) return pc;
+  pc.epoch = c->epochs + dir * EP_FLAG_SLOTS + slot;
+  pc.off = (long long)(seg->canary_off + canary_word(dir, slot, c->rank) * sizeof(uint32_t));
+  pc.world = c->world;
+  pc.stale = tutel_get_option(TUTEL_OPT_EP_CANARY) == 2;  // test injection: every canary of this rank stays one epoch behind
+  return pc;
 }
 static int ipc_signal(tutel_amd_ep_comm *c, int dir, int stage0, int nstages, hipStream_t st) {
   hipLaunchKernelGGL(ep_signal_kernel, dim3(1), dim3(nstages * c->world), 0, st, c->flag_seg->tab_dev, c->epochs, dir, stage0, nstages, c->world, c->rank);
   TUTEL_CHECK_LAUNCH("tutel_amd_ep (signal)");
   return 0;
 }
-static int ipc_wait(tutel_amd_ep_comm *c, int dir, int stage0, int nstages, hipStream_t st) {
+// `seg`: the data segment the awaited producers stored into (its canaries are checked once the flags are here); nullptr: flags only
+static int ipc_wait(tutel_amd_ep_comm *c, int dir, int stage0, int nstages, hipStream_t st, const tutel_amd_ep_segment *seg = nullptr) {
+  const uint32_t *canary = nullptr;
+  if (seg != nullptr && seg->canary_off != 0 && tutel_get_option(TUTEL_OPT_EP_CANARY) != 0)
+    canary = reinterpret_cast<const uint32_t *>((const char *)seg->local + seg->canary_off);
   hipLaunchKernelGGL(ep_wait_kernel, dim3(1), dim3(nstages * c->world), 0, st, (const uint32_t *)c->flag_seg->local, c->epochs, dir, stage0, nstages,
-                     c->world, c->err_dev, c->timeout_ticks);
+                     c->world, c->err_dev, c->timeout_ticks, canary);
   TUTEL_CHECK_LAUNCH("tutel_amd_ep (wait)");
   return 0;
 }
 
 // block r of `send` (bytes_per_peer bytes, 16-byte granules) -> rank r's segment at recv_off + <my rank> * bytes_per_peer
 __global__ __launch_bounds__(256) void ep_peer_copy_kernel(const uint4 *__restrict__ send, const uint64_t *__restrict__ tab, long long recv_off,
-                                                          size_t vec_per_peer, int W, int rank) {
+                                                          size_t vec_per_peer, int W, int rank, PeerCanary can) {
   const size_t n = vec_per_peer * (size_t)W;
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
     const int w = (int)(v / vec_per_peer);
     const size_t o = v % vec_per_peer;
     reinterpret_cast<uint4 *>(tab[w] + recv_off)[(size_t)rank * vec_per_peer + o] = send[v];
   }
+  peer_canary_store(tab, can);
 }
 
 // all_to_all_single with equal splits over the IPC transport: `send` is any device buffer of this rank, the result lands at
@@ -592,15 +656,116 @@ extern "C" int tutel_amd_ep_ipc_exchange(tutel_amd_ep_comm_t *c, tutel_amd_ep_se
     TUTEL_REQUIRE(send != nullptr, "tutel_amd_ep_ipc_exchange: null send buffer");
     const size_t vpp = bytes_per_peer / 16, n = vpp * (size_t)c->world;
     const int grid = (int)(n / 256 + 1 > 2048 ? 2048 : n / 256 + 1);
-    hipLaunchKernelGGL(ep_peer_copy_kernel, dim3(grid), dim3(256), 0, st, (const uint4 *)send, seg->tab_dev, (long long)recv_off, vpp, c->world, c->rank);
+    hipLaunchKernelGGL(ep_peer_copy_kernel, dim3(grid), dim3(256), 0, st, (const uint4 *)send, seg->tab_dev, (long long)recv_off, vpp, c->world, c->rank,
+                       producer_canary(c, seg, 0, EP_MAX_SPLIT));
     TUTEL_CHECK_LAUNCH("tutel_amd_ep_ipc_exchange");
   }
   int rc = ipc_signal(c, 0, EP_MAX_SPLIT, 1, st);
   if (rc) return rc;
-  return ipc_wait(c, 0, EP_MAX_SPLIT, 1, st);
+  return ipc_wait(c, 0, EP_MAX_SPLIT, 1, st, bytes_per_peer > 0 ? seg : nullptr);
 }
 
 extern "C" int tutel_amd_ep_ipc_status(tutel_amd_ep_comm_t *c) { return ipc_check(c, "tutel_amd_ep_ipc_status"); }
+
+// ---- payload-sized self-check of the transport (VERDICT r4 / ADVICE r4) --------------------------------------------------------
+// What the 4 KB tagged exchange of round 4 could not show: ordering behind a kernel's worth of dirty lines.  Every pass a WRITER
+// kernel (grid of 1024 workgroups, 16-byte stores, the store flavour under test) fills block <my rank> of every rank's segment with
+// a pattern that names (call, pass, source, destination, position); the signal kernel follows it on the same stream; the wait kernel
+// and a READER kernel (plain loads, every vector compared, mismatches counted on the device) follow on the consuming stream -- the
+// caller's, or a side stream of the communicator as in the overlapped pipeline -- and an acknowledgement in the other direction
+// keeps pass n + 1 from overwriting what a peer is still reading.  No host synchronisation between the passes: the reader of pass
+// n has just pulled every line of the segment into its caches when pass n + 1 overwrites them from the other side.
+// flavour: 0 plain stores (what the pipeline uses), 1 `sc1`, 2 `sc0 sc1` (system-scope write-through), 3 non-temporal.
+template <int FLAVOUR> __device__ __forceinline__ void store16(uint4 *p, uint4 v) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  const u32x4_t x = {v.x, v.y, v.z, v.w};
+  if (FLAVOUR == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+  else if (FLAVOUR == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+  else if (FLAVOUR == 3) __builtin_nontemporal_store(x, reinterpret_cast<u32x4_t *>(p));
+  else *p = v;
+}
+__device__ __forceinline__ uint4 check_pattern(uint32_t tag, int src, int dst, size_t o) {
+  const uint32_t lo = (uint32_t)o;
+  return make_uint4(tag, ((uint32_t)src << 16) | (uint32_t)dst, lo, lo * 2654435761u + tag);
+}
+template <int FLAVOUR>
+__global__ __launch_bounds__(256) void ep_check_write_kernel(const uint64_t *__restrict__ tab, long long off, size_t vec_per_peer, int W, int rank,
+                                                            uint32_t tag, PeerCanary can) {
+  const size_t n = vec_per_peer * (size_t)W;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
+    const int w = (int)(v / vec_per_peer);
+    const size_t o = v % vec_per_peer;
+    store16<FLAVOUR>(reinterpret_cast<uint4 *>(tab[w] + off) + (size_t)rank * vec_per_peer + o, check_pattern(tag, rank, w, o));
+  }
+  if (FLAVOUR != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  peer_canary_store(tab, can);
+}
+// out[0] = vectors that differ, out[1] = (first) offending position: source rank << 40 | vector index
+__global__ __launch_bounds__(256) void ep_check_read_kernel(const uint4 *__restrict__ local, size_t vec_per_peer, int W, int rank, uint32_t tag,
+                                                           unsigned long long *__restrict__ out) {
+  const size_t n = vec_per_peer * (size_t)W;
+  unsigned long long bad = 0, first = ~0ull;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
+    const int w = (int)(v / vec_per_peer);
+    const size_t o = v % vec_per_peer;
+    const uint4 got = local[v], want = check_pattern(tag, w, rank, o);
+    if (got.x != want.x || got.y != want.y || got.z != want.z || got.w != want.w) {
+      ++bad;
+      if (first == ~0ull) first = ((unsigned long long)w << 40) | (unsigned long long)o;
+    }
+  }
+  if (bad) {
+    atomicAdd(out, bad);
+    atomicMin(out + 1, first);
+  }
+}
+
+extern "C" int tutel_amd_ep_ipc_selfcheck(tutel_amd_ep_comm_t *c, tutel_amd_ep_segment_t *seg, size_t bytes_per_peer, int passes, int flavour,
+                                          int side_stream, unsigned long long *mismatch, tutel_stream_t stream) {
+  if (ipc_check(c, "tutel_amd_ep_ipc_selfcheck") != 0) return -1;
+  TUTEL_REQUIRE(seg != nullptr && seg->tab_dev != nullptr && seg->world == c->world && seg->rank == c->rank, "tutel_amd_ep_ipc_selfcheck: the segment is not open for this communicator");
+  TUTEL_REQUIRE(bytes_per_peer >= 16 && bytes_per_peer % 16 == 0 && bytes_per_peer * (size_t)c->world <= seg->bytes, "tutel_amd_ep_ipc_selfcheck: %zu bytes per peer do not fit the segment", bytes_per_peer);
+  TUTEL_REQUIRE(passes >= 1 && passes <= 255 && flavour >= 0 && flavour <= 3 && mismatch != nullptr, "tutel_amd_ep_ipc_selfcheck: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipStream_t kss[2] = {st, st};
+  if (side_stream) side_streams_for(c, st, kss);
+  hipStream_t rd = kss[0];  // the consuming stream
+  const size_t vpp = bytes_per_peer / 16, n = vpp * (size_t)c->world;
+  const int grid = (int)(n / 256 + 1 > 1024 ? 1024 : n / 256 + 1);
+  const unsigned seq = ++c->selfcheck_seq;
+  const int slot = EP_MAX_SPLIT;
+  HIP_CHECK(hipMemsetAsync(mismatch, 0, sizeof(unsigned long long), st), "hipMemsetAsync");
+  HIP_CHECK(hipMemsetAsync(mismatch + 1, 0xff, sizeof(unsigned long long), st), "hipMemsetAsync");
+  int rc = 0;
+  for (int p = 0; p < passes && rc == 0; ++p) {
+    const uint32_t tag = (seq << 8) | (uint32_t)p;
+    // pass p may overwrite the peers' blocks only when every peer has read pass p - 1 (their acknowledgements)
+    if (p > 0 && (rc = ipc_wait(c, 1, slot, 1, st)) != 0) break;
+    const PeerCanary can = producer_canary(c, seg, 0, slot);
+    switch (flavour) {
+      case 1: hipLaunchKernelGGL(ep_check_write_kernel<1>, dim3(grid), dim3(256), 0, st, seg->tab_dev, 0LL, vpp, c->world, c->rank, tag, can); break;
+      case 2: hipLaunchKernelGGL(ep_check_write_kernel<2>, dim3(grid), dim3(256), 0, st, seg->tab_dev, 0LL, vpp, c->world, c->rank, tag, can); break;
+      case 3: hipLaunchKernelGGL(ep_check_write_kernel<3>, dim3(grid), dim3(256), 0, st, seg->tab_dev, 0LL, vpp, c->world, c->rank, tag, can); break;
+      default: hipLaunchKernelGGL(ep_check_write_kernel<0>, dim3(grid), dim3(256), 0, st, seg->tab_dev, 0LL, vpp, c->world, c->rank, tag, can);
+    }
+    TUTEL_CHECK_LAUNCH("tutel_amd_ep_ipc_selfcheck (write)");
+    if ((rc = ipc_signal(c, 0, slot, 1, st)) != 0) break;
+    if (rd != st) {
+      HIP_CHECK(hipEventRecord(c->recv_ev[0], st), "hipEventRecord");
+      HIP_CHECK(hipStreamWaitEvent(rd, c->recv_ev[0], 0), "hipStreamWaitEvent");
+    }
+    if ((rc = ipc_wait(c, 0, slot, 1, rd, seg)) != 0) break;
+    hipLaunchKernelGGL(ep_check_read_kernel, dim3(grid), dim3(256), 0, rd, (const uint4 *)seg->local, vpp, c->world, c->rank, tag, mismatch);
+    TUTEL_CHECK_LAUNCH("tutel_amd_ep_ipc_selfcheck (read)");
+    if ((rc = ipc_signal(c, 1, slot, 1, rd)) != 0) break;
+    if (rd != st) {
+      HIP_CHECK(hipEventRecord(c->done_ev[0], rd), "hipEventRecord");
+      HIP_CHECK(hipStreamWaitEvent(st, c->done_ev[0], 0), "hipStreamWaitEvent");
+    }
+  }
+  if (rc == 0) rc = ipc_wait(c, 1, slot, 1, st);  // the acknowledgements of the last pass: every signal has its wait
+  return rc;
+}
 
 // ---- stage layouts (== tutel_amd/impls/overlap.py::OverlapPlan) ------------------------------------------------
 extern "C" int tutel_amd_ep_plan(int E, int W, int capacity, int degree, int allow_sliced, tutel_amd_ep_plan_t *out) {
@@ -712,7 +877,7 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     if (ipc)  // rows of source rank w go straight to block <my rank> of stage i of rank w's return array
       return tutel_expert_gemm_peer(hid_i, (int64_t)R * H, 0, R, H, w2, a->w2_kmajor, (int64_t)H * Mo, a->w2_kmajor ? H : Mo, b2, Mo, seg->tab_dev,
                                     back_off + (long long)(((size_t)i * W + c->rank) * rows * Mo * es), (int64_t)cc * Mo, cc, Mo, s, R, Mo, H, a->dtype,
-                                    TUTEL_ACT_NONE, st);
+                                    TUTEL_ACT_NONE, producer_canary(c, seg, 1, i), st);
     char *send_i = (char *)a->send + (size_t)i * msg_out;
     return tutel_amd_expert_gemm(hid_i, (int64_t)R * H, 0, R, H, w2, a->w2_kmajor, (int64_t)H * Mo, a->w2_kmajor ? H : Mo, b2, Mo, send_i,
                                  (int64_t)cc * Mo, (int64_t)rows * Mo, cc, Mo, s, R, Mo, H, a->dtype, TUTEL_ACT_NONE, nullptr, 1, st);
@@ -720,7 +885,7 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
   // stage i's bucket rows: plain launch into `enc`, or (IPC) peer stores into the owners' receive arrays
   auto encode_stage = [&](int i, int nst) -> int {
     Range r("tutel_amd.fast_encode");
-    EncodePeer pe = {ipc ? seg->tab_dev : nullptr, recv_off, ipc ? c->rank : 0, rows, i * W * rows};
+    EncodePeer pe = {ipc ? seg->tab_dev : nullptr, recv_off, ipc ? c->rank : 0, rows, i * W * rows, producer_canary(ipc ? c : nullptr, seg, 0, i)};
     return tutel_encode_launch(a->x, a->dtype, a->slot_map, enc_gates, a->gate_dtype, T, M, (i + nst) * W * rows, C, E, chunk_rows, expert_slice, W,
                                ipc ? nullptr : a->enc, pe, cur);
   };
@@ -752,7 +917,7 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
       if (rc) return rc;
       {
         StageScope sc(TUTEL_STAGE_A2A_DISPATCH, cur);
-        if ((rc = ipc_signal(c, 0, 0, 1, cur)) != 0 || (rc = ipc_wait(c, 0, 0, 1, cur)) != 0) return rc;
+        if ((rc = ipc_signal(c, 0, 0, 1, cur)) != 0 || (rc = ipc_wait(c, 0, 0, 1, cur, seg)) != 0) return rc;
       }
       rc = stage_gemms(0, cur);
       if (rc) return rc;
@@ -774,7 +939,7 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
         guard.fork(i & 1, ks, c->done_ev[i]);
         {
           StageScope sc(TUTEL_STAGE_A2A_DISPATCH, ks);
-          if ((rc = ipc_wait(c, 0, i, 1, ks)) != 0) return rc;
+          if ((rc = ipc_wait(c, 0, i, 1, ks, seg)) != 0) return rc;
         }
         // two stages run side by side on the two side streams: a stage GEMM whose full grid would be one workgroup per CU takes
         // the half-chip 256 x 256 grid instead (launch_gemm, expert_gemm.hip), so that fc1 / fc2 of stage i overlap those of stage
@@ -795,10 +960,16 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
     }
     {
       StageScope sc(TUTEL_STAGE_A2A_COMBINE, cur);
-      if ((rc = ipc_wait(c, 1, 0, degree, cur)) != 0) return rc;
+      if ((rc = ipc_wait(c, 1, 0, degree, cur, seg)) != 0) return rc;
     }
     Range r("tutel_amd.fast_decode");
-    return tutel_amd_fast_decode(a->back, a->dtype, a->idx, a->loc, dec_gates, a->gate_dtype, T, Mo, k, C, E, chunk_rows, expert_slice, W, a->y, cur);
+    rc = tutel_amd_fast_decode(a->back, a->dtype, a->idx, a->loc, dec_gates, a->gate_dtype, T, Mo, k, C, E, chunk_rows, expert_slice, W, a->y, cur);
+    if (rc != 0 || T == 0) return rc;
+    // a forward whose exchange gave up must not hand out rows that never arrived: NaNs instead (one load when all is well)
+    StageScope sc(TUTEL_STAGE_DECODE, cur);
+    hipLaunchKernelGGL(ep_poison_kernel, dim3(1), dim3(1024), 0, cur, (const uint32_t *)c->epochs, (uint32_t *)a->y, (size_t)T * Mo * es / 4);
+    TUTEL_CHECK_LAUNCH("tutel_amd_ep_forward (poison)");
+    return 0;
   }
 
   rc = encode_stage(0, degree);

@@ -31,6 +31,8 @@
 // for a given output element, so the choice never changes a bit of the result.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 #define GM_BM 128
@@ -96,6 +98,7 @@ struct GemmArgs {
   bool rot_on;                                                // K-tile rotation (see launch_gemm)
   const void *mul;                                            // optional epilogue multiplier, D's layout
   const uint64_t *d_peer; long long d_peer_off;               // optional: rows of source rank w go to d_peer[w] + d_peer_off (bytes)
+  PeerCanary d_can;                                           // peer stores: epoch canaries written behind the rows (common.h)
   int ntm, ntn;
 };
 
@@ -169,6 +172,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, f32x16 (&acc)[N
       }
     }
   }
+  if (p.d_peer != nullptr) peer_canary_store(p.d_peer, p.d_can);
 }
 
 // fused fast_encode: the slot-map entries of the lane's 4 token-tile pieces (rows gr[0..3] of expert e), fetched TOGETHER.  Written
@@ -652,6 +656,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&ac
       *reinterpret_cast<u32x4 *>(drow + n) = val;
     }
   }
+  if (p.d_peer != nullptr) peer_canary_store(p.d_peer, p.d_can);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1198,6 +1203,9 @@ static bool lds_optin(const void *kern, size_t lds) {
   static const void *seen[MAXK];
   static uint64_t done[MAXK];  // bit d: device d has the attribute
   static int n = 0;
+  // launches may come from several host threads (one per device is common): the table is shared
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXD) dev = -1;
   int i = 0;
@@ -1372,7 +1380,7 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
                                      const int32_t *row_counts, int row_align,
                                      const int32_t *a_rows, int a_rows_mod, const void *a_zero,
                                      const void *mul, tutel_stream_t stream, const uint64_t *d_peer = nullptr,
-                                     int64_t d_peer_off = 0) {
+                                     int64_t d_peer_off = 0, const PeerCanary *d_can = nullptr) {
   TUTEL_REQUIRE(dtype == TUTEL_BF16 || dtype == TUTEL_F16, "tutel_amd_expert_gemm: dtype must be bf16 or fp16 (got %d)", dtype);
   TUTEL_REQUIRE(E_loc >= 0 && R >= 0 && N >= 1 && K >= 1, "tutel_amd_expert_gemm: bad sizes E_loc=%d R=%d N=%d K=%d", E_loc, R, N, K);
   TUTEL_REQUIRE(K % 64 == 0, "tutel_amd_expert_gemm: K=%d must be a multiple of 64", K);
@@ -1417,6 +1425,7 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   a.rot_on = R < GB_BM;
   a.mul = mul;
   a.d_peer = d_peer; a.d_peer_off = d_peer_off;
+  a.d_can = d_can != nullptr ? *d_can : PeerCanary{nullptr, 0, 0, 0};
   TUTEL_REQUIRE(((uintptr_t)mul % 8) == 0, "tutel_amd_expert_gemm_glu: gating operand must be 8-byte aligned");
   TUTEL_REQUIRE(a_rows == nullptr || (a_rows_mod >= 1 && a_zero != nullptr && ((uintptr_t)a_zero % 16) == 0),
                 "tutel_amd_expert_gemm_gather: need a_rows_mod >= 1 and a 16-byte aligned zero row");
@@ -1450,11 +1459,11 @@ extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t 
 int tutel_expert_gemm_peer(const void *A, int64_t a_stride_e, int64_t a_stride_w, int a_rows_per_w, int lda, const void *W,
                            int w_kmajor, int64_t w_stride_e, int ldw, const void *bias, int64_t bias_stride_e,
                            const uint64_t *d_peer, int64_t d_peer_off, int64_t d_stride_e, int d_rows_per_w, int ldd, int E_loc,
-                           int R, int N, int K, int dtype, int act, hipStream_t st) {
+                           int R, int N, int K, int dtype, int act, const PeerCanary &can, hipStream_t st) {
   TUTEL_REQUIRE(d_peer != nullptr, "tutel_expert_gemm_peer: null peer table");
   return expert_gemm_impl(A, a_stride_e, a_stride_w, a_rows_per_w, lda, W, w_kmajor, w_stride_e, ldw, bias, bias_stride_e, nullptr,
                           d_stride_e, 0, d_rows_per_w, ldd, E_loc, R, N, K, dtype, act, nullptr, 1, nullptr, 0, nullptr, nullptr,
-                          (tutel_stream_t)st, d_peer, d_peer_off);
+                          (tutel_stream_t)st, d_peer, d_peer_off, &can);
 }
 
 extern "C" int tutel_amd_expert_gemm_glu(const void *A, int64_t a_stride_e, int64_t a_stride_w,

@@ -155,12 +155,52 @@ def _open_segment(comm, nbytes, flag_memory):
     return Segment(handle, int(nbytes))
 
 
+def _node_identity():
+    """64 bytes that are equal for processes of one node and (practically) nowhere else: the kernel's boot id, else the hostname"""
+    import hashlib
+    import socket
+    try:
+        ident = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        ident = ""
+    return hashlib.sha512((ident + "|" + socket.gethostname()).encode()).digest()
+
+
+# the payload-sized self-check: per-peer block = SELFCHECK_MB / world MiB (clamped to [1, 32] MiB) -- 64 MiB in all, twice the 32 MiB of
+# L2 a producer's dirty lines can hide in; SELFCHECK_PASSES passes back to back, once consuming on the caller's stream and once on a
+# side stream of the communicator (the two stream layouts of the pipeline: degree 1 and degree > 1)
+SELFCHECK_MB = int(os.environ.get("TUTEL_AMD_EP_SELFCHECK_MB", "64"))
+SELFCHECK_PASSES = int(os.environ.get("TUTEL_AMD_EP_SELFCHECK_PASSES", "4"))
+
+
+def ipc_selfcheck(comm, seg, bytes_per_peer, passes=4, flavour=0, side_stream=False):
+    """tutel_amd_ep_ipc_selfcheck on the current stream; returns (vectors that differed, first offender) after synchronising.
+    Collective over the communicator's ranks."""
+    L = _lib.lib()
+    out = torch.zeros([2], dtype=torch.int64, device=comm.device)
+    with torch.cuda.device(comm.device):
+        _lib.check(L.tutel_amd_ep_ipc_selfcheck(comm.handle, seg.handle, int(bytes_per_peer), int(passes), int(flavour), int(bool(side_stream)),
+                                                out.data_ptr(), ops._stream()), "tutel_amd_ep_ipc_selfcheck")
+        torch.cuda.synchronize(comm.device)
+        _lib.check(L.tutel_amd_ep_ipc_status(comm.handle), "tutel_amd_ep_ipc_status")
+    bad, first = (int(v) for v in out.cpu())
+    return bad, first
+
+
 def _attach_ipc(comm, group, device):
-    """give `comm` the IPC transport (collective).  True when every rank attached it and the tagged exchange delivered the right
-    blocks everywhere; False (on every rank) otherwise -- the communicator then keeps exchanging the way it did."""
+    """give `comm` the IPC transport (collective).  True when every rank attached it and the payload-sized self-check (real
+    kernels, real flags, epoch canaries, no host synchronisation between its passes) read back exactly what the peers stored, on
+    every rank; False (on every rank) otherwise -- the communicator then keeps exchanging the way it did.  Every early exit frees
+    what it opened and every decision is an agreement, so the ranks leave together."""
     L = _lib.lib()
     comm.group, comm.device = group, device
     if comm.world > 16:
+        return False
+    # one node only: hipIpcOpenMemHandle of a handle from another host must not even be attempted (ADVICE r4)
+    ids = _all_gather_bytes(_node_identity(), group, device)
+    if len(set(ids[i:i + 64] for i in range(0, len(ids), 64))) != 1:
+        if comm.rank == 0:
+            logging.info("tutel_amd: the ranks of this group are not on one node: no IPC transport")
         return False
     try:
         flags = _open_segment(comm, int(L.tutel_amd_ep_flag_bytes()), True)
@@ -169,41 +209,40 @@ def _attach_ipc(comm, group, device):
     with torch.cuda.device(device):
         ok = int(L.tutel_amd_ep_comm_attach_ipc(comm.handle, flags.handle, IPC_TIMEOUT_MS) == 0)
     if not _agree(ok, group, device):
+        # (a communicator that did attach keeps its pointer to the flag segment: it is never used again -- comm.ipc stays False --
+        # but the segment must outlive it, so it is parked on the communicator and freed with it)
+        comm._flags = flags
         return False
     comm._flags = flags
-    # self-check through the real kernels (peer stores, signal, wait), twice (the second pass exercises the epoch counters): block p
-    # of my send buffer carries (my rank, p, pass); afterwards block r must carry (r, my rank, pass).  Every pass ends in an
-    # agreement (which is also the barrier that keeps two exchanges into the same offset apart); the ranks are within
-    # milliseconds of each other here, so the waits of the check itself are bounded by 30 s, not by the watchdog-scale default.
-    n, W, rank = 1024, comm.world, comm.rank
+    W = comm.world
+    per_peer = max(1 << 20, min(32 << 20, (SELFCHECK_MB << 20) // W)) // 256 * 256
     try:
-        seg = _open_segment(comm, W * n * 4, False)
+        seg = _open_segment(comm, W * per_peer, False)
     except _lib.TutelAmdError:
         return False
-    comm._selfcheck = seg
+    # the ranks are within milliseconds of each other here, so the waits of the check itself are bounded by 30 s, not by the
+    # watchdog-scale default
     L.tutel_amd_ep_ipc_set_timeout(comm.handle, min(30000, IPC_TIMEOUT_MS))
-    for rep in range(2):
-        good = 1
+    good, report = 1, []
+    for side in (False, True):
         try:
-            send = (torch.arange(W, device=device, dtype=torch.int32).view(W, 1) + 1000 * rank + 100000 * rep).repeat(1, n).contiguous()
-            with torch.cuda.device(device):
-                _lib.check(L.tutel_amd_ep_ipc_exchange(comm.handle, seg.handle, send.data_ptr(), n * 4, 0, ops._stream()), "tutel_amd_ep_ipc_exchange")
-                torch.cuda.synchronize(device)
-                _lib.check(L.tutel_amd_ep_ipc_status(comm.handle), "tutel_amd_ep_ipc_status")
-                got = torch.empty([W, n], dtype=torch.int32, device=device)
-                _lib.check(L.tutel_amd_ep_segment_read(seg.handle, 0, got.data_ptr(), W * n * 4, ops._stream()), "tutel_amd_ep_segment_read")
-                torch.cuda.synchronize(device)
-            want = (torch.arange(W, device=device, dtype=torch.int32).view(W, 1) * 1000 + rank + 100000 * rep).repeat(1, n)
-            if not torch.equal(got, want):
-                raise _lib.TutelAmdError("tagged peer-store exchange returned wrong blocks")
+            bad, first = ipc_selfcheck(comm, seg, per_peer, SELFCHECK_PASSES, 0, side)
+            report.append(bad)
+            if bad:
+                raise _lib.TutelAmdError(f"{bad} of {SELFCHECK_PASSES * W * per_peer // 16} 16-byte vectors differed from what the peers stored "
+                                         f"(first: from rank {first >> 40}, vector {first & ((1 << 40) - 1)}; consuming on "
+                                         f"{'a side stream' if side else 'the calling stream'})")
         except Exception as ex:  # noqa: BLE001
             logging.warning("tutel_amd: the IPC transport failed its self-check on rank %d (%s)", comm.rank, ex)
             good = 0
         if not _agree(good, group, device):
             if comm.rank == 0:
                 logging.warning("tutel_amd: IPC transport unavailable; the exchange stays on the communicator's all-to-all")
+            L.tutel_amd_ep_segment_free(seg.handle)
             return False
+    L.tutel_amd_ep_segment_free(seg.handle)   # (after the agreement: no rank touches it any more)
     L.tutel_amd_ep_ipc_set_timeout(comm.handle, IPC_TIMEOUT_MS)
+    comm.selfcheck = {"bytes_per_peer": per_peer, "passes": SELFCHECK_PASSES, "stream_layouts": 2, "mismatches": report}
     comm.ipc = True
     return True
 
@@ -375,16 +414,53 @@ def communicator(group, device):
     return ent or None
 
 
-def destroy_all():
+_ALL = object()
+
+
+def ipc_status(group=_ALL, device=None):
+    """raise if an exchange of the IPC transport on `group`'s communicator gave up (a peer never arrived, or its rows were behind
+    its flag).  The forward that gave up has returned already -- its output is poisoned with NaN -- so callers that want the error
+    at a definite place (after a synchronize, at the end of a run) ask here; every forward asks on entry anyway."""
+    for (gkey, dkey), c in list(_comms.items()):
+        if c and c.ipc and (group is _ALL or gkey == _group_key(group)) and (device is None or dkey == str(device)):
+            _lib.check(_lib.lib().tutel_amd_ep_ipc_status(c.handle), "tutel_amd_ep_ipc_status")
+
+
+def destroy_all(check=False):
+    """free every communicator and its segments (collective in effect: peers hold mappings).  check=True first raises a pending
+    exchange error (after everything has been freed), so that the LAST forward of a run cannot fail silently."""
     L = _lib.lib()
+    pending = None
     for c in _comms.values():
         if c:
+            if c.ipc and pending is None and L.tutel_amd_ep_ipc_status(c.handle) != 0:
+                pending = L.tutel_amd_last_error().decode("utf-8", "replace")
+                logging.error("tutel_amd: %s", pending)
             L.tutel_amd_ep_comm_destroy(c.handle)
-            for sg in list(c.segments.values()) + [getattr(c, "_flags", None), getattr(c, "_selfcheck", None)]:
+            for sg in list(c.segments.values()) + [getattr(c, "_flags", None)]:
                 if sg is not None:
                     L.tutel_amd_ep_segment_free(sg.handle)
     _comms.clear()
     _groups.clear()
+    if check and pending:
+        raise _lib.TutelAmdError(pending)
+
+
+def set_transport(name, hosted=None):
+    """switch how the NEXT communicators exchange ("auto" | "ipc" | "rccl"): destroys the existing ones (every rank of every group
+    must call this at the same point of its program) -- layers then re-create theirs on their next forward; their cached pipeline
+    workspaces belong to the old communicator, so callers drop them with forget_workspaces(layer).  bench.py times the transports
+    side by side with this."""
+    global TRANSPORT, HOSTED
+    assert name in ("auto", "ipc", "rccl"), name
+    destroy_all()
+    TRANSPORT = name
+    if hosted is not None:
+        HOSTED = bool(hosted)
+
+
+def forget_workspaces(layer):
+    layer.__dict__.pop("_ep_workspaces", None)
 
 
 def plan(E, W, capacity, degree, allow_sliced=True):
@@ -480,19 +556,23 @@ class _Workspace:
                 comm.register(t)
 
 
-def _workspace(layer, static_key, T, C, make):
+def _workspace(layer, static_key, T, C, make, exact_capacity=False):
     """least-recently-used cache of at most WS_MAX workspaces per layer; a hit is ANY workspace of the same configuration
-    that is large enough (variable token counts -- serving -- keep hitting the largest one allocated so far)"""
+    that is large enough (variable token counts -- serving -- keep hitting the largest one allocated so far).
+    exact_capacity (the IPC transport): the capacity bucket decides WHICH peer-mapped segment the kernels store into and where
+    `back` starts inside it, so it must be the same on every rank for a given call -- a function of the call's (agreed) capacity
+    alone, never of which workspaces this rank happens to have cached (its token count differs from its peers': ADVICE r4 high).
+    A hit then needs C_cap == bucket(C); only the token bucket, which no peer ever sees, may be larger than needed."""
     import collections
     cache = layer.__dict__.get("_ep_workspaces")
     if not isinstance(cache, collections.OrderedDict):
         cache = layer.__dict__["_ep_workspaces"] = collections.OrderedDict()
+    C_cap = _bucket_capacity(C)
     for key, ws in cache.items():
-        if key[0] == static_key and ws.T_cap >= T and ws.C_cap >= C:
+        if key[0] == static_key and ws.T_cap >= T and (ws.C_cap == C_cap if exact_capacity else ws.C_cap >= C):
             cache.move_to_end(key)
             return ws
     T_cap = _bucket_tokens(T)
-    C_cap = _bucket_capacity(C)
     ws = make(T_cap, C_cap)
     cache[(static_key, T_cap, C_cap)] = ws
     layer.__dict__["_ep_workspace_allocations"] = layer.__dict__.get("_ep_workspace_allocations", 0) + 1
@@ -516,7 +596,8 @@ def forward(layer, x, crit, degree):
     k = crit.idx2d.shape[0]
     key = ("ep", x.shape[1], x.dtype, x.device, crit[0], k, degree, bool(layer.is_postscore), ex.fused_activation(), ops._stream(), with_comm,
            bool(comm is not None and comm.ipc))
-    ws = _workspace(layer, key, x.shape[0], crit[4], lambda Tc, Cc: _Workspace(layer, x, crit[0], Cc, k, degree, comm, Tc))
+    ws = _workspace(layer, key, x.shape[0], crit[4], lambda Tc, Cc: _Workspace(layer, x, crit[0], Cc, k, degree, comm, Tc),
+                    exact_capacity=bool(comm is not None and comm.ipc))
     a = ws.args
     a.T, a.capacity = x.shape[0], crit[4]
     w1, b1, w2, b2, kmajor = ex.fused_params(x.dtype)
@@ -592,7 +673,8 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
     for attempt in range(4):
         key = ("moe", x.shape[1], x.dtype, x.device, logits.shape[1], logits.dtype, k, degree, bool(layer.is_postscore),
                ex.fused_activation(), ops._stream(), with_comm, bool(comm is not None and comm.ipc))
-        ws = _workspace(layer, key, x.shape[0], capacity, lambda Tc, Cc: _MoeWorkspace(layer, x, logits, k, Cc, degree, comm, Tc))
+        ws = _workspace(layer, key, x.shape[0], capacity, lambda Tc, Cc: _MoeWorkspace(layer, x, logits, k, Cc, degree, comm, Tc),
+                        exact_capacity=bool(comm is not None and comm.ipc))
         m = ws.margs
         a = m.ep
         a.T = x.shape[0]

@@ -18,6 +18,7 @@ class GraphedForward:
         if forward_kwargs.get("capacity_factor", getattr(layer.gates[0], "capacity_factor", 1.0)) <= 0:
             raise ValueError("dropless routing (capacity_factor <= 0) reads the capacity back to the host and cannot be captured")
         self.layer, self.kwargs = layer, forward_kwargs
+        self._ep = getattr(layer, "world_size", 1) > 1
         self.static_in = example.clone()
         self.stream = torch.cuda.Stream(device=example.device)
         self.stream.wait_stream(torch.cuda.current_stream())
@@ -45,6 +46,12 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(self.stream)
 
     def __call__(self, x):
+        # a replay makes no library call, so nothing would ever report an exchange of the IPC transport that gave up (a peer that
+        # never arrived, rows behind their flag): ask before every replay -- one read of a pinned host word.  The
+        # replay that gave up has poisoned its own output with NaN on the device (csrc/ep.hip::ep_poison_kernel).
+        if self._ep:
+            from . import ep_native
+            ep_native.ipc_status(self.layer.group, self.static_in.device)
         if x.data_ptr() != self.static_in.data_ptr():
             self.static_in.copy_(x)
         self.graph.replay()
