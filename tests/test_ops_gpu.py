@@ -410,6 +410,48 @@ def test_expert_gemm_kernels_are_bit_identical(kmajor):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_split_k_pingpong_kernel(dtype):
+    """Round 5: launches of 96 .. 191 tiles of 256 x 256 (one pipeline stage of an 8-way expert-parallel rank: 4 experts x 1024 rows x
+    2048 columns = 128 tiles) run two workgroups per tile, each over half of K, and hand the partial accumulators over through memory
+    (TUTEL_OPT_GEMM_SPLITK).  Against the fp32 reference at the kernels' usual bar, against the unsplit kernel (same values up to the
+    rounding of ONE fp32 add per element), deterministic over repeated launches (the hand-over flags reset themselves), plain rows and
+    the expert-parallel row addressing (rows of two source ranks, output written in the all-to-all layout)."""
+    from tutel_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    E, R, N, K = 4, 1024, 2048, 2048
+    a = torch.randn([E, R, K], generator=g).to(dtype).cuda()
+    w = ((torch.rand([E, N, K], generator=g) * 2 - 1) / math.sqrt(K)).to(dtype).cuda()
+    b = torch.randn([E, N], generator=g).to(dtype).cuda()
+    ref = torch.relu(torch.matmul(a.float(), w.float().transpose(1, 2)) + b.float().unsqueeze(1)).to(dtype).float()
+    try:
+        ops.set_option(_lib.OPT_GEMM_SPLITK, 0)
+        plain = ops.expert_gemm(a, w, b, True, act="relu")
+        ops.set_option(_lib.OPT_GEMM_SPLITK, 1)
+        split = [ops.expert_gemm(a, w, b, True, act="relu") for _ in range(4)]
+        torch.cuda.synchronize()
+        assert all(torch.equal(split[0], o) for o in split[1:]), "a split launch must reproduce itself"
+        torch.testing.assert_close(plain.float(), ref, **_gemm_tol(dtype))
+        torch.testing.assert_close(split[0].float(), ref, **_gemm_tol(dtype))
+        d = (split[0].float() - plain.float()).abs()
+        ulp = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+        assert bool((d <= ulp * plain.float().abs() + 1e-6).all()), float(d.max())   # at most the last bit of the output dtype
+        assert float((d > 0).float().mean()) < 0.05                                     # and that only rarely
+        # expert-parallel addressing: A = [W, E_loc, C, K] as the all-to-all delivers it, D = [W, E_loc, C, N]
+        W, C = 2, R // 2
+        recv = a.view(E, W, C, K).permute(1, 0, 2, 3).contiguous()
+        out = torch.zeros([W, E, C, N], dtype=dtype, device="cuda")
+        ops.expert_gemm(recv, w, b, True, act="relu", E_loc=E, R=R, a_layout=(C * K, E * C * K, C, K), out=out, d_layout=(C * N, E * C * N, C, N))
+        assert torch.equal(out.permute(1, 0, 2, 3).reshape(E, R, N), split[0])
+        # a shape the split does not take (an odd number of tiles per four): falls back to the unsplit grid, silently and correctly
+        a2, w2 = a[:3, :768].contiguous(), w[:3, :1792].contiguous()
+        o2 = ops.expert_gemm(a2, w2, None, True)
+        torch.testing.assert_close(o2.float(), torch.matmul(a2.float(), w2.float().transpose(1, 2)).to(dtype).float(), **_gemm_tol(dtype))
+    finally:
+        ops.set_option(_lib.OPT_GEMM_SPLITK, -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_ring256_kernel_of_the_128_row_regime(oracle, dtype):
     """Round 4's kernel of the <= 128-rows-per-expert regime (128 x 256 tile, three-slot LDS-DMA ring, TUTEL_OPT_GEMM_IMPL = 4;
     automatic when its grid covers the chip, as at the headline shape) against the 128 x 128 LDS-DMA kernel (impl 1), bit for bit, on

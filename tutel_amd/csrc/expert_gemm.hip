@@ -99,6 +99,7 @@ struct GemmArgs {
   const void *mul;                                            // optional epilogue multiplier, D's layout
   const uint64_t *d_peer; long long d_peer_off;               // optional: rows of source rank w go to d_peer[w] + d_peer_off (bytes)
   PeerCanary d_can;                                           // peer stores: epoch canaries written behind the rows (common.h)
+  float *sk_ws; uint32_t *sk_flags;                           // split-K ping-pong kernel: partial accumulators + hand-over flags (see launch_pp_splitk)
   int ntm, ntn;
 };
 
@@ -965,7 +966,16 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
 // -------------------------------------------------------------------------------------------
 #define PP_BUF (4 * GL_STAGE)   // elements per LDS K-tile buffer: [256][64] tokens + [256][64] weights = 64 KB
 
-template <typename T, int ACT, bool W_ONCE, bool RAGGED = false, bool EARLY_BIAS = false>
+// SPLITK (round 5): launches whose 256 x 256 tiles cover only half the chip (96 .. 191 tiles: one pipeline stage of an 8-way
+// expert-parallel rank is 128) give every tile to TWO workgroups, neighbours in the XCD-aware work order (same XCD, dispatched
+// back to back), each running the K loop over one half of K at the full tile's flop-per-byte.  At the end each hands the partial
+// accumulators of ONE 128-column group to its partner (the four waves of that column group store 128 fp32 per lane with
+// system-scope write-through stores, 1 KB per instruction and wave, then raise a flag) and finishes the other column group: the
+// four remaining waves wait for the partner's flag, add its partial (lower-K half + upper-K half: one fp32 add per element, the
+// same whichever workgroup performs it) and run the epilogue on 64 x 128 each.  The hand-over is 128 KB out and 128 KB in per
+// workgroup.  Results differ from the unsplit kernel's in the last bits of the fp32 sum (two half sums added instead of one
+// running sum); a split launch is deterministic and reproduces itself.
+template <typename T, int ACT, bool W_ONCE, bool RAGGED = false, bool EARLY_BIAS = false, bool SPLITK = false>
 __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t *lds = reinterpret_cast<uint16_t *>(smem);  // [2][ tokens 2*GL_STAGE | weights 2*GL_STAGE ]
@@ -980,6 +990,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
     const int b = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = b & 7, pos = b >> 3;
     w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
   }
+  const int half = SPLITK ? (w & 1) : 0;  // which half of K this workgroup multiplies (and which 128-column group it finishes)
+  if (SPLITK) w >>= 1;
+  const int tile_id = w;
   const int mt = w % p.ntm;
   const int nt = (w / p.ntm) % p.ntn;
   const int e = w / (p.ntm * p.ntn);
@@ -1064,14 +1077,15 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
   const int a_row = (wm * 64 + l31) * GL_BK;                    // + mi*32*64
   const int w_row = 2 * GL_STAGE + (wn * 32 + l31) * GL_BK;     // + q*64*64, weights follow the token tile
 
-  const int nk = p.K / GL_BK;
-  const int rot = p.rot_on ? (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk) : 0;
+  const int nk = SPLITK ? p.K / (2 * GL_BK) : p.K / GL_BK;  // K-tiles of THIS workgroup
+  const int kt0 = SPLITK ? half * nk : 0;                   // its first K-tile (split launches never rotate: R >= 256)
+  const int rot = (!SPLITK && p.rot_on) ? (int)(((long long)(nt + 3 * e) * nk / p.ntn) % nk) : 0;
 
 #define PP_KOFF(J, KO)                                     \
   int KO;                                                  \
   {                                                        \
     int kr_ = (J) + rot; kr_ = kr_ >= nk ? kr_ - nk : kr_; \
-    KO = kr_ * (GL_BK * 2); /* bytes */                    \
+    KO = (kr_ + kt0) * (GL_BK * 2); /* bytes */            \
   }
   // LDS-DMA issue of one half of a tile (2 instructions per wave): HALF 0 -> pieces 2w,2w+1; 1 -> 16+2w,17+2w
 #define PP_ISSUE_A(J, BUF, HALF)                                                         \
@@ -1186,6 +1200,47 @@ __global__ __launch_bounds__(GB_THREADS, 2) void expert_gemm_pp_kernel(GemmArgs 
 #undef PP_ISSUE_W
 #undef PP_KOFF
 
+  if (SPLITK) {
+    // hand-over slots: [tile][half][wm] -> 128 fp32 per lane laid out [accumulator register 0..127][lane] (256 contiguous bytes per
+    // wave instruction) + one flag word.  Slot (tile, h, wm) is WRITTEN by workgroup h (its waves of column group 1 - h) and
+    // READ by workgroup 1 - h (its waves of column group 1 - h).
+    const size_t slot = ((size_t)tile_id * 2 + half) * 4 + wm;
+    if (wn != half) {  // giver
+      uint32_t *dst = reinterpret_cast<uint32_t *>(p.sk_ws) + slot * (128 * 64) + lane;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(dst + ((ni * 2 + mi) * 16 + r) * 64, __float_as_uint(acc[ni][mi][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every write-through store of this wave has completed at system scope
+      if (lane == 0) __hip_atomic_store(p.sk_flags + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (p.d_peer != nullptr) peer_canary_store(p.d_peer, p.d_can);  // (its block-wide barrier: every wave of the block passes one)
+      return;
+    }
+    const size_t pslot = ((size_t)tile_id * 2 + (1 - half)) * 4 + wm;  // the partner's slot for my column group
+    {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(p.sk_flags + pslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 400000000LL) __builtin_trap();  // 4 s of the 100 MHz clock: the partner workgroup never ran -- cannot happen with in-order dispatch
+      }
+    }
+    asm volatile("" ::: "memory");
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.sk_ws) + pslot * (128 * 64) + lane;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float o = __uint_as_float(__hip_atomic_load(src + ((ni * 2 + mi) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+          acc[ni][mi][r] = half == 0 ? acc[ni][mi][r] + o : o + acc[ni][mi][r];  // (lower-K half) + (upper-K half)
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(p.sk_flags + pslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // consumed: the slot is free for the next launch
+  }
   if (!EARLY_BIAS) PP_LOAD_BIAS();
 #undef PP_LOAD_BIAS
   if ((p.ldd & 7) || (p.d_stride_e & 7) || (p.d_stride_w & 7) || (reinterpret_cast<uintptr_t>(p.D) & 15)) {
@@ -1230,6 +1285,78 @@ static int launch_pp_cfg(const GemmArgs &b, hipStream_t st) {
   auto kern = expert_gemm_pp_kernel<T, ACT, W_ONCE, RAGGED, EARLY_BIAS>;
   if (!lds_optin((const void *)kern, lds)) return -1;
   hipLaunchKernelGGL(kern, dim3(b.E_loc * b.ntm * b.ntn), dim3(GB_THREADS), lds, st, b);
+  TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
+  return 0;
+}
+
+// ---- split-K launches: workspace per (device, stream) -------------------------------------------------------------------------
+// 256 KB of partial accumulators + 8 flag words per tile.  Launches on one stream are ordered, so one workspace per stream is
+// enough (the two stages of an overlapped pipeline run on two side streams: two workspaces); it grows on demand and is never
+// freed while the process lives.  hipMalloc is not allowed while the stream is being captured: a graph capture must have been
+// preceded by an eager call of the same shape (GraphedForward warms up before it captures) -- otherwise the launcher falls back
+// to the unsplit grid, which is always correct.
+struct SplitKWs { int device; hipStream_t stream; float *ws; uint32_t *flags; size_t tiles; };
+static std::mutex g_sk_mu;
+static SplitKWs g_sk[64];
+static int g_sk_n = 0;
+static bool splitk_workspace(hipStream_t st, size_t tiles, float **ws, uint32_t **flags) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(g_sk_mu);
+  SplitKWs *e = nullptr;
+  for (int i = 0; i < g_sk_n; ++i)
+    if (g_sk[i].device == dev && g_sk[i].stream == st) e = &g_sk[i];
+  if (e != nullptr && e->tiles >= tiles) {
+    *ws = e->ws;
+    *flags = e->flags;
+    return true;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;  // no allocation inside a capture
+  if (e == nullptr) {
+    if (g_sk_n >= 64) return false;
+    e = &g_sk[g_sk_n];
+    *e = SplitKWs{dev, st, nullptr, nullptr, 0};
+  } else {
+    (void)hipStreamSynchronize(st);  // the old buffers may still be in use by work queued on this stream
+    (void)hipFree(e->ws);
+    (void)hipFree(e->flags);
+    e->ws = nullptr; e->flags = nullptr; e->tiles = 0;
+  }
+  float *w = nullptr;
+  uint32_t *f = nullptr;
+  if (hipMalloc((void **)&w, tiles * 2 * 4 * (128 * 64) * sizeof(float)) != hipSuccess ||
+      hipMalloc((void **)&f, tiles * 2 * 4 * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(f, 0, tiles * 2 * 4 * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    if (w) (void)hipFree(w);
+    if (f) (void)hipFree(f);
+    return false;
+  }
+  e->ws = w; e->flags = f; e->tiles = tiles;
+  if (e == &g_sk[g_sk_n]) ++g_sk_n;
+  *ws = w;
+  *flags = f;
+  return true;
+}
+
+// 0: launched split; 1: not applicable here (the caller launches the unsplit grid); < 0: error
+template <typename T, int ACT>
+static int launch_pp_splitk(const GemmArgs &a, hipStream_t st) {
+  GemmArgs b = a;
+  b.ntm = (a.R + GB_BM - 1) / GB_BM;
+  b.ntn = (a.N + 255) / 256;
+  const size_t tiles = (size_t)b.E_loc * b.ntm * b.ntn;
+  const int nk = a.K / GL_BK;
+  // whole 256-row tiles only (no ragged variant), an even number of K-tiles with at least four per half (the steady-state loop),
+  // a multiple of four tiles (so that the two workgroups of a tile are neighbours on one XCD in the work order), 16-byte rows
+  if (a.row_counts != nullptr || a.R % GB_BM != 0 || (nk & 1) || nk < 8 || (tiles & 3) || a.rot_on) return 1;
+  if ((a.ldd & 7) || (a.d_stride_e & 7) || (a.d_stride_w & 7) || (reinterpret_cast<uintptr_t>(a.D) & 15)) return 1;
+  if (!splitk_workspace(st, tiles, &b.sk_ws, &b.sk_flags)) return 1;
+  const size_t lds = (size_t)8 * 64 * EP_PITCH;
+  auto kern = expert_gemm_pp_kernel<T, ACT, false, false, false, true>;
+  if (!lds_optin((const void *)kern, lds)) return -1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(2 * tiles)), dim3(GB_THREADS), lds, st, b);
   TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
   return 0;
 }
@@ -1338,7 +1465,21 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
     // from 42 us to 70 us with 16 CUs held and to 57 us beside a device copy, the 128-block 256 x 256 grid stays at 52 us
     // (tools/contention_probe.py, profiles/r03_contention.json).  So with the co-run hint the half-filled 256 x 256 grid wins.
     const bool corun_pp = tutel_gemm_corun() && big < 0 && a.R > GM_BM && t256 >= 96 && t256 < 192;
-    if (KM && a.fits32 && (big == 4 || corun_pp || (big < 0 && a.R > GM_BM && t256 >= 192))) return launch_pp<T, ACT>(a, st);
+    // Round 5: 96 .. 191 tiles of 256 x 256 (half the chip) CAN run two workgroups per tile, each over half of K (expert_gemm_pp_kernel
+    // <.., SPLITK>).  Built, correct (tests/test_ops_gpu.py::test_split_k_pingpong_kernel) and measured SLOWER than what it was to replace:
+    // the stage GEMM 4 x 1024 x 2048^2 takes 52.6-58.6 us split against 40.8 us on the 256 x 128 ring and 50.5 us on the unsplit half-chip
+    // grid -- the hand-over of 128 KB out + 128 KB in per workgroup through system-scope accesses costs more than the half K loop it saves
+    // (profiles/r05_splitk_probe.json).  So it is opt-in only: TUTEL_OPT_GEMM_SPLITK = 1.
+    if (KM && a.fits32 && a.mul == nullptr && a.R > GM_BM && t256 >= 96 && t256 < 192 && (big < 0 || big == 4) &&
+        tutel_get_option(TUTEL_OPT_GEMM_SPLITK) == 1) {
+      const int rc = launch_pp_splitk<T, ACT>(a, st);
+      if (rc <= 0) return rc;
+    }
+    // What the same A/B did show: with 129 .. 191 tiles the 256 x 128 ring needs TWO rounds of workgroups (2 x t256 > 256 CUs) where the
+    // unsplit 256 x 256 grid needs one at 1.5 x the flop per byte -- 5 x 1024 x 2048 x 4096: 124 us on the ring, 88.5 us on 160 ping-pong
+    // tiles (695 -> 971 TFLOP/s).  At <= 128 tiles the ring's single round wins (40.8 vs 50.5 us at 128).
+    const bool pp_one_round = big < 0 && a.R > GM_BM && t256 > 128 && t256 < 192;
+    if (KM && a.fits32 && (big == 4 || corun_pp || pp_one_round || (big < 0 && a.R > GM_BM && t256 >= 192))) return launch_pp<T, ACT>(a, st);
     if (big == 1 || big == 4 || (big < 0 && a.R > GM_BM && t256 >= 192)) return launch_big<T, KM, ACT, 4>(a, st);
     // 256 x 128: a three-slot ring (3 x 48 KB of LDS) keeps two tiles in flight: +3-4 % over two slots on the
     // stage shapes it is chosen for (tools/stage_probe.py); big = 2 forces the two-slot form for A/B runs
