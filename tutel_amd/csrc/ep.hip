@@ -679,8 +679,11 @@ extern "C" int tutel_amd_ep_ipc_status(tutel_amd_ep_comm_t *c) { return ipc_chec
 template <int FLAVOUR> __device__ __forceinline__ void store16(uint4 *p, uint4 v) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
   const u32x4_t x = {v.x, v.y, v.z, v.w};
-  if (FLAVOUR == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
-  else if (FLAVOUR == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
+  // (s_nop: an inline-assembly VMEM store is invisible to the compiler's hazard recognizer -- the wait states the ISA demands before
+  // a VALU write of the store's data registers are ours to provide; leaving them out is what produced round 4's "stale rows",
+  // profiles/r05_two_process_visibility.txt)
+  if (FLAVOUR == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+  else if (FLAVOUR == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
   else if (FLAVOUR == 3) __builtin_nontemporal_store(x, reinterpret_cast<u32x4_t *>(p));
   else *p = v;
 }
