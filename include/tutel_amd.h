@@ -76,6 +76,28 @@ int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax, int T, int
                         int normalize_gate, void *scores_out, int32_t *idx, void *gates, void *ws,
                         size_t ws_bytes, int32_t *clear_map, int clear_n, tutel_stream_t stream);
 
+/* The gate projection of a 16-bit linear gate, logits = x @ wg^T (x [T, M], wg [E, M] = nn.Linear's weight; replaces
+ * `F.linear(x, self.wg.weight)`, tutel/gates/top.py:20-22), as a split-K MFMA kernel that leaves `splits` fp32 partial sums
+ * partials[s][t][e]; tutel_amd_gate_topk_partials adds them in split order, rounds once to `dtype` (= what a 16-bit
+ * F.linear with fp32 accumulation returns; optionally stored to logits_out [T, E]) and continues exactly as
+ * tutel_amd_gate_topk with apply_softmax = 1 on those logits.  No atomics: the logits are reproducible bit for bit.
+ * tutel_amd_gate_proj_splits: the split count for a shape -- a pure function of (T, M, E, dtype); 0 = shape not covered
+ * (dtype not fp16 / bf16, E > 128, E % 4 != 0, M % 64 != 0): project with a library GEMM and call tutel_amd_gate_topk.
+ * partials must hold splits * T * E floats.  tutel_amd_gate_proj returns TUTEL_AMD_ENOTSUP for a shape that is not covered. */
+int tutel_amd_gate_proj_splits(int T, int M, int E, int dtype);
+int tutel_amd_gate_proj(const void *x, const void *wg, int dtype, int T, int M, int E, float *partials,
+                        size_t partial_bytes, tutel_stream_t stream);
+int tutel_amd_gate_topk_partials(const float *partials, int splits, int dtype, int T, int E, int k,
+                                 int normalize_gate, void *logits_out, void *scores_out, int32_t *idx, void *gates,
+                                 void *ws, size_t ws_bytes, int32_t *clear_map, int clear_n, tutel_stream_t stream);
+
+/* Warm the memory-side cache (256 MiB Infinity Cache) with n_chunks byte ranges of chunk_bytes each, stride_bytes apart: plain
+ * loads, nothing written (sink4: 4 writable bytes or NULL; practically never written).  For a caller that has a second stream
+ * idle while the routing kernels run -- they are latency chains that leave HBM idle, and the first expert GEMM's weights depend
+ * on nothing (tools/r5_headline_ab.py holds the measurement).  blocks < n_chunks: 256. */
+int tutel_amd_cache_warm(const void *p, size_t chunk_bytes, int n_chunks, size_t stride_bytes, int blocks, void *sink4,
+                         tutel_stream_t stream);
+
 /* idx[k,T] -> loc[k,T] (stable rank of token t among tokens with the same k-th choice, queued
  * after ALL tokens' earlier choices -- fast_dispatch.py:159-171), dispatch_count[E] (:177-178),
  * stats[0] = max_e dispatch_count[e] (the dropless capacity before the all-reduce, :192),
@@ -385,6 +407,13 @@ typedef struct {
   int capacity_limit, alignment, max_capacity;
   int *capacity_out;         /* host pointer, out: the capacity used (may be NULL when ep.capacity > 0); dropless: the read-back
                               * lands here (pinned memory keeps the copy asynchronous) */
+  /* the gate projection inside the call (round 5): logits == NULL and gate_w != NULL -> logits = ep.x @ gate_w^T through
+   * tutel_amd_gate_proj + tutel_amd_gate_topk_partials (ep.dtype must equal logits_dtype; the shape must be covered, see
+   * tutel_amd_gate_proj_splits -- otherwise the call fails before anything is enqueued). */
+  const void *gate_w;        /* [num_experts, M] in ep.dtype (nn.Linear weight of the gate), or NULL */
+  float *gate_partials;      /* >= splits * T * num_experts floats */
+  size_t gate_partial_bytes;
+  void *logits_out;          /* optional out [T, num_experts], logits dtype: the projected logits (NULL to skip) */
 } tutel_amd_moe_args_t;
 #define TUTEL_AMD_EAGAIN 1000
 #define TUTEL_AMD_ENOTSUP 1001 /* reserved: "this entry point does not take the shape, nothing was launched" */

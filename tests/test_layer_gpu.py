@@ -269,13 +269,15 @@ def test_dropless_headline_shape_vs_oracle(oracle, fp32_gate):
     x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=3)
     layer = make_layer(M, H, E, k, 0.0, dtype, weights, gate={"fp32_gate": fp32_gate}).eval()
     xd = x.cuda()
+    layer._keep_routing, layer.last_logits = True, None
     with torch.no_grad():
         dense = layer(xd)
         cap_dense = int(layer.protected_shape[1])
         counts = layer.dispatch_count.cpu()
+        # the logits the forward routed on: the in-call projection's (csrc/gate_proj.hip) when it ran, the library GEMM's otherwise
+        logits = layer.last_logits if layer.last_logits is not None else layer.gates[0](xd)
         mega = layer(xd, megablocks_size=4)
         cap_mega = int(layer.protected_shape[1])
-        logits = layer.gates[0](xd)
     assert cap_dense == int(counts.max()) and cap_dense > 128
     assert layer.megablocks_size == 4 and cap_mega == (cap_dense + 3) // 4 * 4
     assert torch.equal(dense, mega)
@@ -815,11 +817,16 @@ def test_low_precision_gate_layer_vs_oracle_on_its_own_scores(oracle, dtype, sha
     T, M, H, E, k = shape   # "headline" = BASELINE configs[1] exactly as bench.py runs it (fp32_gate=False)
     x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=11)
     layer = make_layer(M, H, E, k, 1.0, dtype, weights).eval()
+    layer._keep_routing, layer.last_logits = True, None
     with torch.no_grad():
         xd = x.cuda()
-        logits = layer.gates[0](xd)
         y = layer(xd)
-    assert logits.dtype == dtype
+        native = layer.last_logits is not None   # the projection ran inside the native call (csrc/gate_proj.hip): route the oracle on ITS logits
+        logits = layer.last_logits if native else layer.gates[0](xd)
+        lib_logits = layer.gates[0](xd)
+    assert logits.dtype == dtype and native
+    # the in-call projection against the library GEMM: both accumulate in fp32 and round once, in different orders
+    assert float((logits.float() - lib_logits.float()).abs().max()) <= (2 ** -6 if dtype == torch.bfloat16 else 2 ** -9) * max(1.0, float(lib_logits.float().abs().max()))
     scores = ops.gate_topk(logits, k, apply_softmax=True, want_scores=True)[3].cpu()
     sref = torch.softmax(logits.float(), dim=1).cpu()
     assert float((scores.float() - sref).abs().max()) <= (2 ** -8 if dtype == torch.bfloat16 else 2 ** -11)
@@ -965,3 +972,59 @@ def test_training_forward_and_data_gradients_on_the_mfma_gemm(oracle, monkeypatc
         fro = float((a - b).norm() / b.norm().clamp_min(1e-12))
         assert fro <= mult * eps, (tag, "relative Frobenius error", fro)
         assert float((a - b).abs().max()) <= 12 * mult * eps * scale + 1e-6, (tag, float((a - b).abs().max()), scale)
+
+
+def test_gate_projection_inside_the_native_call(oracle, monkeypatch):
+    """Round 5: for a plain 16-bit linear gate the one-call path projects the logits itself (csrc/gate_proj.hip + the top-k kernel
+    adding the split-K partial sums) instead of F.linear.  The oracle, routed on the logits the call returned, must reproduce the
+    assignment exactly and the output within the dtype's bar; switching the feature off (or hooking the gate) takes the library
+    projection and lands within the same bar; the logits of the two projections agree to an ulp of the dtype."""
+    from tutel_amd import ops
+    from tutel_amd.impls import moe_layer as ML
+    T, M, H, E, k = 2048, 512, 256, 16, 2
+    for dtype in (torch.bfloat16, torch.float16):
+        x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=41)
+        wg, w1, b1, w2, b2 = weights
+        layer = make_layer(M, H, E, k, 1.0, dtype, weights).eval()
+        layer._keep_routing, layer.last_logits = True, None
+        xd = x.cuda()
+        with torch.no_grad():
+            y = layer(xd)
+        assert layer.last_logits is not None, "the projection ran inside the native call"
+        logits = layer.last_logits.clone()
+        idx, loc = [t.cpu() for t in layer.last_routing]
+        scores = ops.gate_topk(logits, k, apply_softmax=True, want_scores=True)[3].cpu()
+        crit, lo = oracle.extract_critical(scores, k, 1.0)
+        assert torch.equal(idx, torch.stack([t.to(torch.int32) for t in crit[1]])) and torch.equal(loc, torch.stack([t.to(torch.int32) for t in crit[2]]))
+        assert torch.equal(layer.dispatch_count.cpu(), crit[5])
+        yo = oracle.fast_decode(oracle.expert_ffn(oracle.fast_encode(x, crit), w1, b1, w2, b2, accum_fp32=True), crit)
+        _close(y, yo, dtype)
+        assert abs(float(y.l_aux) - float(lo)) <= 1e-2
+        with torch.no_grad():
+            lib_logits = layer.gates[0](xd)
+        ulp = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+        assert float((logits.float() - lib_logits.float()).abs().max()) <= ulp * max(1.0, float(lib_logits.float().abs().max()))
+        # off: the library projection, same bar against the oracle on ITS logits
+        monkeypatch.setattr(ML, "_NATIVE_GATE", False)
+        layer.last_logits = None
+        with torch.no_grad():
+            y2 = layer(xd)
+        assert layer.last_logits is None
+        crit2, _ = oracle.extract_critical(ops.gate_topk(lib_logits, k, apply_softmax=True, want_scores=True)[3].cpu(), k, 1.0)
+        assert torch.equal(layer.dispatch_count.cpu(), crit2[5])
+        monkeypatch.setattr(ML, "_NATIVE_GATE", True)
+        # a hook on the gate must keep firing: the projection stays outside
+        calls = []
+        h = layer.gates[0].register_forward_hook(lambda *a: calls.append(1))
+        with torch.no_grad():
+            y3 = layer(xd)
+        h.remove()
+        assert calls == [1] and torch.equal(y3, y2)
+        # HIP-graph replay of the one-call path with the projection inside: equal to eager, replay after replay
+        from tutel_amd.impls.graph import GraphedForward
+        with torch.no_grad():
+            gf = GraphedForward(layer, xd)
+            for _ in range(3):
+                assert torch.equal(gf(xd), y)
+            x2 = torch.roll(xd, 1, 0)
+            assert torch.equal(gf(x2), layer(x2))

@@ -605,3 +605,58 @@ def test_tutel_ops_names_are_registered(oracle):
             assert float((y[e, :n].float() - r1).abs().max()) <= tol * max(1.0, float(r1.abs().max())), (dtype, e)
             r2 = torch.relu(y[e, :n]).float() @ w2[e].float()
             assert float((y2[e, :n].float() - r2).abs().max()) <= tol * max(1.0, float(r2.abs().max())), (dtype, e)
+
+
+GATE_PROJ_SHAPES = [(4096, 2048, 64), (4096, 4096, 64), (1000, 1024, 16), (777, 4096, 128), (64, 64, 4), (5000, 2048, 100),
+                    (1, 2048, 64), (65, 192, 8), (16384, 2048, 64), (300, 8192, 32)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", GATE_PROJ_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gate_projection_split_k_vs_fp32_reference(dtype, shape):
+    """csrc/gate_proj.hip (round 5): logits = x @ wg^T as S fp32 partial sums (replaces F.linear of gates/top.py:20-22 for a
+    16-bit gate).  Bars: (a) sum_s partials == the fp32 product of the same rounded operands to fp32-accumulation accuracy
+    (|err| <= 2e-5 * sum_m |x||wg| -- only the summation order differs); (b) the logits the top-k kernel derives from them are
+    EXACTLY dtype(((p0 + p1) + p2) + ...), fp32 adds in split order, one rounding; (c) idx / gates / histograms / column sums are
+    bit-identical to tutel_amd_gate_topk run on those logits; (d) the split count is the documented pure function of the shape."""
+    ops = _ops()
+    T, M, E = shape
+    g = torch.Generator().manual_seed(T * 7 + M + E)
+    x = torch.randn([T, M], generator=g).to(dtype).cuda()
+    wg = (torch.randn([E, M], generator=g) / M ** 0.5).to(dtype).cuda()
+    S = ops.gate_proj_splits(T, M, E, dtype)
+    assert S >= 1 and S == ops.gate_proj_splits(T, M, E, dtype)
+    part = ops.gate_proj(x, wg)
+    assert part is not None and tuple(part.shape) == (S, T, E)
+    ref = x.double() @ wg.double().t()
+    bound = 2e-5 * (x.double().abs() @ wg.double().abs().t()) + 1e-30
+    assert bool(((part.double().sum(0) - ref).abs() <= bound).all()), float(((part.double().sum(0) - ref).abs() / bound).max())
+    k = min(2, E)
+    idx, gates, ws, logits, scores = ops.gate_topk_partials(part, dtype, k, want_logits=True, want_scores=True)
+    acc = part[0].clone()
+    for s in range(1, S):
+        acc = acc + part[s]
+    assert torch.equal(logits, acc.to(dtype)), "logits are the partial sums added in split order, rounded once"
+    idx2, gates2, ws2, scores2 = ops.gate_topk(logits, k, apply_softmax=True, want_scores=True)
+    assert torch.equal(idx, idx2) and torch.equal(gates, gates2) and torch.equal(scores, scores2)
+    assert torch.equal(ws, ws2), "per-tile histograms and score column sums (what compute_location consumes)"
+    # twice the same input -> the same bits (no atomics anywhere on the path)
+    assert torch.equal(ops.gate_proj(x, wg), part)
+
+
+def test_gate_projection_uncovered_shapes_say_so():
+    """shapes the split-K kernel does not take report 0 splits (the caller projects with a library GEMM); the C entry point
+    returns ENOTSUP before anything is enqueued"""
+    from tutel_amd import _lib
+    ops = _ops()
+    for T, M, E, dt in [(128, 2048, 256, torch.bfloat16), (128, 2040, 64, torch.bfloat16), (128, 2048, 6, torch.float16), (128, 2048, 64, torch.float32)]:
+        assert ops.gate_proj_splits(T, M, E, dt) == 0
+    x = torch.zeros([128, 2048], dtype=torch.bfloat16, device="cuda")
+    wg = torch.zeros([256, 2048], dtype=torch.bfloat16, device="cuda")
+    assert ops.gate_proj(x, wg) is None
+    p = torch.zeros([4], dtype=torch.float32, device="cuda")
+    rc = _lib.lib().tutel_amd_gate_proj(x.data_ptr(), wg.data_ptr(), _lib.BF16, 128, 2048, 256, p.data_ptr(), 16, None)
+    assert rc == _lib.ENOTSUP
+    wg = torch.zeros([64, 2048], dtype=torch.bfloat16, device="cuda")
+    rc = _lib.lib().tutel_amd_gate_proj(x.data_ptr(), wg.data_ptr(), _lib.BF16, 128, 2048, 64, p.data_ptr(), 16, None)
+    assert rc != 0 and b"too small" in _lib.lib().tutel_amd_last_error()

@@ -25,6 +25,10 @@ SIGNATURES = {
     "tutel_amd_last_error": (ctypes.c_char_p, []),
     "tutel_amd_routing_workspace_bytes": (_sz, [_i, _i, _i]),
     "tutel_amd_gate_topk": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
+    "tutel_amd_gate_proj_splits": (_i, [_i, _i, _i, _i]),
+    "tutel_amd_gate_proj": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "tutel_amd_gate_topk_partials": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
+    "tutel_amd_cache_warm": (_i, [_vp, _sz, _i, _sz, _i, _vp, _vp]),
     "tutel_amd_compute_location": (_i, [_vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "tutel_amd_slot_map": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "tutel_amd_cumsum_sub_one": (_i, [_vp, _vp, _i, _i, _vp]),
@@ -61,7 +65,8 @@ class MoeArgs(ctypes.Structure):
     """tutel_amd_moe_args_t"""
     _fields_ = [("ep", EpArgs), ("logits", _vp), ("logits_dtype", _i), ("normalize_gate", _i), ("ws", _vp), ("ws_bytes", _sz),
                 ("dispatch_count", _vp), ("stats", _vp), ("l_aux", _vp),
-                ("capacity_limit", _i), ("alignment", _i), ("max_capacity", _i), ("capacity_out", ctypes.POINTER(_i))]
+                ("capacity_limit", _i), ("alignment", _i), ("max_capacity", _i), ("capacity_out", ctypes.POINTER(_i)),
+                ("gate_w", _vp), ("gate_partials", _vp), ("gate_partial_bytes", _sz), ("logits_out", _vp)]
 
 
 SIGNATURES.update({

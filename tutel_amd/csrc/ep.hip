@@ -1039,7 +1039,16 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
   TUTEL_REQUIRE(m != nullptr, "tutel_amd_moe_forward: null arguments");
   const tutel_amd_ep_args_t &a = m->ep;
   const int T = a.T, E = a.num_experts, k = a.k;
-  TUTEL_REQUIRE((m->logits != nullptr || T == 0) && m->ws != nullptr && m->dispatch_count != nullptr, "tutel_amd_moe_forward: null pointer");
+  const bool project = m->logits == nullptr && m->gate_w != nullptr;  // the gate projection inside the call (gate_proj.hip)
+  TUTEL_REQUIRE((m->logits != nullptr || project || T == 0) && m->ws != nullptr && m->dispatch_count != nullptr, "tutel_amd_moe_forward: null pointer");
+  int splits = 0;
+  if (project && T > 0) {
+    TUTEL_REQUIRE(a.dtype == m->logits_dtype, "tutel_amd_moe_forward: the in-call gate projection needs the gate in the token dtype (%d vs %d)", m->logits_dtype, a.dtype);
+    splits = tutel_amd_gate_proj_splits(T, a.M, E, a.dtype);
+    TUTEL_REQUIRE(splits > 0, "tutel_amd_moe_forward: the in-call gate projection does not cover T=%d, M=%d, E=%d, dtype=%d (pass logits)", T, a.M, E, a.dtype);
+    TUTEL_REQUIRE(a.x != nullptr && m->gate_partials != nullptr && m->gate_partial_bytes >= (size_t)splits * T * E * sizeof(float),
+                  "tutel_amd_moe_forward: gate_partials must hold %d x %d x %d floats", splits, T, E);
+  }
   TUTEL_REQUIRE(a.slot_map && (T == 0 || (a.idx && a.loc && a.gates)), "tutel_amd_moe_forward: null routing buffers");
   if (T == 0 && c == nullptr) return 0;  // (with a communicator an empty rank still takes part in every exchange, see tutel_amd_ep_forward)
   const bool dropless = a.capacity <= 0;
@@ -1047,8 +1056,16 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
                 "tutel_amd_moe_forward: dropless routing needs a single rank, stats, capacity_out and max_capacity");
   int32_t *smap = const_cast<int32_t *>(a.slot_map);
   int rc;
-  rc = tutel_amd_gate_topk(m->logits, m->logits_dtype, 1, T, E, k, m->normalize_gate, nullptr, const_cast<int32_t *>(a.idx),
-                           const_cast<void *>(a.gates), m->ws, m->ws_bytes, dropless ? nullptr : smap, dropless ? 0 : E * a.capacity, stream);
+  if (project && T > 0) {
+    rc = tutel_amd_gate_proj(a.x, m->gate_w, a.dtype, T, a.M, E, m->gate_partials, m->gate_partial_bytes, stream);
+    if (rc) return rc;
+    rc = tutel_amd_gate_topk_partials(m->gate_partials, splits, a.dtype, T, E, k, m->normalize_gate, m->logits_out, nullptr,
+                                      const_cast<int32_t *>(a.idx), const_cast<void *>(a.gates), m->ws, m->ws_bytes,
+                                      dropless ? nullptr : smap, dropless ? 0 : E * a.capacity, stream);
+  } else {
+    rc = tutel_amd_gate_topk(m->logits, m->logits_dtype, 1, T, E, k, m->normalize_gate, nullptr, const_cast<int32_t *>(a.idx),
+                             const_cast<void *>(a.gates), m->ws, m->ws_bytes, dropless ? nullptr : smap, dropless ? 0 : E * a.capacity, stream);
+  }
   if (rc) return rc;
   rc = tutel_amd_compute_location(a.idx, T, E, k, 1, m->ws, m->ws_bytes, const_cast<int32_t *>(a.loc), m->dispatch_count, m->stats,
                                   m->l_aux, m->logits_dtype, dropless ? 0 : a.capacity, dropless ? nullptr : smap, dropless ? 0 : 1, stream);

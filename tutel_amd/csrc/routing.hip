@@ -465,12 +465,21 @@ __global__ __launch_bounds__(RT_THREADS) void location_kernel(
 // GEMM + this kernel (profiles/r04_headline_ab.json).  One workgroup per 64-token tile is 64 workgroups, and fragment loads of
 // 32 bytes per row and instruction are bound by the L1 request rate, not by HBM; a coalesced version is the expert GEMM's LDS-DMA
 // pipeline plus a split-K reduction across workgroups, i.e. the library's skinny GEMM again.  Removed.)
+// EPQ consecutive elements of a row as ONE wide load (the row offset q * EPQ is a multiple of EPQ elements and E == 16 * EPQ, so the
+// address is aligned to the pack).  Per-element loads behind `e < E` predicates compile to a branch + a 2- or 4-byte load each.
+template <typename V, int N> struct alignas((sizeof(V) * N) > 16 ? 16 : (sizeof(V) * N)) GqPack { V v[N]; };
+template <typename V, int N> __device__ __forceinline__ void gq_load(const V *p, V (&o)[N]) {
+  const GqPack<V, N> pk = *reinterpret_cast<const GqPack<V, N> *>(p);
+#pragma unroll
+  for (int i = 0; i < N; ++i) o[i] = pk.v[i];
+}
+
 template <typename T, int EPQ>
 __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
-    int clear_n) {
+    int clear_n, const float *__restrict__ part, int nsplit, T *__restrict__ logits_out) {
   using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ES = GQ_LPT * EPQ + 1;                                    // padded row of the score tile
@@ -494,12 +503,58 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     const int t = ts + tl;
     const bool live = t < t1;
     CT v[EPQ];
-    {
-      const T *row = in + (size_t)min(t, Tn - 1) * E + q * EPQ;
+    if (part != nullptr) {
+      // logits = the gate projection's split-K partial sums (gate_proj.hip: part[s][t][e], fp32), added in split order and
+      // rounded ONCE to the logits dtype -- what a `T`-typed F.linear with fp32 accumulation returns (gates/top.py:20-22).
+      // Four splits' loads are in flight together (clamped addresses, the add is what is conditional).
+      const float *row = part + (size_t)min(t, Tn - 1) * E + q * EPQ;
+      const size_t sstride = (size_t)Tn * E;
+      const bool exact = E == GQ_LPT * EPQ;   // block-uniform
+      int ej[EPQ];                            // ragged E: clamped element offsets, loads stay unconditional
+#pragma unroll
+      for (int j = 0; j < EPQ; ++j) ej[j] = min(q * EPQ + j, E - 1) - q * EPQ;
+      float a[EPQ];
+#pragma unroll
+      for (int j = 0; j < EPQ; ++j) a[j] = 0.f;
+#define GQ_PART_SUM(LOAD)                                                                          \
+      for (int s0 = 0; s0 < nsplit; s0 += 4) {                                                     \
+        float b[4][EPQ];                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+          const float *rs = row + (size_t)min(s0 + i, nsplit - 1) * sstride;                       \
+          LOAD;                                                                                    \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+          if (s0 + i < nsplit) {                                                                   \
+            _Pragma("unroll") for (int j = 0; j < EPQ; ++j) a[j] = (s0 + i == 0) ? b[i][j] : a[j] + b[i][j]; \
+          }                                                                                        \
+      }
+      // two copies of the loop: merged into one, hipcc if-converts the two load forms into per-element loads again
+      if (exact) {
+        GQ_PART_SUM((gq_load<float, EPQ>(rs, b[i])));
+      } else {
+        GQ_PART_SUM(_Pragma("unroll") for (int j = 0; j < EPQ; ++j) b[i][j] = rs[ej[j]]);
+      }
+#undef GQ_PART_SUM
 #pragma unroll
       for (int j = 0; j < EPQ; ++j) {
         int e = q * EPQ + j;
-        v[j] = (e < E) ? Elem<T>::to_f32(row[j]) : -INFINITY;
+        const T r = Elem<T>::from_f32((CT)a[j]);
+        if (logits_out && live && e < E) logits_out[(size_t)t * E + e] = r;
+        v[j] = (e < E) ? Elem<T>::to_f32(r) : -INFINITY;
+      }
+    } else {
+      const T *row = in + (size_t)min(t, Tn - 1) * E + q * EPQ;
+      T raw[EPQ];
+      if (E == GQ_LPT * EPQ && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {   // block-uniform
+        gq_load<T, EPQ>(row, raw);
+      } else {
+#pragma unroll
+        for (int j = 0; j < EPQ; ++j) raw[j] = row[min(q * EPQ + j, E - 1) - q * EPQ];
+      }
+#pragma unroll
+      for (int j = 0; j < EPQ; ++j) {
+        int e = q * EPQ + j;
+        v[j] = (e < E) ? Elem<T>::to_f32(raw[j]) : -INFINITY;
       }
     }
     if (apply_softmax) {
@@ -629,7 +684,8 @@ __global__ __launch_bounds__(CS_WAVES * 64) void cumsum_kernel(const int32_t *__
 template <typename T>
 static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, int k, int normalize,
                             void *scores_out, int32_t *idx, void *gates, void *ws,
-                            int32_t *clear_map, int clear_n, hipStream_t st) {
+                            int32_t *clear_map, int clear_n, hipStream_t st, const float *part = nullptr, int nsplit = 0,
+                            void *logits_out = nullptr) {
   const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
@@ -641,7 +697,7 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
 #define GQ_LAUNCH(EPQ)                                                                         \
     hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ>), dim3(nt), dim3(GQ_THREADS), lds_q, st,            \
                        (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,          \
-                       idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n)
+                       idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, part, nsplit, (T *)logits_out)
     if (epq_t == 1) GQ_LAUNCH(1);
     else if (epq_t == 2) GQ_LAUNCH(2);
     else if (epq_t == 4) GQ_LAUNCH(4);
@@ -650,6 +706,7 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
     TUTEL_CHECK_LAUNCH("tutel_amd_gate_topk");
     return 0;
   }
+  TUTEL_REQUIRE(part == nullptr, "tutel_amd_gate_topk_partials: E = %d is past the 128 experts the partial-sum form covers", E);
   const int epl = (E + 63) / 64;
 #define GT_LAUNCH(EPL)                                                                          \
   do {                                                                                          \
@@ -693,6 +750,26 @@ extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax,
   if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   return launch_gate_topk<f16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
+}
+
+extern "C" int tutel_amd_gate_topk_partials(const float *partials, int splits, int dtype, int T, int E, int k,
+                                            int normalize_gate, void *logits_out, void *scores_out, int32_t *idx,
+                                            void *gates, void *ws, size_t ws_bytes, int32_t *clear_map, int clear_n,
+                                            tutel_stream_t stream) {
+  TUTEL_REQUIRE(dtype == TUTEL_F16 || dtype == TUTEL_BF16, "tutel_amd_gate_topk_partials: the logits dtype must be fp16 / bf16 (got %d)", dtype);
+  TUTEL_REQUIRE(T >= 0 && E >= 1 && E <= 128, "tutel_amd_gate_topk_partials: need 1 <= E <= 128 (got %d)", E);
+  TUTEL_REQUIRE(k >= 1 && k <= RT_MAX_K && k <= E, "tutel_amd_gate_topk_partials: need 1 <= k <= min(E,%d) (got k=%d, E=%d)", RT_MAX_K, k, E);
+  TUTEL_REQUIRE(splits >= 1 && splits <= 64, "tutel_amd_gate_topk_partials: bad split count %d", splits);
+  if (T == 0) return 0;
+  TUTEL_REQUIRE(partials && idx && gates && ws, "tutel_amd_gate_topk_partials: null pointer");
+  TUTEL_REQUIRE(ws_bytes >= tutel_amd_routing_workspace_bytes(T, E, k), "tutel_amd_gate_topk_partials: workspace too small");
+  TUTEL_REQUIRE(clear_n >= 0 && (clear_map != nullptr || clear_n == 0), "tutel_amd_gate_topk_partials: bad clear_map");
+  if (clear_n == 0) clear_map = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  StageScope stage(TUTEL_STAGE_GATE_TOPK, st);
+  if (dtype == TUTEL_BF16)
+    return launch_gate_topk<bf16_t>(nullptr, 1, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st, partials, splits, logits_out);
+  return launch_gate_topk<f16_t>(nullptr, 1, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st, partials, splits, logits_out);
 }
 
 extern "C" int tutel_amd_compute_location(const int32_t *idx, int T, int E, int k, int hist_ready,

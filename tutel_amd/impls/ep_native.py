@@ -649,9 +649,10 @@ class _MoeWorkspace(_Workspace):
         m.ws, m.ws_bytes, m.stats = self.ws.data_ptr(), self.ws.numel(), self.stats.data_ptr()
         m.capacity_out = ctypes.pointer(self.cap_c)
         self.margs = m
+        self.gate_partials, self.gate_partials_keep = None, []   # split-K partial sums of the in-call gate projection (on demand)
 
 
-def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss, dropless=None, megablocks_size=0):
+def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss, dropless=None, megablocks_size=0, gate_w=None):
     """x [T, M], logits [T, E] -> (y [T, M_out], l_aux | None, dispatch_count [E], capacity); None when the native path is
     unavailable.  One C call: softmax + top-k + locations + loss, encode, exchange(s), expert FFN, exchange(s), decode.
     dropless = (capacity_limit, alignment): capacity_factor <= 0 on a single rank -- the capacity is read back inside the call
@@ -692,7 +693,18 @@ def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, w
             a.row_counts, a.row_align = cnt.data_ptr(), int(megablocks_size)
         else:
             a.row_counts, a.row_align = None, 1
-        m.logits, m.normalize_gate = logits.data_ptr(), int(bool(normalize_gate))
+        m.normalize_gate = int(bool(normalize_gate))
+        if gate_w is None:
+            m.logits, m.gate_w, m.logits_out = logits.data_ptr(), None, None
+        else:   # `logits` is a meta tensor (shape / dtype only): the projection runs inside the call (csrc/gate_proj.hip)
+            need = ops.gate_proj_splits(x.shape[0], x.shape[1], logits.shape[1], x.dtype) * x.shape[0] * logits.shape[1]
+            if ws.gate_partials is None or ws.gate_partials.numel() < need:
+                ws.gate_partials_keep.append(ws.gate_partials)   # a captured graph may still hold the old pointer
+                ws.gate_partials = torch.empty([need], dtype=torch.float32, device=dev)
+            m.logits, m.gate_w = None, gate_w.data_ptr()
+            m.gate_partials, m.gate_partial_bytes = ws.gate_partials.data_ptr(), ws.gate_partials.numel() * 4
+            layer.last_logits = torch.empty(list(logits.shape), dtype=x.dtype, device=dev) if getattr(layer, "_keep_routing", False) else None
+            m.logits_out = layer.last_logits.data_ptr() if layer.last_logits is not None else None
         m.dispatch_count = cnt.data_ptr()
         m.l_aux = l_aux.data_ptr() if l_aux is not None else None
         cap_out = ws.cap_c

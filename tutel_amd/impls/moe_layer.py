@@ -29,7 +29,9 @@ from . import losses
 from .fast_dispatch import RoutingPlan, extract_critical, fast_decode, fast_encode, get_dispatch_count
 from .overlap import a2a_ffn_overlap_forward, a2a_ffn_overlap_fused
 from . import ep_native
+from .. import ops
 from ..experts.ffn import FusedExpertsNetwork
+from ..gates.top import LinearTopKGate
 
 
 # test hook: run the overlapped expert-parallel path even with a single rank (exercises its
@@ -37,6 +39,8 @@ from ..experts.ffn import FusedExpertsNetwork
 _FORCE_OVERLAP = int(os.environ.get("TUTEL_AMD_FORCE_OVERLAP", "0")) != 0
 # A/B switch: gather fc1's rows from the tokens (fused fast_encode) on the single-rank path
 _FUSE_ENCODE = int(os.environ.get("TUTEL_AMD_FUSE_ENCODE", "1")) != 0
+# A/B switch: the projection of a 16-bit linear gate inside the native call (csrc/gate_proj.hip) instead of F.linear
+_NATIVE_GATE = int(os.environ.get("TUTEL_AMD_NATIVE_GATE", "1")) != 0
 
 
 def _autocast_dtype(t):
@@ -284,7 +288,23 @@ class MOELayer(torch.nn.Module):
         rem = capacity % alignment
         return capacity + ((alignment - rem) if rem > 0 else 0)
 
-    def _run_native_moe(self, x, logits, top_k, cf, degree, alignment, megablocks_size):
+    @staticmethod
+    def _native_gate_weight(gate, x):
+        """wg.weight when the gate projection can run inside the native call, else None"""
+        if not (_NATIVE_GATE and x.is_cuda and type(gate) is LinearTopKGate and not gate.fp32_gate and x.dim() == 2):
+            return None
+        w = gate.wg.weight
+        if w.dtype != x.dtype or x.dtype not in (torch.bfloat16, torch.float16) or not w.is_contiguous() or w.device != x.device:
+            return None
+        if gate._forward_hooks or gate._forward_pre_hooks or gate.wg._forward_hooks or gate.wg._forward_pre_hooks:
+            return None
+        if torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
+            return None
+        if torch.is_autocast_enabled() or ops.gate_proj_splits(x.shape[0], x.shape[1], w.shape[0], x.dtype) == 0:
+            return None
+        return w
+
+    def _run_native_moe(self, x, logits, top_k, cf, degree, alignment, megablocks_size, gate_w=None):
         T, E = logits.shape
         k = min(top_k, E)
         spe = (T + E - 1) // E
@@ -292,10 +312,11 @@ class MOELayer(torch.nn.Module):
         if cf <= 0:   # dropless: capacity = max expert load, read back inside the native call (fast_dispatch.py:191-199)
             guess = (k * spe * 3 // 2 + 31) // 32 * 32
             res = ep_native.forward_from_logits(self, xc, logits.contiguous(), k, guess, 1, self.normalize_gate, want_loss=True,
-                                                dropless=(k * int(-cf * spe) if cf < 0 else 0, alignment), megablocks_size=megablocks_size)
+                                                dropless=(k * int(-cf * spe) if cf < 0 else 0, alignment), megablocks_size=megablocks_size,
+                                                gate_w=gate_w)
         else:
             res = ep_native.forward_from_logits(self, xc, logits.contiguous(), k, self._static_capacity(T, E, k, cf, alignment), degree,
-                                                self.normalize_gate, want_loss=True)
+                                                self.normalize_gate, want_loss=True, gate_w=gate_w)
         if res is None:   # the library's communicator could not be created: every rank falls back together
             return None
         y, l_aux, cnt, capacity = res
@@ -346,6 +367,17 @@ class MOELayer(torch.nn.Module):
             return self.result_func(y) if self.result_func is not None else y
 
         plan_args = (gate, top_k, cf, degree, alignment, reserve_shape, inequivalent_tokens, megablocks_size, original_dtype)
+        # A plain 16-bit linear gate on the one-call path: the projection runs INSIDE the native call (csrc/gate_proj.hip, split-K
+        # MFMA + the top-k kernel adding the partial sums) instead of F.linear here.  Decided on the logits' shape / dtype alone
+        # (a meta tensor stands in for them); anything else -- hooks on the gate, a gradient, fp32_gate, an uncovered shape --
+        # projects below as before.
+        gate_w = self._native_gate_weight(gate, x)
+        if gate_w is not None:
+            spec = torch.empty([x.shape[0], gate_w.shape[0]], dtype=x.dtype, device="meta")
+            if self._plan("before_routing", x, spec, *plan_args) == "native_moe":
+                res = self._run_native_moe(x, spec, top_k, cf, degree, alignment, megablocks_size, gate_w=gate_w)
+                if res is not None:
+                    return finish(*res)
         # the gate projection: computed ONCE, autocast off (moe_layer.py:315-323), whatever path consumes it
         if x.is_cuda:
             with torch.autocast("cuda", enabled=False):

@@ -80,6 +80,65 @@ def gate_topk(inp, k, apply_softmax=False, normalize_gate=True, want_scores=Fals
     return idx, gates, ws, (scores if apply_softmax else inp)
 
 
+def gate_proj_splits(T, M, E, dtype):
+    """split count of the native gate projection for this shape (0: not covered -> F.linear + gate_topk)"""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return 0
+    return int(_lib.lib().tutel_amd_gate_proj_splits(int(T), int(M), int(E), _lib.BF16 if dtype == torch.bfloat16 else _lib.F16))
+
+
+def gate_proj(x, wg, partials=None):
+    """x [T, M], wg [E, M] (16-bit) -> fp32 partial sums [S, T, E] of x @ wg^T (split-K, csrc/gate_proj.hip); None when the shape is
+    not covered.  gate_topk_partials() adds them in split order and rounds once to x.dtype."""
+    _dev(x)
+    assert x.dim() == 2 and wg.dim() == 2 and x.shape[1] == wg.shape[1] and x.dtype == wg.dtype
+    T, M = x.shape
+    E = wg.shape[0]
+    S = gate_proj_splits(T, M, E, x.dtype)
+    if S == 0 or T == 0:
+        return None
+    x, wg = x.contiguous(), wg.contiguous()
+    if partials is None:
+        partials = torch.empty([S, T, E], dtype=torch.float32, device=x.device)
+    assert partials.numel() >= S * T * E and partials.dtype == torch.float32
+    _lib.check(_lib.lib().tutel_amd_gate_proj(_ptr(x), _ptr(wg), _code(x), T, M, E, _ptr(partials), partials.numel() * 4, _stream()),
+               "tutel_amd_gate_proj")
+    return partials
+
+
+def gate_topk_partials(partials, dtype, k, normalize_gate=True, want_logits=False, want_scores=False, ws=None, clear=None):
+    """partials [S, T, E] fp32 (gate_proj) -> idx [k,T] i32, gates [k,T] dtype, ws, logits|None, scores|None: softmax + top-k on
+    logits = dtype(sum_s partials[s]), exactly as gate_topk(logits, apply_softmax=True)."""
+    _dev(partials)
+    assert partials.dim() == 3 and partials.dtype == torch.float32 and partials.is_contiguous()
+    S, T, E = partials.shape
+    k = min(int(k), E)
+    dev = partials.device
+    idx = torch.empty([k, T], dtype=torch.int32, device=dev)
+    gates = torch.empty([k, T], dtype=dtype, device=dev)
+    logits = torch.empty([T, E], dtype=dtype, device=dev) if want_logits else None
+    scores = torch.empty([T, E], dtype=dtype, device=dev) if want_scores else None
+    if ws is None:
+        ws = routing_workspace(T, E, k, dev)
+    code = _lib.BF16 if dtype == torch.bfloat16 else _lib.F16
+    _lib.check(_lib.lib().tutel_amd_gate_topk_partials(_ptr(partials), S, code, T, E, k, int(bool(normalize_gate)), _ptr(logits),
+                                                       _ptr(scores), _ptr(idx), _ptr(gates), _ptr(ws), ws.numel(), _ptr(clear),
+                                                       clear.numel() if clear is not None else 0, _stream()),
+               "tutel_amd_gate_topk_partials")
+    return idx, gates, ws, logits, scores
+
+
+def cache_warm(t, chunk_bytes=None, n_chunks=1, stride_bytes=0, blocks=0, offset=0):
+    """plain loads over n_chunks ranges of chunk_bytes (stride_bytes apart) of tensor t, from byte `offset` (memory-side cache
+    warm-up on the current stream, csrc/gate_proj.hip)"""
+    _dev(t)
+    total = t.numel() * t.element_size()
+    chunk_bytes = total - offset if chunk_bytes is None else int(chunk_bytes)
+    assert offset + (n_chunks - 1) * stride_bytes + chunk_bytes <= total
+    _lib.check(_lib.lib().tutel_amd_cache_warm(t.data_ptr() + offset, chunk_bytes, int(n_chunks), int(stride_bytes), int(blocks), None, _stream()),
+               "tutel_amd_cache_warm")
+
+
 def compute_location(idx, E, ws=None, capacity=0, want_l_aux=False, l_aux_dtype=torch.float32, cleared_slot_map=None):
     """idx [k,T] -> loc [k,T], dispatch_count [E], stats [1] (max count), l_aux [1]|None, slot_map|None.
     cleared_slot_map: an [E*capacity] int32 tensor already filled with -1 (see gate_topk(clear=...))."""
