@@ -447,7 +447,7 @@ int tutel_amd_marks_report(double *delta_us, int n);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG / TUTEL_AMD_DECODE /
- * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS / TUTEL_AMD_EP_CANARY / TUTEL_AMD_GEMM_SPLITK seed it once), >= 0 = force.  Every choice computes bit-identical results (excepted: TUTEL_OPT_EP_CANARY = 2 provokes the error it tests; TUTEL_OPT_GEMM_SPLITK changes the fp32 summation order).
+ * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS / TUTEL_AMD_EP_CANARY / TUTEL_AMD_GEMM_SPLITK / TUTEL_AMD_GEMM_GATHER seed it once), >= 0 = force.  Every choice computes bit-identical results (excepted: TUTEL_OPT_EP_CANARY = 2 provokes the error it tests; TUTEL_OPT_GEMM_SPLITK changes the fp32 summation order).
  *   TUTEL_OPT_GEMM_IMPL  kernels of the <= 128-rows-per-expert regime: 0 register-staged 128 x 128, 1 LDS-DMA 128 x 128, 4 the
  *                        128 x 256 tile on a three-slot LDS-DMA ring (k-major weights; automatic when its grid covers the chip)
  *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
@@ -466,6 +466,9 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *                        1 = two workgroups per tile, each over half of K, partials handed over through memory (the ONE choice that
  *                        changes result bits: two half sums added instead of one running sum; deterministic).  Measured slower than
  *                        the grids it was to replace (round 5), so 0 / automatic = never
+ *   TUTEL_OPT_GEMM_GATHER  fused fast_encode of the ring kernels: 1 / automatic = the slot-map entries come through the scalar cache
+ *                        and are waited for only after the first weight pieces have been issued; 0 = vector loads in front of them
+ *                        (rounds 1-4)
  *   TUTEL_OPT_EP_CANARY  IPC transport: epoch canaries behind every exchanged block (1 / automatic = written by the producers and
  *                        checked by the wait kernels; 0 = off; 2 = TEST INJECTION: this rank publishes the previous epoch, as if
  *                        its rows had not landed when its flag did -- the peers must report it)
@@ -478,7 +481,8 @@ int tutel_amd_marks_report(double *delta_us, int n);
 #define TUTEL_OPT_EP_STREAMS 5
 #define TUTEL_OPT_EP_CANARY 6
 #define TUTEL_OPT_GEMM_SPLITK 7
-#define TUTEL_OPT_COUNT 8
+#define TUTEL_OPT_GEMM_GATHER 8
+#define TUTEL_OPT_COUNT 9
 int tutel_amd_set_option(int key, int value);
 
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------

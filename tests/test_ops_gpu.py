@@ -483,6 +483,14 @@ def test_ring256_kernel_of_the_128_row_regime(oracle, dtype):
             tag = (E, R, N, K, act)
             for u, v in zip(outs[1], outs[4]):
                 assert torch.equal(u, v), tag
+            # round 5: the ring kernel fetches the slot-map entries through the scalar cache (32 consecutive entries per wave, past
+            # the expert's rows / the end of the map when R < 128: those rows are zeroed whatever was read); the vector-load form
+            # of rounds 1-4 (option 0) must give the same bits
+            ops.set_option(_lib.OPT_GEMM_GATHER, 0)
+            try:
+                assert torch.equal(ops.expert_gemm_gather(x, smap.cuda(), w, b, True, act, R), outs[4][1]), tag
+            finally:
+                ops.set_option(_lib.OPT_GEMM_GATHER, -1)
             # and against fp32 arithmetic on the same operands
             ref = torch.matmul(a.float(), w.float().transpose(1, 2)) + (b.float().unsqueeze(1) if b is not None else 0.0)
             ref = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, "silu": torch.nn.functional.silu, "none": lambda t: t}[act](ref)

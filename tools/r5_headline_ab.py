@@ -46,7 +46,7 @@ def graph_time(fn, n=20, reps=9):
 
 
 def main():
-    sections = sys.argv[1] if len(sys.argv) > 1 else "gfwt"
+    sections = sys.argv[1] if len(sys.argv) > 1 else "gfswt"
     T, M, H, E, k = 4096, 2048, 2048, 64, 2
     C = k * (T // E)
     dt, dev = torch.bfloat16, "cuda"
@@ -81,7 +81,7 @@ def main():
         res["gate"]["assignments_differing_from_the_library_logits"] = int((i1 != i2).sum())
         print(json.dumps(res["gate"]), flush=True)
 
-    if "f" in sections or "w" in sections or "t" in sections:
+    if any(c in sections for c in "fwts"):
         from tutel import moe
         from tutel_amd.impls import moe_layer as ML
         torch.set_default_dtype(dt)
@@ -101,6 +101,30 @@ def main():
                 res["forward"].setdefault("gate projection %s" % ("inside the native call (split-K)" if native else "F.linear (library)"), []).append(graph_time(fwd, n=10))
         ML._NATIVE_GATE = True
         print(json.dumps(res["forward"]), flush=True)
+
+    if "s" in sections:
+        # fc1's fused fast_encode: slot-map entries through the scalar cache, waited for after the first weight pieces went out (1)
+        # vs four vector loads in front of the first DMA (0, rounds 1-4)
+        res["scalar_gather"] = {}
+        for rnd in range(3):
+            for mode in (0, 1):
+                ops.set_option(_lib.OPT_GEMM_GATHER, mode)
+                res["scalar_gather"].setdefault("forward, slot map via %s" % ("scalar loads after the weight issue" if mode else "vector loads first"), []).append(graph_time(fwd, n=10))
+        ops.set_option(_lib.OPT_GEMM_GATHER, -1)
+        import ctypes
+        for rnd in range(2):
+            for mode in (0, 1):
+                ops.set_option(_lib.OPT_GEMM_GATHER, mode)
+                _lib.lib().tutel_amd_stage_timing(2)
+                for _ in range(60):
+                    fwd()
+                torch.cuda.synchronize()
+                tot, cnt = (ctypes.c_double * 16)(), (ctypes.c_int * 16)()
+                _lib.lib().tutel_amd_stage_report(tot, cnt, 16)
+                _lib.lib().tutel_amd_stage_timing(0)
+                res["scalar_gather"].setdefault("eager fc1 / fc2 us, mode %d" % mode, []).append([round(tot[3] / max(cnt[3], 1), 2), round(tot[4] / max(cnt[4], 1), 2)])
+        ops.set_option(_lib.OPT_GEMM_GATHER, -1)
+        print(json.dumps(res["scalar_gather"], indent=0), flush=True)
 
     if "w" in sections:
         w1 = layer.experts.fused_params(dt)[0]          # [E, H, M]: fc1's weights as the GEMM streams them

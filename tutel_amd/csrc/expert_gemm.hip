@@ -46,6 +46,8 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef int sgv4 __attribute__((ext_vector_type(4)));
+typedef int sgv8 __attribute__((ext_vector_type(8)));
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -96,6 +98,7 @@ struct GemmArgs {
   int a_span_bytes;                                           // gather: bytes of the token array (a_rows_mod rows)
   bool fits32;                                                // operands addressable with 32-bit byte offsets
   bool rot_on;                                                // K-tile rotation (see launch_gemm)
+  bool sgather;                                               // ring kernels: slot-map entries through the scalar cache (TUTEL_OPT_GEMM_GATHER)
   const void *mul;                                            // optional epilogue multiplier, D's layout
   const uint64_t *d_peer; long long d_peer_off;               // optional: rows of source rank w go to d_peer[w] + d_peer_off (bytes)
   PeerCanary d_can;                                           // peer stores: epoch canaries written behind the rows (common.h)
@@ -723,23 +726,35 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
   // NSUB sub-tiles of 16 pieces each
   const uint16_t *a_src[4], *w_src[WPW];
   int gr4[4], slot4[4];
+  // SG (round 5; the ring kernels with buffer-descriptor DMA): the slot-map entries of the fused fast_encode come through the SCALAR
+  // cache -- the wave's 32 token-tile rows are 32 consecutive map entries, 4 x s_buffer_load_dwordx8 (out-of-range entries read 0 and
+  // belong to rows past the row count, whose DMA is pointed out of range anyway) -- and the token-tile addresses are worked out only
+  // AFTER the weight pieces of the first tiles have been issued.  As vector loads the four lookups sat in front of the first DMA
+  // (s_waitcnt vmcnt(0) before any weight byte was requested: one dependent L2 round trip at the head of every block), and moving
+  // the weight issue above them would not have helped: vmcnt retires in order, so waiting for the lookups would have meant waiting
+  // for the weight data.  Scalar loads count on lgkmcnt.
+  constexpr bool SG = BUF && NS == 3;
+  sgv8 sg_q[4];
+  const bool sg_on = SG && p.a_rows != nullptr && p.sgather;  // block-uniform
+  const unsigned long long mb_ = (unsigned long long)reinterpret_cast<uintptr_t>(p.a_rows);
+  const sgv4 rs_m = {(int)(unsigned)mb_, (int)((mb_ >> 32) & 0xffff), (int)((unsigned)p.E_loc * (unsigned)p.R * 4u), 0x00020000};
+  const int mo_ = (e * p.R + m0 + 32 * wid) * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) gr4[i] = min(m0 + 8 * (wid * 4 + i) + (lane >> 3), p.R - 1);
-  gather_rows4(p, e, gr4, slot4);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    {
-      const int r = 8 * (wid * 4 + i) + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);
-      const int gr = gr4[i];
-      a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + c * 8;
-      if (p.a_rows != nullptr) {
-        const int q = slot4[i];
-        a_src[i] = (q >= 0 ? reinterpret_cast<const uint16_t *>(p.A) + (size_t)(q % p.a_rows_mod) * p.lda
-                           : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;
-      }
-    }
+  if (!sg_on) gather_rows4(p, e, gr4, slot4);
+#define GB_A_ADDR()                                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+    const int r = 8 * (wid * 4 + i) + (lane >> 3);                                                             \
+    const int c = (lane & 7) ^ ((r >> 1) & 7);                                                                 \
+    const int gr = gr4[i];                                                                                     \
+    a_src[i] = Ae + (size_t)(gr / p.a_rpw) * p.a_stride_w + (size_t)(gr % p.a_rpw) * p.lda + c * 8;            \
+    if (p.a_rows != nullptr) {                                                                                 \
+      const int q = slot4[i];                                                                                  \
+      a_src[i] = (q >= 0 ? reinterpret_cast<const uint16_t *>(p.A) + (size_t)(q % p.a_rows_mod) * p.lda        \
+                         : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;                              \
+    }                                                                                                          \
   }
+  if (!sg_on) { GB_A_ADDR(); }
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
     const int g = wid * WPW + i, dg = g >> 4, j = g & 15;
@@ -758,16 +773,16 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
   const size_t w_step = W_KMAJOR ? (size_t)GL_BK : (size_t)GL_BK * p.ldw;
   const int piece_a = wid * 4 * 512, piece_w = wid * WPW * 512;  // weight pieces are consecutive across the sub-tiles
   int a_off[4], w_off[WPW];
+  const uint16_t *abase = p.a_rows != nullptr ? reinterpret_cast<const uint16_t *>(p.A) : Ae;
+#define GB_A_OFF()                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+    const int r = 8 * (wid * 4 + i) + (lane >> 3);                                                             \
+    a_off[i] = (int)(unsigned)((const char *)a_src[i] - (const char *)abase);                                  \
+    if ((p.a_rows != nullptr && slot4[i] < 0) || m0 + r >= row_limit)                                          \
+      a_off[i] = (int)0x7ffff000u + (((lane & 7) ^ ((r >> 1) & 7)) << 4);  /* empty slot / past the row count: out of range -> zeros */ \
+  }
   if (BUF) {
-    const uint16_t *abase = p.a_rows != nullptr ? reinterpret_cast<const uint16_t *>(p.A) : Ae;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = 8 * (wid * 4 + i) + (lane >> 3);
-      const int gr = min(m0 + r, p.R - 1);
-      a_off[i] = (int)(unsigned)((const char *)a_src[i] - (const char *)abase);
-      if ((p.a_rows != nullptr && slot4[i] < 0) || m0 + r >= row_limit)
-        a_off[i] = (int)0x7ffff000u + (((lane & 7) ^ ((r >> 1) & 7)) << 4);  // empty slot / past the row count: out of range -> zeros
-    }
+    if (!sg_on) { GB_A_OFF(); }
 #pragma unroll
     for (int i = 0; i < WPW; ++i) w_off[i] = (int)(unsigned)((const char *)w_src[i] - (const char *)We);
   }
@@ -899,9 +914,34 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
     // needs everything up to A(0), i.e. all but the 4 * (NS - 2) token ops after it (NS = 3: equal to the steady-state count from
     // the second tile on, where each iteration issues [A, W] of one tile).
     static_assert(NS <= 3, "the prologue order below is worked out for rings of at most three slots");
+    // (the scalar loads go out here, not at the top of the kernel: hipcc fetches kernel arguments lazily and every
+    // `s_waitcnt lgkmcnt(0)` it places for them would wait for these too)
+    if (sg_on) {
+      // everything the weight issue below consumes is forced into registers FIRST (empty volatile asm statements keep their order):
+      // SMEM returns out of order, so the one wait hipcc can place for a late kernel-argument fetch is lgkmcnt(0) -- which would
+      // also wait for the map entries
+      asm volatile("" ::"s"(reinterpret_cast<uintptr_t>(We)), "s"(rot), "s"(nk), "s"((int)w_once), "s"((int)(w_step * 2)));
+#pragma unroll
+      for (int i = 0; i < WPW; ++i) asm volatile("" ::"v"(w_off[i]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("s_buffer_load_dwordx8 %0, %1, %2" : "=&s"(sg_q[i]) : "s"(rs_m), "s"(mo_ + i * 32));
+    }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
       if (t < nk) GB_ISSUE_W(t, t);
+    if (sg_on) {  // the weight stream is on its way: now the slot-map entries and the token addresses
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sg_q[0]), "+s"(sg_q[1]), "+s"(sg_q[2]), "+s"(sg_q[3]));
+      const int rl_ = lane >> 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int q = sg_q[i][0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) q = (rl_ == j) ? sg_q[i][j] : q;
+        slot4[i] = q;
+      }
+      GB_A_ADDR();
+      GB_A_OFF();
+    }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
       if (t < nk) GB_ISSUE_A(t, t);
@@ -923,6 +963,8 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
     }
   }
 #undef GB_TILE
+#undef GB_A_ADDR
+#undef GB_A_OFF
 #undef GB_ISSUE
 #undef GB_ISSUE_A
 #undef GB_ISSUE_W
@@ -1564,6 +1606,7 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   //     together and the later ones hit in L2 (ping-pong kernel 65.7 -> 62.6 us at 8 x 1024 x 2048 x 2048, 242 -> 224 at
   //     4096^2, 85 -> 79 at 32 x 256 rows).
   a.rot_on = R < GB_BM;
+  a.sgather = tutel_get_option(TUTEL_OPT_GEMM_GATHER) != 0 && (long long)E_loc * R * 4 < 0x7fffffffLL;
   a.mul = mul;
   a.d_peer = d_peer; a.d_peer_off = d_peer_off;
   a.d_can = d_can != nullptr ? *d_can : PeerCanary{nullptr, 0, 0, 0};
