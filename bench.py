@@ -655,7 +655,9 @@ def main():
     R = world * C                               # rows per local expert
     stage_us = {name: round(tot / nb, 2) for name, (tot, cnt) in stages.items() if cnt}
     launches = {name: cnt for name, (tot, cnt) in stages.items() if cnt}
-    stage_us["gate_projection(hipBLASLt)"] = round(gate_timer.avg_us(), 2)
+    if gate_timer.events:   # the projection ran outside the native call (F.linear -> hipBLASLt): fp32 gate, TUTEL_AMD_NATIVE_GATE=0, ...
+        stage_us["gate_projection(hipBLASLt)"] = round(gate_timer.avg_us(), 2)
+    # (otherwise stage_us["gate_projection"] is the split-K MFMA kernel inside the call, csrc/gate_proj.hip)
     fc1_tot, fc1_n = gemms["expert_fc1"]
     fc2_tot, fc2_n = gemms["expert_fc2"]
     fc1_us, fc2_us = fc1_tot / max(1, fc1_n), fc2_tot / max(1, fc2_n)   # per LAUNCH (one pipeline stage when N > 1)

@@ -414,6 +414,12 @@ typedef struct {
   float *gate_partials;      /* >= splits * T * num_experts floats */
   size_t gate_partial_bytes;
   void *logits_out;          /* optional out [T, num_experts], logits dtype: the projected logits (NULL to skip) */
+  /* fused location (round 5; TUTEL_OPT_FUSED_LOCATION): scratch of >= round_up(k * T, 16) bytes.  With it, on one rank with
+   * capacity > 0, tutel_amd_compute_location is not launched where the shape allows: the first expert GEMM ranks its expert's
+   * (choice, token) entries itself and fills ep.loc / ep.slot_map; dispatch_count, stats and l_aux come out of an extra block of the
+   * decode launch.  Every output keeps its bits.  NULL: never. */
+  void *fl_ws;
+  size_t fl_ws_bytes;
 } tutel_amd_moe_args_t;
 #define TUTEL_AMD_EAGAIN 1000
 #define TUTEL_AMD_ENOTSUP 1001 /* reserved: "this entry point does not take the shape, nothing was launched" */
@@ -433,7 +439,8 @@ int tutel_amd_range_pop(void);
  * records.  The reference's counterpart is system.record_time around whole steps (system.py:73-79). */
 enum {
   TUTEL_STAGE_GATE_TOPK = 0, TUTEL_STAGE_LOCATION = 1, TUTEL_STAGE_ENCODE = 2, TUTEL_STAGE_FC1 = 3, TUTEL_STAGE_FC2 = 4,
-  TUTEL_STAGE_DECODE = 5, TUTEL_STAGE_A2A_DISPATCH = 6, TUTEL_STAGE_A2A_COMBINE = 7, TUTEL_STAGE_OTHER = 8, TUTEL_STAGE_COUNT = 9
+  TUTEL_STAGE_DECODE = 5, TUTEL_STAGE_A2A_DISPATCH = 6, TUTEL_STAGE_A2A_COMBINE = 7, TUTEL_STAGE_OTHER = 8, TUTEL_STAGE_GATE_PROJ = 9,
+  TUTEL_STAGE_COUNT = 10
 };
 int tutel_amd_stage_timing(int enable);
 int tutel_amd_stage_report(double *total_us, int *counts, int n_stages /* >= TUTEL_STAGE_COUNT */);
@@ -447,7 +454,7 @@ int tutel_amd_marks_report(double *delta_us, int n);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG / TUTEL_AMD_DECODE /
- * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS / TUTEL_AMD_EP_CANARY / TUTEL_AMD_GEMM_SPLITK / TUTEL_AMD_GEMM_GATHER seed it once), >= 0 = force.  Every choice computes bit-identical results (excepted: TUTEL_OPT_EP_CANARY = 2 provokes the error it tests; TUTEL_OPT_GEMM_SPLITK changes the fp32 summation order).
+ * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS / TUTEL_AMD_EP_CANARY / TUTEL_AMD_GEMM_SPLITK / TUTEL_AMD_GEMM_GATHER / TUTEL_AMD_FUSED_LOCATION seed it once), >= 0 = force.  Every choice computes bit-identical results (excepted: TUTEL_OPT_EP_CANARY = 2 provokes the error it tests; TUTEL_OPT_GEMM_SPLITK changes the fp32 summation order).
  *   TUTEL_OPT_GEMM_IMPL  kernels of the <= 128-rows-per-expert regime: 0 register-staged 128 x 128, 1 LDS-DMA 128 x 128, 4 the
  *                        128 x 256 tile on a three-slot LDS-DMA ring (k-major weights; automatic when its grid covers the chip)
  *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
@@ -469,6 +476,9 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *   TUTEL_OPT_GEMM_GATHER  fused fast_encode of the ring kernels: 1 / automatic = the slot-map entries come through the scalar cache
  *                        and are waited for only after the first weight pieces have been issued; 0 = vector loads in front of them
  *                        (rounds 1-4)
+ *   TUTEL_OPT_FUSED_LOCATION  tutel_amd_moe_forward on one rank: 1 / automatic = the locations are computed inside the first expert
+ *                        GEMM (every block ranks its expert's entries itself, no tutel_amd_compute_location launch; dispatch_count and
+ *                        the loss in an extra block of the decode launch) where the shape takes that kernel; 0 = never
  *   TUTEL_OPT_EP_CANARY  IPC transport: epoch canaries behind every exchanged block (1 / automatic = written by the producers and
  *                        checked by the wait kernels; 0 = off; 2 = TEST INJECTION: this rank publishes the previous epoch, as if
  *                        its rows had not landed when its flag did -- the peers must report it)
@@ -482,7 +492,8 @@ int tutel_amd_marks_report(double *delta_us, int n);
 #define TUTEL_OPT_EP_CANARY 6
 #define TUTEL_OPT_GEMM_SPLITK 7
 #define TUTEL_OPT_GEMM_GATHER 8
-#define TUTEL_OPT_COUNT 9
+#define TUTEL_OPT_FUSED_LOCATION 9
+#define TUTEL_OPT_COUNT 10
 int tutel_amd_set_option(int key, int value);
 
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------

@@ -1028,3 +1028,56 @@ def test_gate_projection_inside_the_native_call(oracle, monkeypatch):
                 assert torch.equal(gf(xd), y)
             x2 = torch.roll(xd, 1, 0)
             assert torch.equal(gf(x2), layer(x2))
+
+
+FL_SHAPES = [  # (T, M, H, E, k, capacity_factor): capacity <= 128 rows per expert and k * T <= 15360 entries -- where the fused-location kernel applies
+    (4096, 2048, 2048, 64, 2, 1.0),   # the headline: the ring kernel is the automatic choice
+    (1000, 256, 512, 16, 2, 1.0), (330, 128, 256, 8, 3, 1.0), (777, 64, 256, 128, 1, 1.0), (2000, 192, 320, 16, 2, 0.5), (64, 64, 256, 4, 2, 1.0),
+    (7680, 128, 256, 128, 2, 1.0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", FL_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_fused_location_keeps_every_bit(oracle, shape, dtype):
+    """Round 5: on the single-rank one-call path the locations are computed INSIDE the first expert GEMM (every block ranks its own
+    expert's (choice, token) entries; no tutel_amd_compute_location launch; dispatch_count / loss in an extra block of the decode
+    launch).  Against the unfused path (TUTEL_OPT_FUSED_LOCATION = 0) every output must keep its bits -- y, l_aux, dispatch_count, idx,
+    loc, the slot map -- and idx / loc / counts must equal the oracle's on the scores the kernel derived.  The small shapes force the
+    128 x 256 ring kernel (TUTEL_OPT_GEMM_IMPL = 4), which is the only one that has the fused form."""
+    from tutel_amd import _lib, ops
+    T, M, H, E, k, cf = shape
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=51)
+    layer = make_layer(M, H, E, k, cf, dtype, weights).eval()
+    layer._keep_routing, layer.last_logits = True, None
+    xd = x.cuda()
+    got = {}
+    try:
+        ops.set_option(_lib.OPT_GEMM_IMPL, 4)
+        for mode in (0, -1):
+            ops.set_option(_lib.OPT_FUSED_LOCATION, mode)
+            layer.__dict__.pop("_ep_workspaces", None)
+            ops.stage_timing(1)
+            with torch.no_grad():
+                y = layer(xd)
+            torch.cuda.synchronize()
+            rep = ops.stage_report()
+            ops.stage_timing(0)
+            ws = list(layer._ep_workspaces.values())[0]
+            C = int(layer.protected_shape[1])
+            got[mode] = dict(y=y.clone(), l_aux=y.l_aux.clone(), cnt=layer.dispatch_count.clone(), idx=layer.last_routing[0].clone(),
+                             loc=layer.last_routing[1].clone(), smap=ws.slot_map[:E * C].clone(),
+                             logits=(layer.last_logits if layer.last_logits is not None else layer.gates[0](xd)).clone(),
+                             location_launches=rep["location"][1])
+    finally:
+        ops.stage_timing(0)
+        ops.set_option(_lib.OPT_FUSED_LOCATION, -1)
+        ops.set_option(_lib.OPT_GEMM_IMPL, -1)
+    assert got[0]["location_launches"] == 1 and got[-1]["location_launches"] == 0, "the fused path must be the one that ran"
+    for name in ("y", "l_aux", "cnt", "idx", "loc", "smap", "logits"):
+        assert torch.equal(got[0][name], got[-1][name]), name
+    scores = ops.gate_topk(got[-1]["logits"], k, apply_softmax=True, want_scores=True)[3].cpu()
+    crit, _ = oracle.extract_critical(scores, k, cf)
+    assert torch.equal(got[-1]["idx"].cpu(), torch.stack([t.to(torch.int32) for t in crit[1]]))
+    assert torch.equal(got[-1]["loc"].cpu(), torch.stack([t.to(torch.int32) for t in crit[2]]))
+    assert torch.equal(got[-1]["cnt"].cpu(), crit[5])

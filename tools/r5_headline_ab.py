@@ -46,7 +46,7 @@ def graph_time(fn, n=20, reps=9):
 
 
 def main():
-    sections = sys.argv[1] if len(sys.argv) > 1 else "gfswt"
+    sections = sys.argv[1] if len(sys.argv) > 1 else "gfslwt"
     T, M, H, E, k = 4096, 2048, 2048, 64, 2
     C = k * (T // E)
     dt, dev = torch.bfloat16, "cuda"
@@ -81,7 +81,7 @@ def main():
         res["gate"]["assignments_differing_from_the_library_logits"] = int((i1 != i2).sum())
         print(json.dumps(res["gate"]), flush=True)
 
-    if any(c in sections for c in "fwts"):
+    if any(c in sections for c in "fwtsl"):
         from tutel import moe
         from tutel_amd.impls import moe_layer as ML
         torch.set_default_dtype(dt)
@@ -125,6 +125,31 @@ def main():
                 res["scalar_gather"].setdefault("eager fc1 / fc2 us, mode %d" % mode, []).append([round(tot[3] / max(cnt[3], 1), 2), round(tot[4] / max(cnt[4], 1), 2)])
         ops.set_option(_lib.OPT_GEMM_GATHER, -1)
         print(json.dumps(res["scalar_gather"], indent=0), flush=True)
+
+    if "l" in sections:
+        # locations inside the first expert GEMM (no location launch) vs the location kernel
+        res["fused_location"] = {}
+        for rnd in range(3):
+            for mode in (0, -1):
+                ops.set_option(_lib.OPT_FUSED_LOCATION, mode)
+                layer.__dict__.pop("_ep_workspaces", None)
+                res["fused_location"].setdefault("forward, %s" % ("locations inside fc1" if mode else "location kernel"), []).append(graph_time(fwd, n=10))
+        import ctypes
+        for rnd in range(2):
+            for mode in (0, -1):
+                ops.set_option(_lib.OPT_FUSED_LOCATION, mode)
+                layer.__dict__.pop("_ep_workspaces", None)
+                fwd()
+                ops.stage_timing(1)
+                for _ in range(60):
+                    fwd()
+                torch.cuda.synchronize()
+                rep = ops.stage_report()
+                ops.stage_timing(0)
+                res["fused_location"].setdefault("eager us per launch, %s" % ("fused" if mode else "unfused"), []).append(
+                    {name: round(tot / max(cnt, 1), 2) for name, (tot, cnt) in rep.items() if cnt})
+        ops.set_option(_lib.OPT_FUSED_LOCATION, -1)
+        print(json.dumps(res["fused_location"], indent=0), flush=True)
 
     if "w" in sections:
         w1 = layer.experts.fused_params(dt)[0]          # [E, H, M]: fc1's weights as the GEMM streams them

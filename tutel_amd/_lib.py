@@ -14,7 +14,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
-OPT_GEMM_IMPL, OPT_GEMM_TILE, OPT_DECODE, OPT_EP_STAGE_GRID, OPT_GEMM_PERSIST, OPT_EP_STREAMS, OPT_EP_CANARY, OPT_GEMM_SPLITK, OPT_GEMM_GATHER = 0, 1, 2, 3, 4, 5, 6, 7, 8
+OPT_GEMM_IMPL, OPT_GEMM_TILE, OPT_DECODE, OPT_EP_STAGE_GRID, OPT_GEMM_PERSIST, OPT_EP_STREAMS, OPT_EP_CANARY, OPT_GEMM_SPLITK, OPT_GEMM_GATHER, OPT_FUSED_LOCATION = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -66,7 +66,8 @@ class MoeArgs(ctypes.Structure):
     _fields_ = [("ep", EpArgs), ("logits", _vp), ("logits_dtype", _i), ("normalize_gate", _i), ("ws", _vp), ("ws_bytes", _sz),
                 ("dispatch_count", _vp), ("stats", _vp), ("l_aux", _vp),
                 ("capacity_limit", _i), ("alignment", _i), ("max_capacity", _i), ("capacity_out", ctypes.POINTER(_i)),
-                ("gate_w", _vp), ("gate_partials", _vp), ("gate_partial_bytes", _sz), ("logits_out", _vp)]
+                ("gate_w", _vp), ("gate_partials", _vp), ("gate_partial_bytes", _sz), ("logits_out", _vp),
+                ("fl_ws", _vp), ("fl_ws_bytes", _sz)]
 
 
 SIGNATURES.update({
@@ -110,7 +111,8 @@ EXCHANGE_V_FN = ctypes.CFUNCTYPE(_i, _vp, _vp, _vp, _u64p, _u64p, _u64p, _i)
 EP_ID_BYTES = 128
 IPC_HANDLE_BYTES = 64
 EAGAIN, ENOTSUP = 1000, 1001
-STAGES = ("gate_topk", "location", "fast_encode", "expert_fc1", "expert_fc2", "fast_decode", "all_to_all_dispatch", "all_to_all_combine", "other")
+STAGES = ("gate_topk", "location", "fast_encode", "expert_fc1", "expert_fc2", "fast_decode", "all_to_all_dispatch", "all_to_all_combine", "other",
+          "gate_projection")
 
 _lib = None
 

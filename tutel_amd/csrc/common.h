@@ -63,6 +63,21 @@ int tutel_expert_gemm_peer(const void *A, int64_t a_stride_e, int64_t a_stride_w
                            const uint64_t *d_peer, int64_t d_peer_off, int64_t d_stride_e, int d_rows_per_w, int ldd, int E_loc,
                            int R, int N, int K, int dtype, int act, const PeerCanary &can, hipStream_t st);
 
+// expert_gemm.hip: the gather GEMM with the locations computed inside the launch (fused location); loc == NULL: eligibility query
+int tutel_expert_gemm_gather_fl(const void *X, int ldx, int32_t *slot_map, int T, const void *zero_row, const void *W, int64_t w_stride_e,
+                                int ldw, const void *bias, int64_t bias_stride_e, void *D, int64_t d_stride_e, int ldd, int E_loc, int R,
+                                int N, int K, int dtype, int act, const uint8_t *idx8, int n, int32_t *loc, hipStream_t st);
+// dispatch.hip: fast_decode + the routing finish (routing_dev.h) in one launch
+struct RouteFinish;
+void tutel_route_finish_args(int T, int E, int k, void *ws, RouteFinish *out);  // routing.hip
+int tutel_decode_finish_launch(const void *buf, int dtype, const int32_t *idx, const int32_t *loc, const void *gates, int gate_dtype, int T, int M,
+                               int k, int capacity, int num_experts, void *out, const RouteFinish &fin, hipStream_t st);
+// routing.hip: top-k on logits (`in`) or on the gate projection's split-K partial sums, optionally leaving a byte copy of idx
+// (idx8 [k * T], E <= 128) for the fused-location expert GEMM
+int tutel_gate_topk_launch(const void *in, const float *partials, int splits, int dtype, int T, int E, int k, int normalize_gate,
+                           void *logits_out, int32_t *idx, void *gates, void *ws, int32_t *clear_map, int clear_n, uint8_t *idx8,
+                           hipStream_t st);
+
 #define TUTEL_REQUIRE(cond, ...)           \
   do {                                     \
     if (!(cond)) {                         \

@@ -13,6 +13,7 @@
 // Rows are processed as 16-byte vectors (8 x bf16/fp16 or 4 x fp32 per lane, 1 KiB per wave
 // instruction); rows whose byte length is not a multiple of 16 take the scalar tail path.
 #include "common.h"
+#include "routing_dev.h"
 
 #define DP_THREADS 256
 #define DP_WAVES 4
@@ -119,18 +120,14 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
 // headline shape, so the kernel is one dependent chain (index loads -> row loads -> stores) and shorter per-wave chains overlap
 // better.  NTS: the combined rows are written with non-temporal stores (they are not re-read by this layer).
 template <typename T, int KMAX, int SPLIT, bool NTS>
-__global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict__ buf,
-                                                           const int32_t *__restrict__ idx,
-                                                           const int32_t *__restrict__ loc,
-                                                           const void *__restrict__ gates,
-                                                           int gate_dtype, int Tn, int M, int k,
-                                                           int capacity, int num_experts,
-                                                           int chunk_rows, int expert_slice,
-                                                           int ep_world, T *__restrict__ out) {
+__device__ __forceinline__ void decode_body(const T *__restrict__ buf, const int32_t *__restrict__ idx,
+                                            const int32_t *__restrict__ loc, const void *__restrict__ gates,
+                                            int gate_dtype, int Tn, int M, int k, int capacity, int num_experts,
+                                            int chunk_rows, int expert_slice, int ep_world, T *__restrict__ out, int bid, int nblk) {
   constexpr int VN = Vec<T>::N;
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * DP_WAVES;
+  const int wave = bid * DP_WAVES + (threadIdx.x >> 6);
+  const int nwaves = nblk * DP_WAVES;
   const int nvec = M / VN;
   const bool vec_ok = (M % VN) == 0;
   const int per = SPLIT == 1 ? nvec : (((nvec + SPLIT - 1) / SPLIT + 63) / 64 * 64);  // vectors per wave of a token
@@ -238,6 +235,33 @@ __global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict_
       }
     }
   }
+}
+
+template <typename T, int KMAX, int SPLIT, bool NTS>
+__global__ __launch_bounds__(DP_THREADS) void decode_kernel(const T *__restrict__ buf, const int32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ loc, const void *__restrict__ gates,
+                                                           int gate_dtype, int Tn, int M, int k, int capacity, int num_experts,
+                                                           int chunk_rows, int expert_slice, int ep_world, T *__restrict__ out) {
+  decode_body<T, KMAX, SPLIT, NTS>(buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out,
+                                   (int)blockIdx.x, (int)gridDim.x);
+}
+
+// decode + the routing "finish" in one launch (fused-location path, ep.hip): block 0 -- dispatched first: the finish is a longer
+// dependent chain (~5 us) than one decode block -- computes dispatch_count, the maximum expert load and the gshard loss from the
+// routing workspace, what block 0 of location_kernel does when that kernel runs, off the critical path (nothing on the device
+// waits for those three results); the other blocks are the decode above.
+template <typename T, int KMAX>
+__global__ __launch_bounds__(DP_THREADS) void decode_fin_kernel(const T *__restrict__ buf, const int32_t *__restrict__ idx,
+                                                               const int32_t *__restrict__ loc, const void *__restrict__ gates,
+                                                               int gate_dtype, int Tn, int M, int k, int capacity, int num_experts,
+                                                               T *__restrict__ out, RouteFinish fin) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fin_smem[];
+  if (blockIdx.x == 0) {  // block-uniform
+    route_finish_block(fin, fin_smem);
+    return;
+  }
+  decode_body<T, KMAX, 1, true>(buf, idx, loc, gates, gate_dtype, Tn, M, k, capacity, num_experts, 0, 0, 1, out, (int)blockIdx.x - 1,
+                                (int)gridDim.x - 1);
 }
 
 // any k (k > 16; upstream's ATen chain takes any top-k, fast_dispatch.py:145-148): the same arithmetic with a run-time loop over the
@@ -443,6 +467,39 @@ extern "C" int tutel_amd_fast_decode(const void *buf, int dtype, const int32_t *
   else if (dtype == TUTEL_BF16) launch_decode<bf16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
   else launch_decode<f16_t>(buf, idx, loc, gates, gate_dtype, T, M, k, capacity, num_experts, chunk_rows, expert_slice, ep_world, out, st);
   TUTEL_CHECK_LAUNCH("tutel_amd_fast_decode");
+  return 0;
+}
+
+// internal (common.h): fast_decode of plain [E, C] buckets + the routing finish in ONE launch (k <= 8, bf16 / fp16)
+int tutel_decode_finish_launch(const void *buf, int dtype, const int32_t *idx, const int32_t *loc, const void *gates, int gate_dtype, int T, int M,
+                               int k, int capacity, int num_experts, void *out, const RouteFinish &fin, hipStream_t st) {
+  TUTEL_REQUIRE((dtype == TUTEL_BF16 || dtype == TUTEL_F16) && k >= 1 && k <= 8 && T >= 1 && capacity >= 1 && buf && idx && loc && out,
+                "tutel_decode_finish_launch: bad arguments");
+  TUTEL_REQUIRE(((uintptr_t)buf % 16) == 0 && ((uintptr_t)out % 16) == 0, "tutel_decode_finish_launch: buf/out must be 16-byte aligned");
+  StageScope stage(TUTEL_STAGE_DECODE, st);
+  const int grid = dp_grid(T) + 1;
+  const size_t lds = route_finish_lds(fin.E, fin.k);
+#define DECF(TT, KM)                                                                                                              \
+  do {                                                                                                                            \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)decode_fin_kernel<TT, KM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((decode_fin_kernel<TT, KM>), dim3(grid), dim3(DP_THREADS), lds, st, (const TT *)buf, idx, loc, gates, gate_dtype, T, M, \
+                       k, capacity, num_experts, (TT *)out, fin);                                                                  \
+  } while (0)
+#define DECK(TT)                                                                                                                  \
+  switch (k) {                                                                                                                    \
+    case 1: DECF(TT, 1); break;                                                                                                   \
+    case 2: DECF(TT, 2); break;                                                                                                   \
+    case 3: DECF(TT, 3); break;                                                                                                   \
+    case 4: DECF(TT, 4); break;                                                                                                   \
+    case 5: DECF(TT, 5); break;                                                                                                   \
+    case 6: DECF(TT, 6); break;                                                                                                   \
+    case 7: DECF(TT, 7); break;                                                                                                   \
+    default: DECF(TT, 8);                                                                                                         \
+  }
+  if (dtype == TUTEL_BF16) { DECK(bf16_t); } else { DECK(f16_t); }
+#undef DECK
+#undef DECF
+  TUTEL_CHECK_LAUNCH("tutel_decode_finish_launch");
   return 0;
 }
 

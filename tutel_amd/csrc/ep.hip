@@ -37,6 +37,7 @@
 #include <rccl/rccl.h>
 
 #include "common.h"
+#include "routing_dev.h"
 
 // ---- RCCL, resolved at run time -------------------------------------------------------------
 struct RcclApi {
@@ -1056,6 +1057,50 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
                 "tutel_amd_moe_forward: dropless routing needs a single rank, stats, capacity_out and max_capacity");
   int32_t *smap = const_cast<int32_t *>(a.slot_map);
   int rc;
+  // ---- fused location (see expert_gemm_big_kernel<.., FL>): no location launch between the top-k kernel and the first expert GEMM
+  const int Ho = a.H, Mo = a.M_out;
+  bool fl = !dropless && c == nullptr && a.world == 1 && a.degree <= 1 && a.is_postscore && a.fuse_encode && T > 0 && k <= 8 && E <= 128 &&
+            (long long)k * T <= 15360 && m->fl_ws != nullptr && m->fl_ws_bytes >= (((size_t)k * T + 15) & ~(size_t)15) &&
+            (a.dtype == TUTEL_BF16 || a.dtype == TUTEL_F16) && a.row_counts == nullptr && a.hid && a.send && a.zero_row && a.loc && a.w1 &&
+            ((uintptr_t)m->fl_ws & 15) == 0;
+  if (fl)
+    fl = tutel_expert_gemm_gather_fl(a.x, a.M, smap, T, a.zero_row, a.w1, (int64_t)Ho * a.M, a.M, a.b1, Ho, a.hid, (int64_t)a.capacity * Ho, Ho, E,
+                                     a.capacity, Ho, a.M, a.dtype, a.act, (const uint8_t *)m->fl_ws, k * T, nullptr, (hipStream_t)stream) == 0;
+  if (fl) {
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *idx8 = (uint8_t *)m->fl_ws;
+    if (project) {
+      rc = tutel_amd_gate_proj(a.x, m->gate_w, a.dtype, T, a.M, E, m->gate_partials, m->gate_partial_bytes, stream);
+      if (rc) return rc;
+    }
+    rc = tutel_gate_topk_launch(project ? nullptr : m->logits, project ? m->gate_partials : nullptr, splits, m->logits_dtype, T, E, k,
+                                m->normalize_gate, project ? m->logits_out : nullptr, const_cast<int32_t *>(a.idx), const_cast<void *>(a.gates),
+                                m->ws, nullptr, 0, idx8, st);
+    if (rc) return rc;
+    if (m->capacity_out != nullptr) *m->capacity_out = a.capacity;
+    {
+      Range r("tutel_amd.expert_fc1");
+      rc = tutel_expert_gemm_gather_fl(a.x, a.M, smap, T, a.zero_row, a.w1, (int64_t)Ho * a.M, a.M, a.b1, Ho, a.hid, (int64_t)a.capacity * Ho, Ho,
+                                       E, a.capacity, Ho, a.M, a.dtype, a.act, idx8, k * T, const_cast<int32_t *>(a.loc), st);
+      if (rc) return rc;
+    }
+    {
+      Range r("tutel_amd.expert_fc2");
+      rc = tutel_amd_expert_gemm(a.hid, (int64_t)a.capacity * Ho, 0, a.capacity, Ho, a.w2, a.w2_kmajor, (int64_t)Ho * Mo, a.w2_kmajor ? Ho : Mo,
+                                 a.b2, Mo, a.send, (int64_t)a.capacity * Mo, 0, a.capacity, Mo, E, a.capacity, Mo, Ho, a.dtype, TUTEL_ACT_NONE,
+                                 nullptr, 1, stream);
+      if (rc) return rc;
+    }
+    Range r("tutel_amd.fast_decode");
+    RouteFinish fin;
+    tutel_route_finish_args(T, E, k, m->ws, &fin);
+    fin.on = 1;
+    fin.dispatch_count = m->dispatch_count;
+    fin.stats = m->stats;
+    fin.l_aux = m->l_aux;
+    fin.l_aux_dtype = m->logits_dtype;
+    return tutel_decode_finish_launch(a.send, a.dtype, a.idx, a.loc, a.gates, m->logits_dtype, T, Mo, k, a.capacity, E, a.y, fin, st);
+  }
   if (project && T > 0) {
     rc = tutel_amd_gate_proj(a.x, m->gate_w, a.dtype, T, a.M, E, m->gate_partials, m->gate_partial_bytes, stream);
     if (rc) return rc;

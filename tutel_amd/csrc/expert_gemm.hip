@@ -99,6 +99,7 @@ struct GemmArgs {
   bool fits32;                                                // operands addressable with 32-bit byte offsets
   bool rot_on;                                                // K-tile rotation (see launch_gemm)
   bool sgather;                                               // ring kernels: slot-map entries through the scalar cache (TUTEL_OPT_GEMM_GATHER)
+  const uint8_t *fl_idx8; int fl_n; int32_t *fl_loc;          // fused location (FL kernels): byte copy of idx [k*T], its length, loc out
   const void *mul;                                            // optional epilogue multiplier, D's layout
   const uint64_t *d_peer; long long d_peer_off;               // optional: rows of source rank w go to d_peer[w] + d_peer_off (bytes)
   PeerCanary d_can;                                           // peer stores: epoch canaries written behind the rows (common.h)
@@ -684,8 +685,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&ac
 // BM = 128 (4 waves, 2 x 2; round 4): the 128-row HBM-bound regime on a 128 x 256 tile -- every row of an expert and TWO of its
 // 128-column weight tiles per block, so the token tile crosses L2 -> LDS once per 256 columns instead of once per 128, on a
 // three-slot ring (3 x 48 KB, two K-tiles = 96 KB of DMA in flight per CU, never drained), one 4-wave block per CU.
-template <typename T, bool W_KMAJOR, int ACT, int NI, int NS, bool BUF = false, int BM = GB_BM>
+// FL (round 5, the 128 x 256 ring only): FUSED LOCATION.  On the single-rank one-call path the stable rank of every (choice, token)
+// entry inside its expert -- what location_kernel (routing.hip) computes between the top-k kernel and this GEMM: 7.3 us of dependent
+// L2 round trips on 64 workgroups while 192 CUs and HBM idle -- is recomputed HERE by every block for ITS expert, instead of being
+// waited for: the block scans the byte copy of idx (k*T bytes, 8 KB at the headline, L2-resident after the first block of an XCD
+// touched it) for its expert id, ranks the matches in (choice, token) order with one block-wide prefix sum, and keeps the first C
+// of them as its token-tile rows -- `slot_map[e][0..C)` without a launch in between, under the weight DMA of the first two K-tiles.
+// The n-tile-0 block of each expert also stores loc[] of its entries and its row of the slot map (decode and the API want them).
+// Recomputing beats synchronising: the scan is ~100 VALU operations per thread and one load round trip that was there anyway (the
+// slot-map lookup).  dispatch_count / max load / gshard loss move into an extra block of the decode launch (dispatch.hip).
+template <typename T, bool W_KMAJOR, int ACT, int NI, int NS, bool BUF = false, int BM = GB_BM, bool FL = false>
 __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) {
+  static_assert(!FL || (BUF && NS == 3 && BM == 128 && W_KMAJOR), "FL: the 128 x 256 ring kernel only");
   constexpr int NW = BM / 32;               // waves: (BM / 64) row groups x 2 column groups
   constexpr int NSUB = NI / 2;              // 128-column weight sub-tiles per stage
   constexpr int WPW = 16 * NSUB / NW;       // weight DMA pieces per wave and stage
@@ -735,13 +746,14 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
   // for the weight data.  Scalar loads count on lgkmcnt.
   constexpr bool SG = BUF && NS == 3;
   sgv8 sg_q[4];
-  const bool sg_on = SG && p.a_rows != nullptr && p.sgather;  // block-uniform
+  const bool fl_on = FL && p.fl_idx8 != nullptr;             // block-uniform
+  const bool sg_on = SG && p.a_rows != nullptr && p.sgather && !fl_on;  // block-uniform
   const unsigned long long mb_ = (unsigned long long)reinterpret_cast<uintptr_t>(p.a_rows);
   const sgv4 rs_m = {(int)(unsigned)mb_, (int)((mb_ >> 32) & 0xffff), (int)((unsigned)p.E_loc * (unsigned)p.R * 4u), 0x00020000};
   const int mo_ = (e * p.R + m0 + 32 * wid) * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) gr4[i] = min(m0 + 8 * (wid * 4 + i) + (lane >> 3), p.R - 1);
-  if (!sg_on) gather_rows4(p, e, gr4, slot4);
+  if (!sg_on && !fl_on) gather_rows4(p, e, gr4, slot4);
 #define GB_A_ADDR()                                                                                             \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
     const int r = 8 * (wid * 4 + i) + (lane >> 3);                                                             \
@@ -754,7 +766,7 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
                          : reinterpret_cast<const uint16_t *>(p.a_zero)) + c * 8;                              \
     }                                                                                                          \
   }
-  if (!sg_on) { GB_A_ADDR(); }
+  if (!sg_on && !fl_on) { GB_A_ADDR(); }
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
     const int g = wid * WPW + i, dg = g >> 4, j = g & 15;
@@ -782,7 +794,7 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
       a_off[i] = (int)0x7ffff000u + (((lane & 7) ^ ((r >> 1) & 7)) << 4);  /* empty slot / past the row count: out of range -> zeros */ \
   }
   if (BUF) {
-    if (!sg_on) { GB_A_OFF(); }
+    if (!sg_on && !fl_on) { GB_A_OFF(); }
 #pragma unroll
     for (int i = 0; i < WPW; ++i) w_off[i] = (int)(unsigned)((const char *)w_src[i] - (const char *)We);
   }
@@ -914,6 +926,21 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
     // needs everything up to A(0), i.e. all but the 4 * (NS - 2) token ops after it (NS = 3: equal to the steady-state count from
     // the second tile on, where each iteration issues [A, W] of one tile).
     static_assert(NS <= 3, "the prologue order below is worked out for rings of at most three slots");
+    // FL: the byte copy of idx goes out FIRST, as LDS-DMA into the 16 KB past the ring -- vmcnt retires in order, so being older than
+    // the weight DMA is what lets `s_waitcnt vmcnt(16)` below wait for it WITHOUT waiting for the weights (16 = the 2 x WPW weight
+    // ops every wave issues after it; as register loads hipcc placed a vmcnt(0) at their first use).  1 KB per wave instruction
+    // through a descriptor whose range is the buffer: the tail reads zeros.
+    constexpr int FL_CH = 4;  // 16-byte chunks per thread: k*T <= 15 KB of entries
+    unsigned char *s_fl = smem + (size_t)NS * (A_STAGE + NSUB * GL_STAGE) * 2;  // [15360] idx bytes, [128] slots, [4] wave totals
+    if (FL && fl_on) {
+      static_assert(!FL || WPW * (NS - 1) == 16, "the vmcnt(16) of the fused-location prologue counts the weight ops of the first two tiles");
+      const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.fl_idx8), 0, (p.fl_n + 15) & ~15, 0x00020000);
+      // wave w fetches exactly the bytes ITS threads scan (thread t owns entries [t * per, (t + 1) * per), per a multiple of 16: a
+      // wave's share is per / 16 KB): its own `s_waitcnt vmcnt(16)` is then all the ordering the reads below need -- no barrier
+      const int per_ = (((p.fl_n + 255) >> 8) + 15) & ~15, ipw = per_ >> 4;
+      for (int i = wid * ipw; i < (wid + 1) * ipw; ++i)
+        if (i < 15) bdma16<false>(rs_i, i * 1024 + lane * 16, 0, reinterpret_cast<uint16_t *>(s_fl + i * 1024));
+    }
     // (the scalar loads go out here, not at the top of the kernel: hipcc fetches kernel arguments lazily and every
     // `s_waitcnt lgkmcnt(0)` it places for them would wait for these too)
     if (sg_on) {
@@ -939,6 +966,86 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
         for (int j = 1; j < 8; ++j) q = (rl_ == j) ? sg_q[i][j] : q;
         slot4[i] = q;
       }
+      GB_A_ADDR();
+      GB_A_OFF();
+    }
+    if (FL && fl_on) {
+      int *s_slot = reinterpret_cast<int *>(s_fl + 15360);
+      int *s_wt = s_slot + 128;
+      if (tid < 128) s_slot[tid] = -1;
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // this wave's share of the idx bytes is in LDS; the weight pieces are still in flight
+      // The scan sits on the block's critical path (the token tile cannot be requested before it ends), so it is kept to a few
+      // hundred cycles: dead chunks skipped (block-uniform), the tail mask only in the one thread that crosses k*T, the wave prefix
+      // from 7 ballots over the bits of the per-thread count (<= 64) instead of 6 ds_bpermute round trips, and only threads that
+      // own a match enter the assignment loop.
+      const int per = (((p.fl_n + 255) >> 8) + 15) & ~15;  // consecutive entries per thread, a multiple of 16 (<= 64)
+      const int nch = per >> 4;                            // block-uniform
+      const int fl_e0 = tid * per;
+      const uint32_t eb = (uint32_t)e * 0x01010101u;
+      uint32_t fl_t[FL_CH][4];                             // bit 7 of every byte that equals this block's expert id
+      int cnt = 0;
+#pragma unroll
+      for (int c = 0; c < FL_CH; ++c) {
+        if (c < nch) {
+          const u32x4 v = *reinterpret_cast<const u32x4 *>(s_fl + min(fl_e0 + c * 16, 15360 - 16));
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const uint32_t x = v[d] ^ eb;
+            fl_t[c][d] = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) fl_t[c][d] = 0u;
+        }
+      }
+      if (fl_e0 + per > p.fl_n) {  // entries past k*T (the last threads only)
+#pragma unroll
+        for (int c = 0; c < FL_CH; ++c)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int nv = p.fl_n - (fl_e0 + c * 16 + d * 4);
+            fl_t[c][d] = nv >= 4 ? fl_t[c][d] : (nv <= 0 ? 0u : (fl_t[c][d] & ((1u << (8 * nv)) - 1u)));
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < FL_CH; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) cnt += __popc(fl_t[c][d]);
+      int below = 0;  // matches in the lower lanes of the wave
+#pragma unroll
+      for (int bit = 0; bit < 7; ++bit) {
+        const unsigned long long bb = __ballot((cnt >> bit) & 1);
+        below += __popcll(bb & ((1ull << lane) - 1ull)) << bit;
+      }
+      const int wtot = __shfl(below + cnt, 63, 64);
+      if (lane == 0) s_wt[wid] = wtot;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int r = below;
+      for (int w2 = 0; w2 < wid; ++w2) r += s_wt[w2];
+      const bool first_tile = nt == 0;
+      if (cnt != 0) {
+#pragma unroll
+        for (int c = 0; c < FL_CH; ++c)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            uint32_t t = fl_t[c][d];
+            while (t) {
+              const int q = fl_e0 + c * 16 + d * 4 + ((__ffs(t) - 1) >> 3);
+              if (first_tile) p.fl_loc[q] = r;
+              if (r < p.R) s_slot[r] = q;
+              ++r;
+              t &= t - 1;
+            }
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) slot4[i] = s_slot[8 * (wid * 4 + i) + (lane >> 3)];
+      if (first_tile && tid < p.R) const_cast<int32_t *>(p.a_rows)[(size_t)e * p.R + tid] = s_slot[tid];
       GB_A_ADDR();
       GB_A_OFF();
     }
@@ -1418,14 +1525,14 @@ static int launch_pp(const GemmArgs &a, hipStream_t st) {
   return ragged ? launch_pp_cfg<T, ACT, false, true>(b, st) : (early ? launch_pp_cfg<T, ACT, false, false, true>(b, st) : launch_pp_cfg<T, ACT, false>(b, st));
 }
 
-template <typename T, bool KM, int ACT, int NI, int NS = 2, bool BUF = false, int BM = GB_BM>
+template <typename T, bool KM, int ACT, int NI, int NS = 2, bool BUF = false, int BM = GB_BM, bool FL = false>
 static int launch_big(const GemmArgs &a, hipStream_t st) {
   GemmArgs b = a;
   b.ntm = (a.R + BM - 1) / BM;
   b.ntn = (a.N + NI * 64 - 1) / (NI * 64);
-  const size_t lds_k = (size_t)NS * (BM / 128 + NI / 2) * GL_STAGE * 2, lds_e = BUF ? (size_t)(BM / 32) * 64 * (NI * 64 + 16) : 0;
+  const size_t lds_k = (size_t)NS * (BM / 128 + NI / 2) * GL_STAGE * 2 + (FL ? 16384 : 0), lds_e = BUF ? (size_t)(BM / 32) * 64 * (NI * 64 + 16) : 0;
   const size_t lds = lds_k > lds_e ? lds_k : lds_e;
-  auto kern = expert_gemm_big_kernel<T, KM, ACT, NI, NS, BUF, BM>;
+  auto kern = expert_gemm_big_kernel<T, KM, ACT, NI, NS, BUF, BM, FL>;
   if (!lds_optin((const void *)kern, lds)) return -1;
   hipLaunchKernelGGL(kern, dim3(a.E_loc * b.ntm * b.ntn), dim3(BM * 2), lds, st, b);
   TUTEL_CHECK_LAUNCH("tutel_amd_expert_gemm");
@@ -1536,8 +1643,16 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   // the chip (one 144 KB block per CU): with fewer tiles the 128 x 128 kernel's twice as many blocks keep more CUs busy.
   // TUTEL_OPT_GEMM_IMPL = 4 forces it (where it applies), 1 forces the 128 x 128 LDS-DMA kernel.
   const bool ring256_ok = KM && a.fits32 && a.N >= 256 && a.R <= GM_BM;
-  if (ring256_ok && (impl == 4 || (impl < 0 && (long long)a.E_loc * ((a.N + 255) / 256) >= 256)))
-    return launch_big<T, true, ACT, 4, 3, true, 128>(a, st);
+  const bool ring256 = ring256_ok && (impl == 4 || (impl < 0 && (long long)a.E_loc * ((a.N + 255) / 256) >= 256));
+  if (a.fl_idx8 != nullptr) {  // fused location: only the ring kernel has it (the caller asked tutel_expert_gemm_gather_fl first)
+    if (!(ring256 && KM && a.a_rows != nullptr && a.row_counts == nullptr && a.fl_n >= 1 && a.fl_n <= 15360 && a.E_loc <= 128)) {
+      tutel_set_error("tutel_expert_gemm_gather_fl: this launch does not take the fused-location ring kernel");
+      return TUTEL_AMD_ENOTSUP;
+    }
+    if (a.fl_loc == nullptr) return 0;  // eligibility query
+    return launch_big<T, true, ACT, 4, 3, true, 128, KM>(a, st);   // (FL = KM: the n-major instantiations never reach this line)
+  }
+  if (ring256) return launch_big<T, true, ACT, 4, 3, true, 128>(a, st);
   const bool use_dma = impl < 0 ? KM : (impl == 1 || impl == 4);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
   return launch_cfg<T, KM, ACT>(a, grid, st);
@@ -1563,7 +1678,8 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
                                      const int32_t *row_counts, int row_align,
                                      const int32_t *a_rows, int a_rows_mod, const void *a_zero,
                                      const void *mul, tutel_stream_t stream, const uint64_t *d_peer = nullptr,
-                                     int64_t d_peer_off = 0, const PeerCanary *d_can = nullptr) {
+                                     int64_t d_peer_off = 0, const PeerCanary *d_can = nullptr, const uint8_t *fl_idx8 = nullptr,
+                                     int fl_n = 0, int32_t *fl_loc = nullptr) {
   TUTEL_REQUIRE(dtype == TUTEL_BF16 || dtype == TUTEL_F16, "tutel_amd_expert_gemm: dtype must be bf16 or fp16 (got %d)", dtype);
   TUTEL_REQUIRE(E_loc >= 0 && R >= 0 && N >= 1 && K >= 1, "tutel_amd_expert_gemm: bad sizes E_loc=%d R=%d N=%d K=%d", E_loc, R, N, K);
   TUTEL_REQUIRE(K % 64 == 0, "tutel_amd_expert_gemm: K=%d must be a multiple of 64", K);
@@ -1608,6 +1724,7 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   a.rot_on = R < GB_BM;
   a.sgather = tutel_get_option(TUTEL_OPT_GEMM_GATHER) != 0 && (long long)E_loc * R * 4 < 0x7fffffffLL;
   a.mul = mul;
+  a.fl_idx8 = fl_idx8; a.fl_n = fl_n; a.fl_loc = fl_loc;
   a.d_peer = d_peer; a.d_peer_off = d_peer_off;
   a.d_can = d_can != nullptr ? *d_can : PeerCanary{nullptr, 0, 0, 0};
   TUTEL_REQUIRE(((uintptr_t)mul % 8) == 0, "tutel_amd_expert_gemm_glu: gating operand must be 8-byte aligned");
@@ -1621,10 +1738,14 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   hipStream_t st = (hipStream_t)stream;
   // per-stage timing: the launch with a fused activation is fc1, the one without is fc2 (callers that know better --
   // the native pipeline -- set a hint)
+  auto go = [&]() -> int {
+    if (dtype == TUTEL_BF16)
+      return w_kmajor ? launch_gemm_act<bf16_t, true>(a, act, grid, st) : launch_gemm_act<bf16_t, false>(a, act, grid, st);
+    return w_kmajor ? launch_gemm_act<f16_t, true>(a, act, grid, st) : launch_gemm_act<f16_t, false>(a, act, grid, st);
+  };
+  if (fl_idx8 != nullptr && fl_loc == nullptr) return go();  // eligibility query of the fused-location path: nothing is launched, nothing timed
   StageScope stage(act != TUTEL_ACT_NONE ? TUTEL_STAGE_FC1 : TUTEL_STAGE_FC2, st);
-  if (dtype == TUTEL_BF16)
-    return w_kmajor ? launch_gemm_act<bf16_t, true>(a, act, grid, st) : launch_gemm_act<bf16_t, false>(a, act, grid, st);
-  return w_kmajor ? launch_gemm_act<f16_t, true>(a, act, grid, st) : launch_gemm_act<f16_t, false>(a, act, grid, st);
+  return go();
 }
 
 extern "C" int tutel_amd_expert_gemm(const void *A, int64_t a_stride_e, int64_t a_stride_w,
@@ -1648,6 +1769,18 @@ int tutel_expert_gemm_peer(const void *A, int64_t a_stride_e, int64_t a_stride_w
   return expert_gemm_impl(A, a_stride_e, a_stride_w, a_rows_per_w, lda, W, w_kmajor, w_stride_e, ldw, bias, bias_stride_e, nullptr,
                           d_stride_e, 0, d_rows_per_w, ldd, E_loc, R, N, K, dtype, act, nullptr, 1, nullptr, 0, nullptr, nullptr,
                           (tutel_stream_t)st, d_peer, d_peer_off, &can);
+}
+
+// tutel_amd_expert_gemm_gather with the locations computed INSIDE the launch (see the FL comment at expert_gemm_big_kernel): the
+// kernel fills slot_map [E_loc * R] and loc [n] itself from idx8 [n] (n = k * T bytes, buffer padded to 16).  loc == NULL: only
+// answers whether this shape takes the fused kernel (0) or not (TUTEL_AMD_ENOTSUP) -- nothing is launched.
+int tutel_expert_gemm_gather_fl(const void *X, int ldx, int32_t *slot_map, int T, const void *zero_row, const void *W, int64_t w_stride_e,
+                                int ldw, const void *bias, int64_t bias_stride_e, void *D, int64_t d_stride_e, int ldd, int E_loc, int R,
+                                int N, int K, int dtype, int act, const uint8_t *idx8, int n, int32_t *loc, hipStream_t st) {
+  TUTEL_REQUIRE(slot_map != nullptr && idx8 != nullptr && T >= 1 && ((uintptr_t)idx8 & 15) == 0, "tutel_expert_gemm_gather_fl: bad arguments");
+  if (tutel_get_option(TUTEL_OPT_FUSED_LOCATION) == 0) return TUTEL_AMD_ENOTSUP;
+  return expert_gemm_impl(X, 0, 0, R > 0 ? R : 1, ldx, W, 1, w_stride_e, ldw, bias, bias_stride_e, D, d_stride_e, 0, R > 0 ? R : 1, ldd, E_loc,
+                          R, N, K, dtype, act, nullptr, 1, slot_map, T, zero_row, nullptr, (tutel_stream_t)st, nullptr, 0, nullptr, idx8, n, loc);
 }
 
 extern "C" int tutel_amd_expert_gemm_glu(const void *A, int64_t a_stride_e, int64_t a_stride_w,

@@ -228,7 +228,7 @@ extern "C" int tutel_amd_gate_proj(const void *x, const void *wg, int dtype, int
   TUTEL_REQUIRE(partial_bytes >= (size_t)pl.splits * T * E * sizeof(float), "tutel_amd_gate_proj: partials buffer too small (%zu < %zu)",
                 partial_bytes, (size_t)pl.splits * T * E * sizeof(float));
   hipStream_t st = (hipStream_t)stream;
-  StageScope stage(TUTEL_STAGE_GATE_TOPK, st);
+  StageScope stage(TUTEL_STAGE_GATE_PROJ, st);
   if (dtype == TUTEL_BF16) return gp_dispatch<bf16_t>(pl, x, wg, T, M, E, partials, st);
   return gp_dispatch<f16_t>(pl, x, wg, T, M, E, partials, st);
 }

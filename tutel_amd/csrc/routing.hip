@@ -20,9 +20,8 @@
 // Index outputs are integers and bit-exact against the reference CPU path; gates follow its
 // per-op rounding in the scores dtype.
 #include "common.h"
+#include "routing_dev.h"
 
-#define RT_THREADS 256
-#define RT_WAVES 4
 #define GT_THREADS 1024  // gate_topk: 16 waves per tile, 4 interleaved tokens per wave
 #define GT_WAVES 16
 #define RT_MAX_TILES 128
@@ -243,67 +242,6 @@ __global__ __launch_bounds__(RT_THREADS) void tile_hist_kernel(const int32_t *__
 // behind a hand-rolled grid barrier; measured equal to two launches, and a grid barrier without a residency check is a hang
 // waiting for a partitioned device, so round 4 removed it.)
 // -------------------------------------------------------------------------------------------
-// COH = the fused kernel: data another block of the SAME launch wrote (or will overwrite) moves with device-scope relaxed atomics
-// (sc1 accesses: coherent across the XCDs' L2s without a cache-wide write-back / invalidate -- a device-scope release + acquire
-// fence pair around the barrier cost 25 us of a 40 us kernel, profiles/r03_routing_fused.txt).
-template <bool COH> __device__ __forceinline__ int ld_i32(const int32_t *p) {
-  return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <bool COH> __device__ __forceinline__ float ld_f32(const float *p) {
-  return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <bool COH> __device__ __forceinline__ void st_i32(int32_t *p, int v) {
-  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-template <bool COH> __device__ __forceinline__ void st_f32(float *p, float v) {
-  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-
-// phases 1 + 2: s_cur[j][e] = absolute location of the tile's first token that picks (choice j, expert e); s_tot[j][e] = totals
-template <int NW, bool COH = false>
-__device__ __forceinline__ void loc_prefix(int tid, int b, int E, int k, int ntiles, const int32_t *__restrict__ ws_hist,
-                                           int32_t *s_cur, int32_t *s_tot, int32_t *__restrict__ dispatch_count) {
-  const int lane = tid & 63, wid = tid >> 6, kE = k * E;
-  // base[j][e] = sum over earlier tiles, tot[j][e] = sum over all tiles.  The tile axis is
-  // split over the waves and unrolled so the (<=128) dependent-free L2 loads overlap.
-  for (int i = tid; i < kE; i += NW * 64) { s_cur[i] = 0; s_tot[i] = 0; }
-  __syncthreads();
-  for (int i = lane; i < kE; i += 64) {
-    int base = 0, tot = 0;
-    for (int tl0 = wid; tl0 < ntiles; tl0 += NW * 16) {
-      int h[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        int tl = tl0 + u * NW;
-        h[u] = (tl < ntiles) ? ld_i32<COH>(ws_hist + (size_t)tl * kE + i) : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        int tl = tl0 + u * NW;
-        tot += h[u];
-        if (tl < b) base += h[u];
-      }
-    }
-    if (wid < ntiles) {   // (waves past the tile count hold zeros)
-      atomicAdd(&s_cur[i], base);
-      atomicAdd(&s_tot[i], tot);
-    }
-  }
-  __syncthreads();
-  // choice j is queued after ALL tokens' choices < j (fast_dispatch.py:165-169)
-  for (int e = tid; e < E; e += NW * 64) {
-    int acc = 0;
-    for (int j = 0; j < k; ++j) {
-      s_cur[j * E + e] += acc;
-      acc += s_tot[j * E + e];
-    }
-    if (b == 0) dispatch_count[e] = acc;
-  }
-  __syncthreads();
-}
-
 // phase 3: stable rank inside the tile: a wave handles one choice, 64 tokens per step.  `lidx` (optional): the tile's expert
 // ids in LDS, [k][t1 - t0 rounded up to the tile]; `e_first`: the wave's first 64 ids when the caller loaded them early.
 template <int NW, bool COH = false>
@@ -340,73 +278,6 @@ __device__ __forceinline__ void loc_rank(int tid, int t0, int t1, int Tn, int E,
         loc[(size_t)j * Tn + t] = valid ? l : 0;
         if (slot_map != nullptr && valid && l < capacity) st_i32<COH>(slot_map + (size_t)e * capacity + l, j * Tn + t);
       }
-    }
-  }
-}
-
-// phase 4 (one block): max count and gshard loss.  Column sums: `parts` threads per expert, each a contiguous tile range in
-// fixed order, combined in fixed order.  The arithmetic is done by the block's first RT_THREADS threads in BOTH kernels, so the
-// loss does not depend on which kernel computed it (deterministic, bit for bit).
-template <int NW, bool COH = false>
-__device__ __forceinline__ void loc_finish(int tid, int Tn, int E, int k, int ntiles, const float *__restrict__ ws_colsum,
-                                           const int32_t *s_tot, float *s_parts, float *s_red, int *s_redi, const float *cs_first,
-                                           bool cs_early, int32_t *__restrict__ stats, void *__restrict__ l_aux, int l_aux_dtype) {
-  const int lane = tid & 63, wid = tid >> 6;
-  const bool act = tid < RT_THREADS;
-  const int cs_parts = (E >= RT_THREADS) ? 1 : (RT_THREADS / E);
-  const int cs_per = (ntiles + cs_parts - 1) / cs_parts;
-  int mx = 0;
-  if (act)
-    for (int e = tid; e < E; e += RT_THREADS) {
-      int acc = 0;
-      for (int j = 0; j < k; ++j) acc += s_tot[j * E + e];
-      mx = max(mx, acc);
-    }
-  float part = 0.f;
-  if (l_aux != nullptr) {
-    __syncthreads();
-    const int parts = cs_parts, per = cs_per;
-    if (act)
-      for (int w = tid; w < parts * E; w += RT_THREADS) {
-        const int e = w % E, pt = w / E;
-        const int a = pt * per, z = min(ntiles, a + per);
-        float me = 0.f;
-        for (int tl0 = a; tl0 < z; tl0 += 16) {
-          float cs[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            cs[u] = (cs_early && tl0 == a) ? cs_first[u] : ((tl0 + u < z) ? ld_f32<COH>(ws_colsum + (size_t)(tl0 + u) * E + e) : 0.f);
-#pragma unroll
-          for (int u = 0; u < 16; ++u) me += cs[u];
-        }
-        s_parts[pt * E + e] = me;
-      }
-    __syncthreads();
-    if (act)
-      for (int e = tid; e < E; e += RT_THREADS) {
-        float me = 0.f;
-        for (int pt = 0; pt < parts; ++pt) me += s_parts[pt * E + e];
-        float ce = (float)s_tot[e] * ((float)E / (float)Tn);
-        part += me * ce;
-      }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mx = max(mx, __shfl_xor(mx, o, 64));
-    part += __shfl_xor(part, o, 64);
-  }
-  if (act && lane == 0) { s_red[wid] = part; s_redi[wid] = mx; }
-  __syncthreads();
-  if (tid == 0) {
-    float p = 0.f;
-    int m2 = 0;
-    for (int w = 0; w < RT_WAVES; ++w) { p += s_red[w]; m2 = max(m2, s_redi[w]); }
-    if (stats != nullptr) stats[0] = m2;
-    if (l_aux != nullptr) {
-      const float la = p / (float)Tn;
-      if (l_aux_dtype == TUTEL_F32) reinterpret_cast<float *>(l_aux)[0] = la;
-      else if (l_aux_dtype == TUTEL_BF16) reinterpret_cast<uint16_t *>(l_aux)[0] = f32_to_bf16_bits(la);
-      else reinterpret_cast<_Float16 *>(l_aux)[0] = (_Float16)la;
     }
   }
 }
@@ -479,7 +350,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
-    int clear_n, const float *__restrict__ part, int nsplit, T *__restrict__ logits_out) {
+    int clear_n, const float *__restrict__ part, int nsplit, T *__restrict__ logits_out, uint8_t *__restrict__ idx8) {
   using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ES = GQ_LPT * EPQ + 1;                                    // padded row of the score tile
@@ -614,6 +485,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       if (c == q) myg = bv;                              // choice c parked on lane c of the row (k <= 16)
       if (q == 0 && live) {
         idx[(size_t)c * Tn + t] = be;
+        if (idx8 != nullptr) idx8[(size_t)c * Tn + t] = (uint8_t)be;  // byte copy for the in-GEMM location scan (expert_gemm.hip, FL)
         atomicAdd(&s_hist[c * E + be], 1);
       }
     }
@@ -685,7 +557,7 @@ template <typename T>
 static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, int k, int normalize,
                             void *scores_out, int32_t *idx, void *gates, void *ws,
                             int32_t *clear_map, int clear_n, hipStream_t st, const float *part = nullptr, int nsplit = 0,
-                            void *logits_out = nullptr) {
+                            void *logits_out = nullptr, uint8_t *idx8 = nullptr) {
   const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
@@ -697,7 +569,7 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
 #define GQ_LAUNCH(EPQ)                                                                         \
     hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ>), dim3(nt), dim3(GQ_THREADS), lds_q, st,            \
                        (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,          \
-                       idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, part, nsplit, (T *)logits_out)
+                       idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, part, nsplit, (T *)logits_out, idx8)
     if (epq_t == 1) GQ_LAUNCH(1);
     else if (epq_t == 2) GQ_LAUNCH(2);
     else if (epq_t == 4) GQ_LAUNCH(4);
@@ -706,7 +578,7 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
     TUTEL_CHECK_LAUNCH("tutel_amd_gate_topk");
     return 0;
   }
-  TUTEL_REQUIRE(part == nullptr, "tutel_amd_gate_topk_partials: E = %d is past the 128 experts the partial-sum form covers", E);
+  TUTEL_REQUIRE(part == nullptr && idx8 == nullptr, "tutel_amd_gate_topk_partials: E = %d is past the 128 experts the partial-sum form covers", E);
   const int epl = (E + 63) / 64;
 #define GT_LAUNCH(EPL)                                                                          \
   do {                                                                                          \
@@ -750,6 +622,28 @@ extern "C" int tutel_amd_gate_topk(const void *in, int dtype, int apply_softmax,
   if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
   return launch_gate_topk<f16_t>(in, apply_softmax, T, E, k, normalize_gate, scores_out, idx, gates, ws, clear_map, clear_n, st);
+}
+
+// internal (common.h): where the top-k kernel left the per-tile histograms / column sums of a (T, E, k) problem inside `ws`
+void tutel_route_finish_args(int T, int E, int k, void *ws, RouteFinish *out) {
+  const int nt = rt_ntiles(T);
+  out->Tn = T; out->E = E; out->k = k; out->ntiles = nt;
+  out->ws_hist = (const int32_t *)ws;
+  out->ws_colsum = (const float *)((const int32_t *)ws + (size_t)nt * k * E);
+}
+
+// internal (common.h): either form of the top-k launch (logits `in`, or split-K partial sums), plus the byte copy of idx that the
+// fused-location expert GEMM scans.  Arguments are the callers' (ep.hip), already validated by the public entry points' rules.
+int tutel_gate_topk_launch(const void *in, const float *partials, int splits, int dtype, int T, int E, int k, int normalize_gate,
+                           void *logits_out, int32_t *idx, void *gates, void *ws, int32_t *clear_map, int clear_n, uint8_t *idx8,
+                           hipStream_t st) {
+  TUTEL_REQUIRE(E <= 128 || (partials == nullptr && idx8 == nullptr), "tutel_gate_topk_launch: E = %d is past the 16-lanes-per-token kernel", E);
+  if (clear_n == 0) clear_map = nullptr;
+  StageScope stage(TUTEL_STAGE_GATE_TOPK, st);
+  const int sm = 1;
+  if (dtype == TUTEL_F32) return launch_gate_topk<float>(in, sm, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear_map, clear_n, st, partials, splits, logits_out, idx8);
+  if (dtype == TUTEL_BF16) return launch_gate_topk<bf16_t>(in, sm, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear_map, clear_n, st, partials, splits, logits_out, idx8);
+  return launch_gate_topk<f16_t>(in, sm, T, E, k, normalize_gate, nullptr, idx, gates, ws, clear_map, clear_n, st, partials, splits, logits_out, idx8);
 }
 
 extern "C" int tutel_amd_gate_topk_partials(const float *partials, int splits, int dtype, int T, int E, int k,

@@ -26,6 +26,7 @@ from .. import _lib, ops
 
 ENABLED = int(os.environ.get("TUTEL_AMD_NATIVE_EP", "1")) != 0
 FAST_PATH = int(os.environ.get("TUTEL_AMD_FAST_PATH", "1")) != 0  # routing + pipeline in one call (tutel_amd_moe_forward)
+_FUSED_LOCATION = int(os.environ.get("TUTEL_AMD_FUSED_LOCATION", "1")) != 0  # hand the one-call path its fused-location scratch (single rank)
 HOSTED = int(os.environ.get("TUTEL_AMD_NATIVE_HOSTED", "0")) != 0  # bring-up / tests: native pipeline over a gloo group, exchange staged by the host
 # How the bucket rows travel between the ranks of a node:
 #   "auto"  peer stores over xGMI (IPC transport, csrc/ep.hip) when every rank can map every other rank's segment and the tagged
@@ -650,6 +651,11 @@ class _MoeWorkspace(_Workspace):
         m.capacity_out = ctypes.pointer(self.cap_c)
         self.margs = m
         self.gate_partials, self.gate_partials_keep = None, []   # split-K partial sums of the in-call gate projection (on demand)
+        # fused location (single rank; csrc/expert_gemm.hip FL kernels): the top-k kernel's byte copy of idx, k * T bytes padded to 16
+        self.fl_ws = None
+        if comm is None and _FUSED_LOCATION:
+            self.fl_ws = torch.empty([(k * T + 15) // 16 * 16 + 16], dtype=torch.uint8, device=dev)
+            m.fl_ws, m.fl_ws_bytes = self.fl_ws.data_ptr(), self.fl_ws.numel()
 
 
 def forward_from_logits(layer, x, logits, k, capacity, degree, normalize_gate, want_loss, dropless=None, megablocks_size=0, gate_w=None):
