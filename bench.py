@@ -699,7 +699,11 @@ def main():
                     "avg_launch_us": round(fc1_us, 2), "launches_timed": fc1_n, "fc2_gemm": fc2_obj}
     else:
         gbs = gemm_bytes / fc1_us * 1e-3
-        roofline = {"bound": "hbm", "kernel": f"expert_gemm_big_kernel<{dname},k-major,relu,NI=4,NS=3,BUF,BM=128> (fc1 grouped GEMM: 128 x 256 tile, three-slot LDS-DMA ring)",
+        fused_loc = "location" not in stage_us
+        roofline = {"bound": "hbm", "kernel": f"expert_gemm_big_kernel<{dname},k-major,relu,NI=4,NS=3,BUF,BM=128{',FL' if fused_loc else ''}> (fc1 grouped GEMM: 128 x 256 tile, "
+                                              "three-slot LDS-DMA ring" + ("; fast_encode's row gather AND the location step run inside this launch (round 5: no "
+                                                                           "compute_location kernel between top-k and fc1; its ~3 us show up here, the 7.3 us "
+                                                                           "kernel is gone)" if fused_loc else "") + ")",
                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                     "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4), "achievable_GBs": HBM_ACHIEVABLE_GBS, "traffic": traffic,
                     "traffic_over_algorithmic": round(traffic / gemm_bytes, 4) if traffic else None, "traffic_note": traffic_note,
@@ -797,7 +801,42 @@ def main():
                 el2, _, _, _ = run_timed(lambda t: lay2(t, megablocks_size=4), x, 30, 1, gt2, mode=0, marks=False)
                 _, _, st2, _ = run_timed(lambda t: lay2(t, megablocks_size=4), x, 30, 1, gt2, mode=2, marks=False)
             ms2 = el2 / 30 * 1e3
-            out["extra"] = {"dropless_configs2": {
+            # round 5's three changes to the headline path, each switched off in turn (graph replay of the same forward, 3 x 20 steps)
+            feat = {}
+            try:
+                from tutel_amd import _lib, ops
+                from tutel_amd.impls import moe_layer as _ML
+                from tutel_amd.impls.graph import GraphedForward as _GF
+
+                def _replay_ms():
+                    layer.__dict__.pop("_ep_workspaces", None)
+                    with torch.no_grad():
+                        gfx = _GF(layer, x, **fwd_kw)
+                        for _ in range(60):
+                            gfx(gfx.static_in)
+                        ts = [run_timed(gfx, gfx.static_in, 20, 1, gate_timer, mode=0, marks=False)[0] / 20 * 1e3 for _ in range(3)]
+                    return round(sorted(ts)[1], 4)
+                feat["all on (as timed)"] = _replay_ms()
+                ops.set_option(_lib.OPT_FUSED_LOCATION, 0)
+                feat["location kernel instead of the in-GEMM scan"] = _replay_ms()
+                ops.set_option(_lib.OPT_FUSED_LOCATION, -1)
+                ops.set_option(_lib.OPT_GEMM_GATHER, 0)
+                ops.set_option(_lib.OPT_FUSED_LOCATION, 0)
+                feat["fused location off + vector slot-map lookups in front of the weight DMA"] = _replay_ms()
+                ops.set_option(_lib.OPT_GEMM_GATHER, -1)
+                ops.set_option(_lib.OPT_FUSED_LOCATION, -1)
+                _ML._NATIVE_GATE = False
+                feat["gate projection by F.linear (hipBLASLt) instead of the split-K kernel"] = _replay_ms()
+            except Exception as ex:   # noqa: BLE001
+                feat["error"] = f"{type(ex).__name__}: {str(ex)[:200]}"
+            finally:
+                from tutel_amd import _lib, ops
+                from tutel_amd.impls import moe_layer as _ML
+                _ML._NATIVE_GATE = True
+                ops.set_option(_lib.OPT_GEMM_GATHER, -1)
+                ops.set_option(_lib.OPT_FUSED_LOCATION, -1)
+                layer.__dict__.pop("_ep_workspaces", None)
+            out["extra"] = {"round5_features_ms_per_step": feat, "dropless_configs2": {
                 "workload": "BASELINE.json configs[2]: same shape, capacity_factor 0 (capacity = max expert load, read back each step), megablocks_size 4",
                 "value": round(T / (el2 / 30), 1), "unit": "tokens/s", "ms_per_step": round(ms2, 4), "steps": 30,
                 "capacity": int(lay2.protected_shape[1]),

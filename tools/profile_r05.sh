@@ -16,7 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py 
 python - <<'PY'
 import csv, glob, collections, hashlib, json, os
 out = "gpurun_out/prof_r05"
-FC1 = "expert_gemm_big_kernel<bf16_t, true, 1, 4, 3, true, 128>"   # the 128 x 256 ring kernel with the fused ReLU epilogue = fc1
+FC1 = "expert_gemm_big_kernel<bf16_t, true, 1, 4, 3, true, 128, true>"   # the 128 x 256 ring kernel, fused ReLU epilogue + fused location = fc1
 val = {}
 for name in ("fetch", "write"):
     acc = collections.defaultdict(lambda: [0.0, 0])
@@ -34,7 +34,7 @@ for st in glob.glob(f"{out}/bench_n1/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(st)):
         if FC1 in r["Name"]:
             avg_us, kern = float(r["AverageNs"]) * 1e-3, r["Name"]
-        if "decode_kernel<bf16_t, 2," in r["Name"]:
+        if "decode_kernel<bf16_t, 2," in r["Name"] or "decode_fin_kernel<bf16_t, 2>" in r["Name"]:
             dec_us, dec_kern = float(r["AverageNs"]) * 1e-3, r["Name"][:60]
 h = hashlib.sha256()
 for f in ("expert_gemm.hip", "common.h"):
