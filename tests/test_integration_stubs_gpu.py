@@ -103,3 +103,29 @@ def test_b3_expert_gemm_stub(ns, oracle):
         h2 = gemm(x.cuda(), w1.cuda(), b1.cuda(), True, 1, counts.cuda(), 4)
         for e, c in enumerate([160, 40, 0]):
             assert torch.equal(h2[e, :c], h[e, :c])
+
+
+def test_b6_gate_projection_stub(ns, oracle):
+    """B.6: the gate projection of a 16-bit gate through the split-K kernel + top-k on its partial sums, executed verbatim from the
+    markdown: the logits it returns equal x @ wg^T to an ulp of the dtype, and idx / gates equal the oracle's routing on those logits."""
+    from tutel_amd import ops
+    blocks = _blocks("B.6")
+    T, M, E, k = 1500, 512, 32, 2
+    for dtype in (torch.bfloat16, torch.float16):
+        g = torch.Generator().manual_seed(13)
+        x = torch.randn([T, M], generator=g).to(dtype).cuda()
+        gate = torch.nn.Module()
+        gate.wg = torch.nn.Linear(M, E, bias=False).to(dtype).cuda()
+        env = dict(ns)
+        env.update(T=T, M=M, E=E, k=k, dev=torch.device("cuda"), x=x, gate=gate, capacity=k * ((T + E - 1) // E), normalize_gate=True)
+        exec(compile(blocks[0], "INTEGRATION.md:B.6[0]", "exec"), env)
+        torch.cuda.synchronize()
+        assert env["S"] >= 1
+        with torch.no_grad():
+            ref = x.float() @ gate.wg.weight.float().t()
+        ulp = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+        assert float((env["logits"].float() - ref).abs().max()) <= ulp * max(1.0, float(ref.abs().max()))
+        scores = ops.gate_topk(env["logits"], k, apply_softmax=True, want_scores=True)[3].cpu()
+        crit, _ = oracle.extract_critical(scores, k, 1.0)
+        assert torch.equal(env["idx"].cpu(), torch.stack(crit[1]).to(torch.int32))
+        assert torch.equal(env["gates"].cpu(), torch.stack(crit[3]).to(dtype))

@@ -1600,6 +1600,18 @@ static int launch_cfg(const GemmArgs &a, int grid, hipStream_t st) {
 template <typename T, bool KM, int ACT>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   const int impl = tutel_get_option(TUTEL_OPT_GEMM_IMPL), big = tutel_get_option(TUTEL_OPT_GEMM_TILE);
+  const bool ring256_ok = KM && a.fits32 && a.N >= 256 && a.R <= GM_BM;
+  const bool ring256 = ring256_ok && (impl == 4 || (impl < 0 && (long long)a.E_loc * ((a.N + 255) / 256) >= 256));
+  // Fused location FIRST: a request for it (or the eligibility query, fl_loc == NULL) must never fall into one of the launches
+  // below -- only the 128 x 256 ring kernel has the fused form (capacity <= 128 rows per expert), and a query launches nothing.
+  if (a.fl_idx8 != nullptr) {
+    if (!(ring256 && KM && big <= 0 && a.a_rows != nullptr && a.row_counts == nullptr && a.fl_n >= 1 && a.fl_n <= 15360 && a.E_loc <= 128)) {
+      tutel_set_error("tutel_expert_gemm_gather_fl: this launch does not take the fused-location ring kernel");
+      return TUTEL_AMD_ENOTSUP;
+    }
+    if (a.fl_loc == nullptr) return 0;  // eligibility query
+    return launch_big<T, true, ACT, 4, 3, true, 128, KM>(a, st);   // (FL = KM: the n-major instantiations never reach this line)
+  }
   // R > 128 rows per expert: the 256-row tiles (more flop per byte crossing L2 -> CU) -- provided the grid
   // still covers the chip: one such block occupies a CU, so with fewer than ~3/4 x 256 blocks CUs sit idle.
   // 256 x 256 first, 256 x 128 when only that fills the chip (a pipeline stage of the overlapped
@@ -1642,16 +1654,6 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   // 111.9 -> 106.6 us, the forward 264.0 -> 258.4 us, same bits (profiles/r04_headline_ab.json).  Only when the grid still covers
   // the chip (one 144 KB block per CU): with fewer tiles the 128 x 128 kernel's twice as many blocks keep more CUs busy.
   // TUTEL_OPT_GEMM_IMPL = 4 forces it (where it applies), 1 forces the 128 x 128 LDS-DMA kernel.
-  const bool ring256_ok = KM && a.fits32 && a.N >= 256 && a.R <= GM_BM;
-  const bool ring256 = ring256_ok && (impl == 4 || (impl < 0 && (long long)a.E_loc * ((a.N + 255) / 256) >= 256));
-  if (a.fl_idx8 != nullptr) {  // fused location: only the ring kernel has it (the caller asked tutel_expert_gemm_gather_fl first)
-    if (!(ring256 && KM && a.a_rows != nullptr && a.row_counts == nullptr && a.fl_n >= 1 && a.fl_n <= 15360 && a.E_loc <= 128)) {
-      tutel_set_error("tutel_expert_gemm_gather_fl: this launch does not take the fused-location ring kernel");
-      return TUTEL_AMD_ENOTSUP;
-    }
-    if (a.fl_loc == nullptr) return 0;  // eligibility query
-    return launch_big<T, true, ACT, 4, 3, true, 128, KM>(a, st);   // (FL = KM: the n-major instantiations never reach this line)
-  }
   if (ring256) return launch_big<T, true, ACT, 4, 3, true, 128>(a, st);
   const bool use_dma = impl < 0 ? KM : (impl == 1 || impl == 4);
   if (use_dma) return launch_glds<T, KM, ACT>(a, grid, st);
