@@ -37,12 +37,14 @@ every launch (`stages`) -- all live, inside this script, on the same tensors.
 
 `roofline`: the dominant kernel is the fc1 grouped GEMM.  N = 1 (128 rows per expert):
 expert_gemm_big_kernel<bf16,k-major,relu,128 x 256 tile on a three-slot LDS-DMA ring> (round 4; rounds 1-3:
-expert_gemm_glds_kernel, 128 x 128), HBM-bound; achieved = algorithmic bytes per launch
+expert_gemm_glds_kernel, 128 x 128) -- since round 5 its FL form, which also does fast_encode's row gather and the location step
+(no compute_location launch; `extra.round5_features_ms_per_step` switches that, the scalar slot-map lookups and the split-K gate
+projection off one at a time) --, HBM-bound; achieved = algorithmic bytes per launch
 (E_loc*H*M weights + E_loc*R*M tokens + E_loc*R*H hidden out, x2 bytes) / its average duration.
 256 rows or more per expert and launch (N > 1, --tokens 65536): expert_gemm_pp_kernel, MFMA-bound; achieved = flop
 per launch / its average duration.
 `roofline.traffic` / `roofline.frac_rocprof` come from profiles/traffic.json (PMC FETCH_SIZE / WRITE_SIZE passes and the rocprofv3
-kernel-trace average of the same command, written by tools/profile_r04.sh) and are emitted only while the sha256 of
+kernel-trace average of the same command, written by tools/profile_r05.sh) and are emitted only while the sha256 of
 csrc/expert_gemm.hip equals the one stamped there -- otherwise null with the reason.  `decode` and `extra.ep8_rank_gemms` are
 roofline objects of the second / third kernels of interest (fast_decode; the grouped GEMM at the per-rank shapes of an 8-way
 expert-parallel run: one pipeline stage, and the whole rank).
@@ -682,7 +684,7 @@ def main():
         have = source_sha()
         if tj.get("expert_gemm_hip_sha256") != have:
             traffic_note = (f"stale: profiles/traffic.json was measured on csrc/expert_gemm.hip sha256 {str(tj.get('expert_gemm_hip_sha256'))[:12]}, "
-                            f"the library was built from {have[:12]} -- re-run tools/profile_r04.sh")
+                            f"the library was built from {have[:12]} -- re-run tools/profile_r05.sh")
         else:
             traffic = tj.get("expert_gemm_fc1_hbm_bytes_per_launch")
             rocprof_us = tj.get("expert_gemm_fc1_avg_us_rocprofv3")

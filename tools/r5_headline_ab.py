@@ -106,6 +106,7 @@ def main():
         # fc1's fused fast_encode: slot-map entries through the scalar cache, waited for after the first weight pieces went out (1)
         # vs four vector loads in front of the first DMA (0, rounds 1-4)
         res["scalar_gather"] = {}
+        ops.set_option(_lib.OPT_FUSED_LOCATION, 0)   # (with the fused location on, the ring kernel takes its rows from the in-kernel scan)
         for rnd in range(3):
             for mode in (0, 1):
                 ops.set_option(_lib.OPT_GEMM_GATHER, mode)
@@ -124,6 +125,7 @@ def main():
                 _lib.lib().tutel_amd_stage_timing(0)
                 res["scalar_gather"].setdefault("eager fc1 / fc2 us, mode %d" % mode, []).append([round(tot[3] / max(cnt[3], 1), 2), round(tot[4] / max(cnt[4], 1), 2)])
         ops.set_option(_lib.OPT_GEMM_GATHER, -1)
+        ops.set_option(_lib.OPT_FUSED_LOCATION, -1)
         print(json.dumps(res["scalar_gather"], indent=0), flush=True)
 
     if "l" in sections:

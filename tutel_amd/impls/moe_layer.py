@@ -378,8 +378,14 @@ class MOELayer(torch.nn.Module):
                 res = self._run_native_moe(x, spec, top_k, cf, degree, alignment, megablocks_size, gate_w=gate_w)
                 if res is not None:
                     return finish(*res)
-        # the gate projection: computed ONCE, autocast off (moe_layer.py:315-323), whatever path consumes it
-        if x.is_cuda:
+        # the gate projection: computed ONCE, autocast off (moe_layer.py:315-323), whatever path consumes it.  Where the in-call
+        # projection would have applied, the other paths project with the same kernel (same partial sums, same order: same bits),
+        # so that a batch is routed the same way whichever path the planner picks (bench.py's N > 1 parity canary compares the
+        # native pipelines with the torch.distributed path and expects equal tokens, not merely equally valid roundings)
+        logits = ops.gate_logits(x, gate_w) if gate_w is not None else None
+        if logits is not None:
+            pass
+        elif x.is_cuda:
             with torch.autocast("cuda", enabled=False):
                 logits = gate(x)
         else:

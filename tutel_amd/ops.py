@@ -128,6 +128,16 @@ def gate_topk_partials(partials, dtype, k, normalize_gate=True, want_logits=Fals
     return idx, gates, ws, logits, scores
 
 
+def gate_logits(x, wg):
+    """x @ wg^T in x.dtype through the split-K kernel: the SAME logits, bit for bit, that the one-call path routes on (its top-k kernel
+    adds the same partial sums in the same order) -- so that a layer's routing does not depend on which path its planner picks.
+    None when the shape is not covered."""
+    part = gate_proj(x, wg)
+    if part is None:
+        return None
+    return gate_topk_partials(part, x.dtype, 1, want_logits=True)[3]
+
+
 def cache_warm(t, chunk_bytes=None, n_chunks=1, stride_bytes=0, blocks=0, offset=0):
     """plain loads over n_chunks ranges of chunk_bytes (stride_bytes apart) of tensor t, from byte `offset` (memory-side cache
     warm-up on the current stream, csrc/gate_proj.hip)"""
