@@ -30,9 +30,19 @@ def _set_transport(ep_native, native):
     ep_native.TRANSPORT = "ipc" if native == "ipc" else "rccl"
 
 
+def _tick(rank, label):
+    """where a rank process spends its wall time: TUTEL_AMD_TEST_TIMING=<file> appends one line per call (diagnosis only)"""
+    path = os.environ.get("TUTEL_AMD_TEST_TIMING")
+    if path:
+        import time
+        with open(path, "a") as f:
+            f.write(f"{time.time() % 10000:9.2f} s  rank {rank}: {label}\n")
+
+
 def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        _tick(rank, f"start W={world} degree={degree} native={native}")
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import torch.distributed as dist
@@ -45,7 +55,9 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
         fast_calls = []
         real_fast = ep_native.forward_from_logits
         ep_native.forward_from_logits = lambda *a, **kw: fast_calls.append(1) or real_fast(*a, **kw)
+        _tick(rank, "imports done")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        _tick(rank, "process group up")
         torch.cuda.set_device(0)
         T, M, H, k = shape or (512, 128, 192, 2)
         E = E_loc * world
@@ -65,6 +77,7 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
             layer.experts.batched_fc1_w.copy_(w1[sl]); layer.experts.batched_fc1_bias.copy_(b1[sl])
             layer.experts.batched_fc2_w.copy_(w2[sl]); layer.experts.batched_fc2_bias.copy_(b2[sl])
         layer = layer.cuda().eval()
+        _tick(rank, "layer on the device")
         assert layer.world_size == world and layer.num_global_experts == E
         plans = []
         if degree > 1 and not native:  # record which pipeline the fused routine took
@@ -77,6 +90,8 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
             OV.OverlapPlan = Spy
         with torch.no_grad():
             y = layer(xs[rank].cuda())
+            torch.cuda.synchronize()
+            _tick(rank, "first forward done")
             if native:
                 # cached workspace, events re-recorded, exchange buffers reused: ANOTHER batch in between (every rank its neighbour's
                 # tokens), then the first batch again, twice -- bit for bit the first result, i.e. nothing of the batch in between
@@ -85,6 +100,7 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
                 for _ in range(2):
                     assert torch.equal(layer(xs[rank].cuda()), y)
         torch.cuda.synchronize()
+        _tick(rank, "forwards done")
         if native == "ipc":
             comm = ep_native.communicator(layer.group, torch.device("cuda", 0))
             assert comm is not None and comm.ipc and not comm.generic, "the IPC transport must be the exchange"
@@ -108,7 +124,9 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
                                       [w2[r * E_loc:(r + 1) * E_loc] for r in range(world)],
                                       [b2[r * E_loc:(r + 1) * E_loc] for r in range(world)],
                                       top_k=k, fp32_gate=True, alignment=degree, accum_fp32=True)
+        _tick(rank, "oracle done (rank 0 computes)")
         dist.broadcast_object_list(box, src=0)
+        _tick(rank, "expectation received")
         want, crits = box[0]
         err = (y.cpu().double() - want[rank].double()).abs()
         # bf16 bar (tests/test_layer_gpu.py header): 2 ulps of the element + an absolute term.  The absolute
@@ -121,6 +139,7 @@ def _worker(rank, world, port, degree, E_loc, q, shape=None, native=False):
         ok = bad == 0 and torch.equal(layer.dispatch_count.cpu(), crits[rank][5])
         q.put((rank, ok, f"max err {float(err.max()):.3e}, {bad} elements over the bar, |y|max {scale:.3f}; pipeline sliced={plans}", plans))
         dist.destroy_process_group()
+        _tick(rank, "end")
     except Exception:  # pragma: no cover
         import traceback
         q.put((rank, False, traceback.format_exc(), []))
@@ -255,22 +274,37 @@ def _sweep_worker(rank, world, port, cfg, q):
         q.put((rank, False, traceback.format_exc(), []))
 
 
+def _threads_per_rank(world):
+    """CPU threads each of `world` rank processes may use: the physical cores shared out, at most 32."""
+    return max(4, min(32, (os.cpu_count() or 8) // 2 // max(1, world)))
+
+
 @contextlib.contextmanager
-def _rank_env(world):
-    """environment the spawned rank processes inherit.  Several HIP processes on ONE device oversubscribe its hardware queues with
-    the runtime's default of 4 normal-priority queues per process (+ the side streams' priority queues): the scheduler then time-slices
-    the queues and a forward of the IPC transport takes 29 ms instead of 0.9 (profiles/r04_bench_ranks_sharing_one_gpu.txt) -- correct,
-    but 30 x slower and at the mercy of the wait bound.  Two queues per process keep the ranks inside the device's queue slots (round 5:
-    for every world size -- VERDICT r4 item 8; it used to be W >= 4 only).  (An artefact of ranks sharing a device; one process per GPU
-    never gets there.)"""
-    old = os.environ.get("GPU_MAX_HW_QUEUES")
-    if world >= 2 and old is None:
-        os.environ["GPU_MAX_HW_QUEUES"] = "2"
+def _rank_env(world, share_gpu=True):
+    """environment the spawned rank processes inherit.
+    (1) Several HIP processes on ONE device oversubscribe its hardware queues with the runtime's default of 4 normal-priority queues
+    per process (+ the side streams' priority queues): the scheduler then time-slices the queues and a forward of the IPC transport
+    takes 29 ms instead of 0.9 (profiles/r04_bench_ranks_sharing_one_gpu.txt) -- correct, but 30 x slower and at the mercy of the
+    wait bound.  Two queues per process keep the ranks inside the device's queue slots (round 5: for every world size -- VERDICT r4
+    item 8; it used to be W >= 4 only).  An artefact of ranks sharing a device; one process per GPU never gets there.
+    (2) Every rank process starts an OpenMP pool as wide as the HOST (256 threads on the GPU box) for the seeded problem, the layer's
+    initialisation and the oracle, and libgomp's idle threads spin: four ranks = 1024 spinning threads on 256 hardware threads.
+    Measured (round 5, profiles/r05_rank_tests_cpu_threads.txt): the W = 4 tests took 10.5 - 13.1 s each, 8 s of it between "process
+    group up" and "layer on the device"; with the pool capped they take 2.2 - 2.7 s.  The physical cores are shared out between
+    the ranks (at most 32 each: the largest oracle evaluation, configs[4]'s per-rank shape, is 2 TFLOP of sgemm)."""
+    want = {"OMP_NUM_THREADS": str(_threads_per_rank(world)), "MKL_NUM_THREADS": str(_threads_per_rank(world))}
+    if share_gpu:
+        want["GPU_MAX_HW_QUEUES"] = "2"
+    old = {k: os.environ.get(k) for k in want}
+    for k, v in want.items():
+        if world >= 2 and old[k] is None:
+            os.environ[k] = v
     try:
         yield
     finally:
-        if world >= 2 and old is None:
-            os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        for k in want:
+            if world >= 2 and old[k] is None:
+                os.environ.pop(k, None)
 
 
 def _run_ranks(target, world, args, timeout=900):
@@ -284,6 +318,7 @@ def _run_ranks(target, world, args, timeout=900):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    _tick("parent", f"spawning {world} ranks of {getattr(target, '__name__', target)}")
     with _rank_env(world):
         for p in procs:
             p.start()
@@ -301,8 +336,10 @@ def _run_ranks(target, world, args, timeout=900):
         assert not failed, f"rank {failed[0][0]}: {failed[0][2]}"
         pytest.skip(f"{world} rank processes sharing ONE GPU did not finish within {timeout} s (every wait of the transport is bounded and "
                     f"reports its peer well inside that): the device is oversubscribed -- not a verdict on the code")
+    _tick("parent", "all verdicts in")
     for p in procs:
         p.join(timeout=60)
+    _tick("parent", "ranks joined")
     for rank, ok, info, _ in res:
         assert ok, f"rank {rank}: {info}"
     return res

@@ -231,8 +231,10 @@ def test_changing_batch_stress_between_gpus(transport):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_stress_worker, args=(r, world, port, transport, (4096, 2048, 1024, 2, 8), 240, 300, False, q)) for r in range(world)]
-    for p in procs:
-        p.start()
+    from test_ep_ranks_one_gpu import _rank_env
+    with _rank_env(world, share_gpu=False):   # the host's cores shared out between the ranks' OpenMP pools
+        for p in procs:
+            p.start()
     res = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
@@ -249,8 +251,10 @@ def test_expert_parallel_between_gpus(world, E_loc, transport):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, E_loc, transport, q)) for r in range(world)]
-    for p in procs:
-        p.start()
+    from test_ep_ranks_one_gpu import _rank_env
+    with _rank_env(world, share_gpu=False):   # the host's cores shared out between the ranks' OpenMP pools
+        for p in procs:
+            p.start()
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
