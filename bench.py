@@ -159,28 +159,49 @@ def physical_cores():
 
 
 def cpu_baseline(T, M, H, E, k, max_seconds=20.0):
-    from oracle import moe_oracle as O
-    threads = min(physical_cores(), 32)  # ATen GEMMs stop scaling (and the C scatter loops are single-threaded) well before that
+    """the reference's CPU path at the headline shape, timed on this box's host cores (rank 0 at N = 1, after every GPU pass).
+    kind "reference": fast_encode / fast_decode run the REFERENCE'S OWN compiled CPU kernels (oracle/_ref/tutel_custom_kernel.so =
+    tutel/custom/custom_kernel.cpp built where it lies; the .so travels to the GPU box, the reference's Python package does not),
+    called as its Python calls them (oracle/ref_kernels.py), between the ATen calls that Python makes (softmax, top-k, matmul:
+    oracle/moe_oracle.py).  The plain-C port of the same loops is timed beside it (`port`), and is `value` only where _ref is absent."""
+    from oracle import moe_oracle as O, ref_kernels as R
+    threads = min(physical_cores(), 32)  # ATen GEMMs stop scaling (and the scatter loops are single-threaded) well before that
     old = torch.get_num_threads()
     torch.set_num_threads(threads)
+
+    def median_forward(fwd, budget):
+        with torch.no_grad():
+            fwd()  # warm-up (page-in, thread pool)
+            times, t_all = [], time.time()
+            while len(times) < 10 and (time.time() - t_all) < budget:
+                t0 = time.time()
+                fwd()
+                times.append(time.time() - t0)
+        return sorted(times)[len(times) // 2], len(times)
     try:
         x, wg, w1, b1, w2, b2 = O.make_problem(T, M, H, E, dtype=torch.float32, seed=0)
-        with torch.no_grad():
-            O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)  # warm-up (page-in, thread pool)
-            times = []
-            t_all = time.time()
-            while len(times) < 10 and (time.time() - t_all) < max_seconds:
-                t0 = time.time()
-                O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)
-                times.append(time.time() - t0)
+        have_ref = R.available()
+        if have_ref:
+            with torch.no_grad():   # the two must agree before either is quoted
+                ya, yb = O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)[0], R.moe_forward(x, wg, w1, b1, w2, b2, top_k=k)[0]
+            assert torch.equal(ya, yb), "oracle/_ref kernels and the port disagree"
+            dt_ref, n_ref = median_forward(lambda: R.moe_forward(x, wg, w1, b1, w2, b2, top_k=k), max_seconds / 2)
+        dt_port, n_port = median_forward(lambda: O.moe_forward(x, wg, w1, b1, w2, b2, top_k=k), max_seconds / 2)
     finally:
         torch.set_num_threads(old)
-    dt = sorted(times)[len(times) // 2]
-    return {"value": round(T / dt, 1), "unit": "tokens/s", "cores": threads, "kind": "port",
-            "kind_note": "oracle/moe_oracle.py moe_forward: the reference's CPU path restated (ATen softmax / matmul + C scatter / gather "
-                         "loops); /root/reference does not exist on the GPU box, so the reference itself cannot be timed here",
-            "ms_per_step": round(dt * 1e3, 2), "dtype": "f32", "host_logical_cpus": os.cpu_count(), "host_physical_cores": physical_cores(),
-            "sample": f"median of {len(times)} forward passes of the same {T}-token workload (fp32), torch.set_num_threads({threads})",
+    dt, n = (dt_ref, n_ref) if have_ref else (dt_port, n_port)
+    note = ("oracle/_ref/tutel_custom_kernel.so -- the reference's tutel/custom/custom_kernel.cpp compiled where it lies (oracle/Makefile), its "
+            "invoke_cpu_fp32 scatter / gather kernels called as tutel/impls/fast_dispatch.py calls them (oracle/ref_kernels.py) -- between the "
+            "ATen calls the reference's Python makes on its CPU path (softmax, top-k, cumsum, matmul: oracle/moe_oracle.py); the Python package "
+            "itself cannot travel to the GPU box (/root/reference does not exist there)") if have_ref else \
+           ("oracle/moe_oracle.py moe_forward: the reference's CPU path restated (ATen softmax / matmul + C scatter / gather loops); "
+            "oracle/_ref/ is not on this box, so no reference code can be timed here")
+    return {"value": round(T / dt, 1), "unit": "tokens/s", "cores": threads, "kind": "reference" if have_ref else "port",
+            "kind_note": note, "ms_per_step": round(dt * 1e3, 2), "dtype": "f32", "host_logical_cpus": os.cpu_count(), "host_physical_cores": physical_cores(),
+            "sample": f"median of {n} forward passes of the same {T}-token workload (fp32), torch.set_num_threads({threads}); outputs of the "
+                      f"reference kernels and of the port compared bit for bit first",
+            "port": {"value": round(T / dt_port, 1), "ms_per_step": round(dt_port * 1e3, 2), "kind": "port", "passes": n_port,
+                     "note": "oracle/moe_oracle.c loops instead of the reference's compiled kernels, everything else the same"},
             "reference_measured": {"value": "13-15 k tokens/s (0.27-0.31 s per forward)", "cores": 8, "kind": "reference",
                                    "source": "BASELINE.md section 2: the reference's own helloworld --device=cpu --eval at this shape, survey container (8 x Xeon 2.1 GHz)"}}
 

@@ -299,7 +299,7 @@ def a2a_combine(per_rank, C):
 def moe_forward(x, wg, w1, b1, w2, b2, top_k=2, capacity_factor=1.0, fp32_gate=False,
                 normalize_gate=True, is_postscore=True, act=torch.relu, alignment=1,
                 accum_fp32=False, topk_override=None, logits_fn=None, expert_fn=None, noise=None,
-                gate_noise=0.0, is_gshard_loss=True):
+                gate_noise=0.0, is_gshard_loss=True, encode_fn=None, decode_fn=None):
     """Single-rank MOELayer.forward.  Reference: moe_layer.py:255-363 (dtype chain :264-270,
     :327, :359-361).  x [..., M] -> (y [..., M_out], l_aux, crit, stages dict).
     logits_fn(x[T,M]) -> logits replaces the linear gate (custom / cosine gates, moe_layer.py:283);
@@ -322,12 +322,12 @@ def moe_forward(x, wg, w1, b1, w2, b2, top_k=2, capacity_factor=1.0, fp32_gate=F
     if not is_gshard_loss:
         ids = torch.stack(crit[1], dim=1).long()
         l_aux = load_importance_loss(torch.softmax(logits, dim=1), noisy.gather(1, ids), logits.shape[1], gate_noise)
-    enc = fast_encode(xr.to(logits_dtype), crit, is_postscore).to(xr.dtype)
+    enc = (encode_fn or fast_encode)(xr.to(logits_dtype), crit, is_postscore).to(xr.dtype)
     if expert_fn is not None:
         ffn = expert_fn(enc)
     else:
         ffn = expert_ffn(enc, w1, b1, w2, b2, act, accum_fp32=accum_fp32)
-    dec = fast_decode(ffn.to(logits_dtype), crit, is_postscore)
+    dec = (decode_fn or fast_decode)(ffn.to(logits_dtype), crit, is_postscore)
     y = dec.view(list(orig_shape[:-1]) + [ffn.shape[-1]]).to(orig_dtype)
     return y, l_aux, crit, {"scores": scores, "encoded": enc, "expert_out": ffn}
 
