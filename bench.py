@@ -57,8 +57,9 @@ N > 1: the graph is replayed as well when the exchange is the IPC transport (pla
 2000 replays in tests/test_ep_ipc_one_gpu.py; host cost 0.05 ms per forward against 0.16 ms eager); with RCCL on the path the
 forward is timed eager, because replaying captured RCCL collectives was seen to hang after a few hundred replays with this RCCL
 build (profiles/r03_ep_streams.txt) and GraphedForward refuses to capture them.
-`cpu_baseline`: the CPU oracle (a port of the reference CPU path, oracle/moe_oracle.py) timed on this box's host
-cores on a bounded sample, rank 0, N=1 only, next to the figure BASELINE.md measured with the reference itself.
+`cpu_baseline`: the reference's CPU path timed on this box's host cores on a bounded sample, rank 0, N=1 only -- fast_encode /
+fast_decode through the reference's OWN compiled CPU kernels (oracle/_ref, kind "reference"; see cpu_baseline()), the plain-C port
+beside it -- next to the figure BASELINE.md measured with the reference's Python itself.
 Checker code is used here ONLY as that reported baseline; it is never part of the measured GPU path.
 """
 import argparse
@@ -467,7 +468,7 @@ def modelled_scaling(M, H, T, E, k, C, dtype, dev):
 
 
 def round5_features(layer, x, fwd_kw, gate_timer):
-    """round 5's three changes to the headline path, each switched off in turn: ms per step of the HIP-graph replay of the same forward
+    """round 5's four changes to the headline path, each switched off in turn: ms per step of the HIP-graph replay of the same forward
     (median of 3 x 20 steps).  bench.py runs it in a child process (`--round5_features`): every capture brings a stream of its own."""
     from tutel_amd import _lib, ops
     from tutel_amd.impls import moe_layer as _ML
@@ -475,15 +476,18 @@ def round5_features(layer, x, fwd_kw, gate_timer):
     feat = {}
     names = ["all on (as timed)", "location kernel instead of the in-GEMM scan",
              "fused location off + vector slot-map lookups in front of the weight DMA",
-             "gate projection by F.linear (hipBLASLt) instead of the split-K kernel"]
-    settings = [(-1, -1, True), (0, -1, True), (0, 0, True), (-1, -1, False)]   # (TUTEL_OPT_FUSED_LOCATION, TUTEL_OPT_GEMM_GATHER, native gate)
+             "gate projection by F.linear (hipBLASLt) instead of the split-K kernel",
+             "plain (write-back) output stores in the expert GEMMs instead of write-through"]
+    # (TUTEL_OPT_FUSED_LOCATION, TUTEL_OPT_GEMM_GATHER, native gate, TUTEL_OPT_GEMM_STORE)
+    settings = [(-1, -1, True, -1), (0, -1, True, -1), (0, 0, True, -1), (-1, -1, False, -1), (-1, -1, True, 0)]
     graphs = []
     try:
-        # one capture per setting (the kernel choice is made at capture time, each graph keeps its own workspace), then the four
+        # one capture per setting (the kernel choice is made at capture time, each graph keeps its own workspace), then the
         # graphs are replayed INTERLEAVED, three rounds: clocks and neighbours drift by more than the differences being measured
-        for fl, ga, ng in settings:
+        for fl, ga, ng, st in settings:
             ops.set_option(_lib.OPT_FUSED_LOCATION, fl)
             ops.set_option(_lib.OPT_GEMM_GATHER, ga)
+            ops.set_option(_lib.OPT_GEMM_STORE, st)
             _ML._NATIVE_GATE = ng
             layer.__dict__.pop("_ep_workspaces", None)
             with torch.no_grad():
@@ -506,6 +510,7 @@ def round5_features(layer, x, fwd_kw, gate_timer):
         _ML._NATIVE_GATE = True
         ops.set_option(_lib.OPT_GEMM_GATHER, -1)
         ops.set_option(_lib.OPT_FUSED_LOCATION, -1)
+        ops.set_option(_lib.OPT_GEMM_STORE, -1)
         layer.__dict__.pop("_ep_workspaces", None)
     return feat
 

@@ -409,6 +409,51 @@ def test_expert_gemm_kernels_are_bit_identical(kmajor):
         assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), float(err.max())
 
 
+def test_expert_gemm_store_policies_keep_every_bit():
+    """TUTEL_OPT_GEMM_STORE (round 5): the output tile of the LDS-epilogue kernels (128 x 256 ring, 256 x 128 ring, 256 x 256 ping-pong)
+    leaves with write-through (1) or non-temporal (2) buffer stores instead of plain stores -- same values at the same addresses: plain
+    rows, ragged row counts, the expert-parallel row addressing (output rows of two source ranks written in the all-to-all layout,
+    bytes between them untouched) and the GLU form."""
+    from tutel_amd import ops, _lib
+    g = torch.Generator().manual_seed(23)
+    cases = []
+    for tile, (E, R, N, K) in ((-1, (6, 128, 512, 256)), (3, (2, 512, 256, 512)), (4, (2, 512, 512, 256)), (-1, (64, 128, 2048, 2048))):
+        a = torch.randn([E, R, K], generator=g).bfloat16().cuda()
+        w = ((torch.rand([E, N, K], generator=g) * 2 - 1) / 16).bfloat16().cuda()
+        b = torch.randn([E, N], generator=g).bfloat16().cuda()
+        cases.append((tile, a, w, b, E, R, N, K))
+    try:
+        for tile, a, w, b, E, R, N, K in cases:
+            outs = {}
+            for mode in (0, 1, 2):
+                ops.set_option(_lib.OPT_GEMM_TILE, tile)
+                ops.set_option(_lib.OPT_GEMM_STORE, mode)
+                got = [ops.expert_gemm(a, w, b, True, act="relu")]
+                counts = torch.tensor([(R * (e + 1)) // (E + 1) for e in range(E)], dtype=torch.int32).cuda()
+                o = torch.full([E, R, N], 7.0, dtype=torch.bfloat16).cuda()
+                ops.expert_gemm(a, w, b, True, act="relu", out=o, d_layout=(R * N, 0, R, N), row_counts=counts, row_align=32)
+                got.append(o)
+                if R % 2 == 0:   # rows of two source ranks: [W = 2][E][R / 2][N] with a gap row behind every rank's rows of an expert
+                    half = R // 2
+                    o2 = torch.full([2, E, half + 1, N], 7.0, dtype=torch.bfloat16).cuda()
+                    ops.expert_gemm(a, w, b, True, act="relu", out=o2, d_layout=((half + 1) * N, E * (half + 1) * N, half, N))
+                    got.append(o2)
+                m = torch.randn([E, R, N], generator=torch.Generator().manual_seed(5)).bfloat16().cuda()
+                got.append(ops.expert_gemm(a, w, None, True, mul=m))
+                outs[mode] = got
+            torch.cuda.synchronize()
+            for mode in (1, 2):
+                assert all(torch.equal(x, y) for x, y in zip(outs[0], outs[mode])), (mode, tile, E, R, N, K)
+            ref = torch.relu(torch.matmul(a.float(), w.float().transpose(1, 2)) + b.float().unsqueeze(1))
+            err = (outs[1][0].float() - ref).abs()
+            assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), float(err.max())
+            if len(outs[1]) == 4:
+                assert bool((outs[1][2][:, :, -1, :] == 7.0).all()), "the gap rows of the all-to-all layout must stay untouched"
+    finally:
+        ops.set_option(_lib.OPT_GEMM_TILE, -1)
+        ops.set_option(_lib.OPT_GEMM_STORE, -1)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_split_k_pingpong_kernel(dtype):
     """Round 5: launches of 96 .. 191 tiles of 256 x 256 (one pipeline stage of an 8-way expert-parallel rank: 4 experts x 1024 rows x

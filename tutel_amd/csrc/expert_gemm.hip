@@ -99,6 +99,7 @@ struct GemmArgs {
   bool fits32;                                                // operands addressable with 32-bit byte offsets
   bool rot_on;                                                // K-tile rotation (see launch_gemm)
   bool sgather;                                               // ring kernels: slot-map entries through the scalar cache (TUTEL_OPT_GEMM_GATHER)
+  int d_store;                                                // LDS epilogue: 1 write-through (sc0 sc1) stores, 0 plain (write-back), 2 non-temporal (TUTEL_OPT_GEMM_STORE)
   const uint8_t *fl_idx8; int fl_n; int32_t *fl_loc;          // fused location (FL kernels): byte copy of idx [k*T], its length, loc out
   const void *mul;                                            // optional epilogue multiplier, D's layout
   const uint64_t *d_peer; long long d_peer_off;               // optional: rows of source rank w go to d_peer[w] + d_peer_off (bytes)
@@ -650,6 +651,29 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&ac
   constexpr int LPR = NI * 4, RPI = 64 / LPR;  // lanes per row (16 bytes each), rows per store instruction
   const int c16 = lane % LPR, r4 = lane / LPR;
   const int n = n0 + wn * (NI * 32) + c16 * 8;
+  if (p.d_store != 0 && p.d_peer == nullptr) {
+    // TUTEL_OPT_GEMM_STORE (round 5): the output tile leaves with write-through (sc0 sc1; the default) or non-temporal stores -- buffer
+    // stores through a descriptor over the expert's output, so the cache-policy bits come from the compiler (round 4's inline-assembly
+    // stores lacked the hazard wait states).  Plain stores leave the tile dirty in the XCD's L2, and what is still
+    // dirty when the last wave ends is written back THEN, with nothing left to hide it behind: measured (profiles/r05_store_ab.json)
+    // fc1 110.2 -> 104.5 us and fc2 106.8 -> 103.3 us inside the headline forward, the MFMA-bound pair of an 8-way rank 130.4 -> 126.8 us,
+    // its pipeline stage 76.4 -> 73.0 us.  Write-through keeps the lines valid in L2 for the next kernel (decode is unchanged at 12.1 us;
+    // with non-temporal stores it reads the expert outputs from HBM: 14.2 us).  Same values, same addresses.
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(De, 0, -1, 0x00020000);
+#define EP_STORE_LOOP(AUX)                                                                                        \
+    _Pragma("unroll 4") for (int it = 0; it < 64 / RPI; ++it) {                                                   \
+      const int row = it * RPI + r4;                                                                              \
+      const int m = m0 + wm * 64 + row;                                                                           \
+      const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + row * PITCH + c16 * 16);                         \
+      if (m < row_limit && n < p.N) {                                                                             \
+        const size_t roff = (size_t)(m / p.d_rpw) * p.d_stride_w + (size_t)(m % p.d_rpw) * p.ldd;                 \
+        __builtin_amdgcn_raw_buffer_store_b128(val, rs_d, (int)((roff + n) * 2), 0, AUX);                         \
+      }                                                                                                           \
+    }
+    if (p.d_store == 1) { EP_STORE_LOOP(17); } else { EP_STORE_LOOP(2); }
+#undef EP_STORE_LOOP
+    return;
+  }
 #pragma unroll 4
   for (int it = 0; it < 64 / RPI; ++it) {
     const int row = it * RPI + r4;
@@ -1725,6 +1749,11 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   //     4096^2, 85 -> 79 at 32 x 256 rows).
   a.rot_on = R < GB_BM;
   a.sgather = tutel_get_option(TUTEL_OPT_GEMM_GATHER) != 0 && (long long)E_loc * R * 4 < 0x7fffffffLL;
+  {  // store policy of the LDS epilogue; the descriptor form needs every byte offset inside an expert's output below 2^31
+    const int ds = tutel_get_option(TUTEL_OPT_GEMM_STORE);
+    const long long span = ((long long)((R - 1) / d_rows_per_w) * (d_stride_w < 0 ? -d_stride_w : d_stride_w) + (long long)(d_rows_per_w < R ? d_rows_per_w : R) * ldd + N) * 2;
+    a.d_store = (ds == 0 || d_peer != nullptr || span >= 0x7fffffffLL) ? 0 : (ds == 2 ? 2 : 1);   // automatic: write-through
+  }
   a.mul = mul;
   a.fl_idx8 = fl_idx8; a.fl_n = fl_n; a.fl_loc = fl_loc;
   a.d_peer = d_peer; a.d_peer_off = d_peer_off;
