@@ -36,10 +36,11 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
                                                            int gate_dtype, int Tn, int M,
                                                            int n_slots, int capacity, int num_experts,
                                                            int chunk_rows, int expert_slice, int ep_world,
-                                                           T *__restrict__ out, EncodePeer peer) {
+                                                           T *__restrict__ out, EncodePeer peer, int wt) {
   constexpr int VN = Vec<T>::N;
+  typedef __attribute__((ext_vector_type(4))) uint32_t enc_u32x4;
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * DP_WAVES + (threadIdx.x >> 6)));  // (uniform: the row's descriptor below lives in SGPRs)
   const int nwaves = gridDim.x * DP_WAVES;
   const int nvec = M / VN;  // full 16-byte vectors per row (rows are 16B aligned when M % VN == 0)
   const bool vec_ok = (M % VN) == 0;
@@ -66,11 +67,21 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
       const int blk = slot / peer.rows, rem = slot % peer.rows, st = blk / ep_world, w = blk % ep_world;
       dst = reinterpret_cast<T *>(peer.tab[w] + peer.off) + ((size_t)(st * ep_world + peer.rank) * peer.rows + rem) * M;
     }
+    // wt (TUTEL_OPT_GEMM_STORE, as the expert GEMMs' output tiles): the row leaves with write-through (sc0 sc1) buffer stores through a
+    // descriptor over the row -- it streams out (over xGMI when dst is a peer's buffer) while the kernel runs, instead of staying dirty
+    // in this XCD's L2 until it is evicted or the kernel ends.  Compiler-generated stores: the hazard wait states are the compiler's.
+    const bool wts = wt != 0 && vec_ok;   // wave-uniform
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(dst, 0, wts ? M * (int)sizeof(T) : 0, 0x00020000);
+#define ENC_ST16(D, I, V)                                                                                      \
+    do {                                                                                                       \
+      if (wts) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(enc_u32x4, (V)), rs_o, (I) * 16, 0, 17); \
+      else (D)[(I)] = (V);                                                                                     \
+    } while (0)
     if (q < 0) {
       if (vec_ok) {
         vec16 z = {{0u, 0u, 0u, 0u}};
         vec16 *d = reinterpret_cast<vec16 *>(dst);
-        for (int i = lane; i < nvec; i += 64) d[i] = z;
+        for (int i = lane; i < nvec; i += 64) ENC_ST16(d, i, z);
       } else {
         for (int i = lane; i < M; i += 64) dst[i] = Elem<T>::from_f32(0.f);
       }
@@ -85,9 +96,9 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
         int i = lane;
         for (; i + 192 < nvec; i += 256) {  // 4 independent 16B loads in flight per lane
           vec16 a = s[i], b = s[i + 64], c = s[i + 128], e = s[i + 192];
-          d[i] = a; d[i + 64] = b; d[i + 128] = c; d[i + 192] = e;
+          ENC_ST16(d, i, a); ENC_ST16(d, i + 64, b); ENC_ST16(d, i + 128, c); ENC_ST16(d, i + 192, e);
         }
-        for (; i < nvec; i += 64) d[i] = s[i];
+        for (; i < nvec; i += 64) { vec16 a = s[i]; ENC_ST16(d, i, a); }
       } else {
         for (int i = lane; i < M; i += 64) dst[i] = src[i];
       }
@@ -103,12 +114,13 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
 #pragma unroll
           for (int u = 0; u < VN; ++u) f[u] = mul_rn(g, f[u]);
           Vec<T>::pack(f, v);
-          d[i] = v;
+          ENC_ST16(d, i, v);
         }
       } else {
         for (int i = lane; i < M; i += 64) dst[i] = Elem<T>::from_f32(mul_rn(g, Elem<T>::to_f32(src[i])));
       }
     }
+#undef ENC_ST16
   }
   if (peer.tab != nullptr) peer_canary_store(peer.tab, peer.can);  // IPC transport: epoch canaries behind the rows (common.h)
 }
@@ -374,12 +386,13 @@ int tutel_encode_launch(const void *x, int dtype, const int32_t *slot_map, const
   StageScope stage(TUTEL_STAGE_ENCODE, st);
   int grid = dp_grid(n_slots - peer.slot0);
   int Tn = T > 0 ? T : 1;
+  const int wt = tutel_get_option(TUTEL_OPT_GEMM_STORE) != 0 && (long long)M * 4 < 0x7fffffffLL ? 1 : 0;   // write-through row stores (automatic: on)
   if (dtype == TUTEL_F32)
-    hipLaunchKernelGGL(encode_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (float *)out, peer);
+    hipLaunchKernelGGL(encode_kernel<float>, dim3(grid), dim3(DP_THREADS), 0, st, (const float *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (float *)out, peer, wt);
   else if (dtype == TUTEL_BF16)
-    hipLaunchKernelGGL(encode_kernel<bf16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const bf16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (bf16_t *)out, peer);
+    hipLaunchKernelGGL(encode_kernel<bf16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const bf16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (bf16_t *)out, peer, wt);
   else
-    hipLaunchKernelGGL(encode_kernel<f16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const f16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (f16_t *)out, peer);
+    hipLaunchKernelGGL(encode_kernel<f16_t>, dim3(grid), dim3(DP_THREADS), 0, st, (const f16_t *)x, slot_map, gates, gate_dtype, Tn, M, n_slots, capacity, num_experts, chunk_rows, expert_slice, ep_world, (f16_t *)out, peer, wt);
   TUTEL_CHECK_LAUNCH("tutel_amd_fast_encode");
   return 0;
 }

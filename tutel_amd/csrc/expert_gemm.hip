@@ -651,7 +651,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs &p, f32x16 (&ac
   constexpr int LPR = NI * 4, RPI = 64 / LPR;  // lanes per row (16 bytes each), rows per store instruction
   const int c16 = lane % LPR, r4 = lane / LPR;
   const int n = n0 + wn * (NI * 32) + c16 * 8;
-  if (p.d_store != 0 && p.d_peer == nullptr) {
+  if (p.d_store != 0 && p.d_peer != nullptr) {
+    // peer rows (IPC transport), write-through: the rows of ONE store instruction -- RPI consecutive rows starting at a multiple of RPI --
+    // belong to one source rank (the host sets d_store for peer stores only when d_rpw % 8 == 0), so the descriptor over that rank's
+    // return buffer is wave-uniform.  The payload leaves for the peer while the kernel runs instead of in its end-of-kernel write-back.
+    const int mw = __builtin_amdgcn_readfirstlane(m0 + wm * 64);
+    const int wmax = (p.R - 1) / p.d_rpw;
+#pragma unroll 4
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int mf = mw + it * RPI;                       // first row of this instruction (uniform)
+      const int w = min(mf / p.d_rpw, wmax), l0 = mf - (mf / p.d_rpw) * p.d_rpw;
+      const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p.d_peer[w] + p.d_peer_off), 0, -1, 0x00020000);
+      const int row = it * RPI + r4;
+      const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + row * PITCH + c16 * 16);
+      if (mw + row < row_limit && n < p.N)
+        __builtin_amdgcn_raw_buffer_store_b128(val, rs_w, (int)(((size_t)e * p.d_stride_e + (size_t)(l0 + r4) * p.ldd + n) * 2), 0, 17);
+    }
+    peer_canary_store(p.d_peer, p.d_can);
+    return;
+  }
+  if (p.d_store != 0) {
     // TUTEL_OPT_GEMM_STORE (round 5): the output tile leaves with write-through (sc0 sc1; the default) or non-temporal stores -- buffer
     // stores through a descriptor over the expert's output, so the cache-policy bits come from the compiler (round 4's inline-assembly
     // stores lacked the hazard wait states).  Plain stores leave the tile dirty in the XCD's L2, and what is still
@@ -1752,7 +1771,11 @@ static int expert_gemm_impl(const void *A, int64_t a_stride_e, int64_t a_stride_
   {  // store policy of the LDS epilogue; the descriptor form needs every byte offset inside an expert's output below 2^31
     const int ds = tutel_get_option(TUTEL_OPT_GEMM_STORE);
     const long long span = ((long long)((R - 1) / d_rows_per_w) * (d_stride_w < 0 ? -d_stride_w : d_stride_w) + (long long)(d_rows_per_w < R ? d_rows_per_w : R) * ldd + N) * 2;
-    a.d_store = (ds == 0 || d_peer != nullptr || span >= 0x7fffffffLL) ? 0 : (ds == 2 ? 2 : 1);   // automatic: write-through
+    a.d_store = (ds == 0 || span >= 0x7fffffffLL) ? 0 : (ds == 2 ? 2 : 1);   // automatic: write-through
+    if (d_peer != nullptr) {  // peer rows: write-through only (a non-temporal hint means nothing to a peer's memory), one source rank per store instruction
+      const long long pspan = ((long long)E_loc * d_stride_e + (long long)d_rows_per_w * ldd + N) * 2;
+      a.d_store = (ds != 0 && d_rows_per_w % 8 == 0 && pspan < 0x7fffffffLL) ? 1 : 0;
+    }
   }
   a.mul = mul;
   a.fl_idx8 = fl_idx8; a.fl_n = fl_n; a.fl_loc = fl_loc;
