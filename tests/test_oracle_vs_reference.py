@@ -58,3 +58,19 @@ def test_reference_kernels_equal_the_port(T, M, H, E, k, cf, post, dts):
     crit = a[2]
     enc = R.fast_encode(x.float(), crit, post)
     assert torch.equal(enc, O.fast_encode(x.float(), crit, post)) and torch.equal(R.fast_decode(enc, crit, post), O.fast_decode(enc, crit, post))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "tutel_custom_kernel.so")) and not os.path.isdir(os.path.join(REF, "tutel")),
+                    reason="neither the prebuilt oracle/_ref/ nor the reference tree is on this box")
+def test_bench_cpu_baseline_times_the_reference_kernels():
+    """bench.py's cpu_baseline leg (the only place outside tests/ and smoke() that may touch oracle/): with oracle/_ref/ present it
+    reports kind "reference" (the reference's compiled kernels, compared bit for bit with the port before either is quoted) and carries
+    the port's figure beside it; a small shape here, the headline's on the GPU box."""
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+    from oracle import ref_kernels as R
+    if not R.available():
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    r = bench.cpu_baseline(512, 256, 128, 16, 2, max_seconds=4.0)
+    assert r["kind"] == "reference" and r["unit"] == "tokens/s" and r["value"] > 0 and r["cores"] >= 1
+    assert r["port"]["kind"] == "port" and r["port"]["value"] > 0 and "oracle/_ref" in r["kind_note"] and "bit for bit" in r["sample"]
