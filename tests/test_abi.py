@@ -74,10 +74,16 @@ def test_round3_entry_points_reject_bad_arguments(L):
     # limits named in the error text (INTEGRATION.md "Limits")
     assert L.tutel_amd_gate_topk(None, 0, 0, 4, 4097, 1, 1, None, None, None, None, 0, None, 0, None) != 0 and b"4096" in L.tutel_amd_last_error()
     assert L.tutel_amd_gate_topk(None, 0, 0, 4, 4096, 3, 1, None, None, None, None, 0, None, 0, None) != 0 and b"8192" in L.tutel_amd_last_error()
-    # options: the round-3 keys exist, unknown keys are refused
-    for key in (_lib.OPT_DECODE, _lib.OPT_EP_STAGE_GRID, _lib.OPT_GEMM_PERSIST, _lib.OPT_EP_STREAMS):
-        assert L.tutel_amd_set_option(key, -1) == 0
-    assert L.tutel_amd_set_option(99, 0) != 0
+    # options: every key the header defines exists (and Python's copy of the numbering agrees with it), unknown keys are refused
+    import re
+    hdr = open(os.path.join(ROOT, "include", "tutel_amd.h")).read()
+    keys = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define TUTEL_OPT_(\w+) (\d+)", hdr)}
+    count = keys.pop("COUNT")
+    assert sorted(keys.values()) == list(range(count)) and keys["GEMM_STORE"] == _lib.OPT_GEMM_STORE == count - 1
+    for name, key in keys.items():
+        assert L.tutel_amd_set_option(key, -1) == 0, name
+        assert getattr(_lib, "OPT_" + name, key) == key, name
+    assert L.tutel_amd_set_option(count, 0) != 0 and L.tutel_amd_set_option(99, 0) != 0
 
 
 def test_product_has_no_cpu_path():
