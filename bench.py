@@ -283,7 +283,57 @@ def parity_of(y, ref):
     return {"max_abs_err": err, "scale": scale, "bitwise": bool(torch.equal(y, ref)), "ok": fin and err <= 2 ** -6 * max(scale, 1e-6)}
 
 
-EP_TRANSPORTS = ("ipc", "rccl", "torch")
+def single_rank_parity(layer, step, T, M, k, dtype, dev, graphed):
+    """N = 1: the parity canary the N > 1 branch has had since round 5 -- before anything is timed, a SECOND random batch goes through the
+    timed path (the HIP-graph replay when there is one) and is compared with the CPU oracle routed on the kernel's own scores (softmax is
+    not bit-specified across exp implementations; everything after it is): every (token, choice) expert id and bucket slot must be the
+    oracle's -- ties in torch.topk's CPU order -- and the output must sit within the dtype's bar of the oracle's fp32-accumulated FFN.
+    The oracle is the CHECKER here (test infrastructure, like the cpu_baseline leg); a forward that fails is never timed."""
+    from oracle import moe_oracle as O
+    from tutel_amd import ops
+    g = torch.Generator().manual_seed(20250601)
+    x2 = torch.randn([16, T // 16, M], generator=g, dtype=torch.float32).to(dtype)
+    keep = getattr(layer, "_keep_routing", False)
+    layer._keep_routing, layer.last_logits, layer.last_routing = True, None, None
+    replay_equal = None
+    try:
+        with torch.no_grad():
+            y = step(x2.to(dev)).clone()          # the eager forward: its routing arrays and logits are read back (`_keep_routing`)
+            cnt = layer.dispatch_count.clone()
+            logits = layer.last_logits.clone() if layer.last_logits is not None else layer.gates[0](x2.to(dev).view(-1, M))
+            idx, loc = [t.clone() for t in layer.last_routing]
+            if graphed is not None:               # the captured forward reads its tokens from the static input buffer: same batch, same bits?
+                saved = graphed.static_in.clone()
+                graphed.static_in.copy_(x2.to(dev))
+                yg = graphed(graphed.static_in).clone()
+                replay_equal = bool(torch.equal(yg, y)) and bool(torch.equal(layer.dispatch_count, cnt))
+                graphed.static_in.copy_(saved)
+            torch.cuda.synchronize()
+            scores = ops.gate_topk(logits, k, apply_softmax=True, want_scores=True)[3].cpu()
+    finally:
+        layer._keep_routing = keep
+    ex = layer.experts
+    w1, b1 = ex.batched_fc1_w.detach().cpu(), ex.batched_fc1_bias.detach().cpu()
+    w2, b2 = ex.batched_fc2_w.detach().cpu(), ex.batched_fc2_bias.detach().cpu()
+    cf = float(layer.gates[0].capacity_factor)
+    with torch.no_grad():
+        crit, _ = O.extract_critical(scores, k, cf)
+        ok_idx = bool(torch.equal(torch.stack(crit[1]).to(torch.int32), idx.cpu())) and bool(torch.equal(torch.stack(crit[2]), loc.cpu()))
+        ok_cnt = bool(torch.equal(cnt.cpu(), crit[5]))
+        enc = O.fast_encode(x2.view(-1, M), crit)
+        yo = O.fast_decode(O.expert_ffn(enc, w1, b1, w2, b2, accum_fp32=True), crit)
+    err = (y.view(-1, M).float().cpu().double() - yo.double()).abs()
+    rel = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    ok_y = bool(torch.isfinite(y.float()).all()) and bool((err <= rel * yo.double().abs() + 2e-3).all())
+    return {"ok": ok_idx and ok_cnt and ok_y and replay_equal is not False, "assignments_checked": int(idx.numel()), "assignment_exact": ok_idx,
+            "dispatch_count_exact": ok_cnt, "max_abs_err": float(err.max()), "output_scale": float(yo.double().abs().max()),
+            "bar": f"|err| <= {rel} * |ref| + 2e-3", "hip_graph_replay_bitwise_equal_to_the_checked_eager_forward": replay_equal,
+            "through": "eager forward vs the oracle" + ("; the HIP-graph replay (the timed path) vs that eager forward, bit for bit" if graphed is not None else ""),
+            "reference": "oracle/moe_oracle.py (extract_critical with torch.topk's CPU tie order, fast_encode, expert_ffn with fp32 accumulation, fast_decode) on the "
+                         "kernel's own scores, a second random batch"}
+
+
+EP_TRANSPORTS = ("rccl", "ipc", "torch")   # `value` = the first that passes its parity canary: RCCL all_to_all (north_star) before the peer stores
 
 
 def configure_ep(layer, transport, degree):
@@ -516,17 +566,24 @@ def round5_features(layer, x, fwd_kw, gate_timer):
 
 
 def tie_rule(dname):
-    """north_star asks for bit-exact token-to-expert assignment; torch.topk leaves the order of EXACT ties unspecified (and its CPU
-    and GPU kernels differ), so the library pins one: lowest expert index.  How often that differs from the reference's CPU run at
-    this very configuration is measured and committed (tests/test_layer_gpu.py::test_headline_low_precision_gate_assignment_vs_reference)."""
-    path = os.path.join(ROOT, "profiles", f"r04_headline_gate_assignment_{'bfloat16' if dname == 'bf16' else 'float16'}.json")
+    """north_star asks for bit-exact token-to-expert assignment against the reference's CPU path.  Among EXACTLY equal scores that path
+    returns what ATen's CPU torch.topk leaves (nth_element / partial_sort over (value, index) pairs); since round 6 the top-k kernels
+    replay exactly that on the rows that tie (csrc/topk_ties.h, TUTEL_OPT_TIE_RULE).  What is left at this very configuration is
+    measured against the reference-written fixture and committed (tests/test_layer_gpu.py::test_headline_low_precision_gate_assignment_vs_reference)."""
+    from tutel_amd import _lib, ops
+    mode = ops.get_option(_lib.OPT_TIE_RULE)
+    if mode == 0:
+        return "TUTEL_OPT_TIE_RULE = 0: lowest expert index on exact ties (rounds 1-5); differs from the reference's CPU torch.topk on tied rows"
+    path = os.path.join(ROOT, "profiles", f"r06_headline_gate_assignment_{'bfloat16' if dname == 'bf16' else 'float16'}.json")
     try:
         d = json.load(open(path))
-        return (f"lowest expert index on exact ties; {d['differing_assignments']} of {d['assignments']} (token, k) assignments on "
-                f"{d['differing_tokens']} tokens differ from the reference's torch.topk (CPU) at this configuration with a {d['dtype']} gate -- "
-                f"every one an exact tie among the reference's own scores ({os.path.relpath(path, ROOT)})")
+        return (f"exact ties in the order of the reference's CPU torch.topk; at this configuration with a {d['dtype']} gate "
+                f"{d['differing_tokens_with_the_references_logits_and_scores']} tokens whose logits and scores carry the reference's bits route "
+                f"differently ({d['tied_rows_with_the_references_bits']} of them tie at the k / k+1 boundary); {d['differing_assignments']} of "
+                f"{d['assignments']} (token, k) assignments differ in all, each on a token where a logit or a score rounds the other way in its "
+                f"last bit ({os.path.relpath(path, ROOT)})")
     except Exception:   # noqa: BLE001
-        return "lowest expert index on exact ties (torch.topk leaves tie order unspecified)"
+        return "exact ties in the order of the reference's CPU torch.topk (csrc/topk_ties.h)"
 
 
 def main():
@@ -685,6 +742,13 @@ def main():
         if graphed is not None and step is graphed:
             graphed.static_in.copy_(batches[0])
             x = graphed.static_in
+    if world == 1 and args.capacity_factor > 0 and not args.megablocks_size:
+        parity = single_rank_parity(layer, eager_step, T, M, k, dtype, dev, graphed if step is graphed else None)
+        if not parity["ok"]:
+            print("bench.py: the timed path FAILED its parity canary -- refusing to report a throughput for wrong tokens", file=sys.stderr, flush=True)
+            print(json.dumps({"metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2", "value": None, "n_gpus": world,
+                              "error": "timed path failed its parity canary", "parity": parity}), flush=True)
+            sys.exit(3)
     with torch.no_grad():
         for _ in range(args.settle):
             step(x)
@@ -858,6 +922,8 @@ def main():
                                "frac_of_hbm_peak": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
                                "frac_of_hbm_achievable": round(layer_bytes / (ms * 1e-3) * 1e-9 / HBM_ACHIEVABLE_GBS, 4)},
         }
+        if world == 1 and parity is not None:
+            out["parity"] = parity
         if world > 1:
             ok_modes = [m for m in ep_modes if m["value"] is not None]
             bm = max(ok_modes, key=lambda m: m["value"]) if ok_modes else None

@@ -454,7 +454,7 @@ int tutel_amd_marks_report(double *delta_us, int n);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG / TUTEL_AMD_DECODE /
- * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS / TUTEL_AMD_EP_CANARY / TUTEL_AMD_GEMM_SPLITK / TUTEL_AMD_GEMM_GATHER / TUTEL_AMD_FUSED_LOCATION / TUTEL_AMD_GEMM_STORE seed it once), >= 0 = force.  Every choice computes bit-identical results (excepted: TUTEL_OPT_EP_CANARY = 2 provokes the error it tests; TUTEL_OPT_GEMM_SPLITK changes the fp32 summation order).
+ * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS / TUTEL_AMD_EP_CANARY / TUTEL_AMD_GEMM_SPLITK / TUTEL_AMD_GEMM_GATHER / TUTEL_AMD_FUSED_LOCATION / TUTEL_AMD_GEMM_STORE / TUTEL_AMD_TIE_RULE seed it once), >= 0 = force.  Every choice computes bit-identical results (excepted: TUTEL_OPT_EP_CANARY = 2 provokes the error it tests; TUTEL_OPT_GEMM_SPLITK changes the fp32 summation order; TUTEL_OPT_TIE_RULE = 0 changes which of two EXACTLY equal scores is chosen).
  *   TUTEL_OPT_GEMM_IMPL  kernels of the <= 128-rows-per-expert regime: 0 register-staged 128 x 128, 1 LDS-DMA 128 x 128, 4 the
  *                        128 x 256 tile on a three-slot LDS-DMA ring (k-major weights; automatic when its grid covers the chip)
  *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
@@ -483,6 +483,10 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *                        write-through (sc0 sc1: the tile streams out while the kernel runs and stays valid in L2 for the next kernel),
  *                        0 = plain stores (the tile stays dirty in the XCD's L2 and what is left is written back when the kernel ends,
  *                        after the last wave: rounds 1-4), 2 = non-temporal; buffer stores through a descriptor, same values and addresses
+ *   TUTEL_OPT_TIE_RULE   top-k among EXACTLY equal scores: 1 / automatic = the expert ids the reference's CPU path gets from torch.topk
+ *                        (tutel/impls/fast_dispatch.py:146-148; ATen's nth_element / partial_sort over (value, index) pairs replayed per
+ *                        tied row, csrc/topk_ties.h; launches of more than ~1024 experts keep the order below), 0 = descending score,
+ *                        lowest expert index first (rounds 1-5)
  *   TUTEL_OPT_EP_CANARY  IPC transport: epoch canaries behind every exchanged block (1 / automatic = written by the producers and
  *                        checked by the wait kernels; 0 = off; 2 = TEST INJECTION: this rank publishes the previous epoch, as if
  *                        its rows had not landed when its flag did -- the peers must report it)
@@ -498,7 +502,8 @@ int tutel_amd_marks_report(double *delta_us, int n);
 #define TUTEL_OPT_GEMM_GATHER 8
 #define TUTEL_OPT_FUSED_LOCATION 9
 #define TUTEL_OPT_GEMM_STORE 10
-#define TUTEL_OPT_COUNT 11
+#define TUTEL_OPT_TIE_RULE 11
+#define TUTEL_OPT_COUNT 12
 int tutel_amd_set_option(int key, int value);
 
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------

@@ -20,14 +20,14 @@
 #include <string.h>
 
 /* ------------------------------------------------------------------------------------------
- * top-k expert selection.
+ * top-k expert selection, "lowest index" tie rule (the product's TUTEL_OPT_TIE_RULE = 0; oracle tie_rule="lowest").
  * Reference: tutel/impls/fast_dispatch.py:146-148  (torch.topk(scores, k, dim=1).indices, then
- * one index vector per choice).  torch.topk's order among EXACTLY equal scores is unspecified
- * (CPU nth_element based) -- SURVEY.md section 7 hard part 1.  This oracle pins the rule the
- * HIP kernel implements: descending score, ties broken towards the LOWEST expert index.  On
- * tie-free rows this equals torch.topk (checked against the reference in tests).
+ * one index vector per choice).  On tie-free rows this IS torch.topk; among EXACTLY equal scores
+ * torch.topk's CPU kernel returns what libstdc++'s nth_element / partial_sort leave there -- that
+ * order, the default of both the oracle and the product since round 6, is restated in
+ * oracle/aten_topk.c.  Here: descending score, ties broken towards the LOWEST expert index.
  * idx layout: [k][T] int32 (one contiguous vector per choice, as the reference's indices_s).
- * NaN scores: a NaN never compares greater, so NaNs are selected last (not exercised).
+ * NaN scores: a NaN never compares greater, so NaNs are selected last.
  * ---------------------------------------------------------------------------------------- */
 #define DEFINE_TOPK(NAME, TYPE)                                                              \
   void NAME(const TYPE *scores, int T, int E, int k, int32_t *idx) {                         \

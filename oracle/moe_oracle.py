@@ -53,18 +53,29 @@ def _p(t):
 # ---------------------------------------------------------------------------------------------
 # routing
 # ---------------------------------------------------------------------------------------------
-def topk_indices(scores, k):
-    """k index vectors [T] int32: descending score, ties -> lowest expert index.
-    Reference: fast_dispatch.py:146-148 (torch.topk; tie order unspecified there, pinned here)."""
+TIE_RULE = "aten"   # "aten": the reference's CPU torch.topk, ties included (aten_topk.c); "lowest": lowest expert index first (the
+                    # product's TUTEL_OPT_TIE_RULE = 0; rounds 1-5)
+
+
+def topk_indices(scores, k, tie_rule=None):
+    """k index vectors [T] int32 -- torch.topk(scores, k, dim=1).indices of the reference's CPU path (fast_dispatch.py:146-148),
+    INCLUDING its order among exactly equal scores: ATen's CPU kernel (nth_element / partial_sort over (value, index) pairs with a
+    value-only comparator) restated in oracle/aten_topk.c and pinned against live torch.topk on tie-heavy rows
+    (tests/test_oracle_vs_reference.py).  tie_rule="lowest": descending score, ties -> lowest expert index (tie-free rows: the same)."""
     T, E = scores.shape
     k = min(k, E)
+    rule = tie_rule or TIE_RULE
+    assert rule in ("aten", "lowest")
     idx = torch.empty([k, T], dtype=torch.int32)
+    L = _lib()
     if scores.dtype == torch.float64:
         s = scores.contiguous()
-        _lib().orc_topk_f64(_p(s), T, E, k, _p(idx))
+        fn = L.orc_aten_topk_f64 if rule == "aten" else L.orc_topk_f64
     else:
-        s = scores.float().contiguous()  # bf16/fp16 -> fp32 is exact, ordering preserved
-        _lib().orc_topk_f32(_p(s), T, E, k, _p(idx))
+        s = scores.float().contiguous()  # bf16/fp16 -> fp32 is exact, ordering (and NaN-ness) preserved
+        fn = L.orc_aten_topk_f32 if rule == "aten" else L.orc_topk_f32
+    rc = fn(_p(s), T, E, k, _p(idx))
+    assert rule == "lowest" or rc == 0
     return [idx[j].clone() for j in range(k)]
 
 

@@ -199,6 +199,28 @@ def headline_low_precision_gate_case(dts, seed=11):
                 dispatch_count=np_(crit[5].to(torch.int32)), l_aux=np.array([float(l_aux)]))
 
 
+def headline_fp32_gate_case(dts, seed=0):
+    """BASELINE configs[1] with `fp32_gate=True` (gates/top.py:7-22: the projection in fp32 whatever the experts' dtype): the
+    reference's routing at T = 4096, M = 2048, E = 64, k = 2 from the LAYER's own logits (its nn.Linear gate on make_problem's tokens,
+    not softmax(randn) like headline_integers.npz) -- idx / loc / counts for the element-wise test of the HIP layer at the headline
+    shape.  Only the gate is built (H = 8); the test regenerates x / wg with the same arguments (make_problem draws them first)."""
+    dtype = DT[dts]
+    T, M, H, E, k = 4096, 2048, 8, 64, 2
+    layer, (x, wg, *_rest) = build_reference_layer(T, M, H, E, k, 1.0, dtype, True, True, True, seed)
+    with torch.no_grad():
+        logits = layer.gates[0](x)
+        assert logits.dtype == torch.float32
+        scores = torch.softmax(logits, dim=1)
+        crit, l_aux = ref_moe.top_k_routing(scores, k, capacity_factor=1.0)
+        top3 = torch.topk(scores, k + 1, dim=1).values
+    return dict(meta=np.array([T, M, H, E, k, seed], dtype=np.int64), dtype=np.array([dts]), in_checksum=np.array([checksum([x, wg])]),
+                idx=np.stack([np_(i) for i in crit[1]]).astype(np.int32), loc=np.stack([np_(i) for i in crit[2]]).astype(np.int32),
+                capacity=np.array([crit[4]]), dispatch_count=np_(crit[5].to(torch.int32)), l_aux=np.array([float(l_aux)]),
+                # smallest relative gap between neighbouring scores among each row's three largest: rows below ~1e-6 could legitimately
+                # order differently under another fp32 summation order of the gate GEMM (there are none in these fixtures)
+                min_rel_gap=np.array([float(((top3[:, :-1] - top3[:, 1:]) / top3[:, :-1]).min())]))
+
+
 def train_losses_case(E_loc=2, k=2, steps=4, T=1024, M=256, H=256, seed=5):
     """A short training replay in the style of the reference's golden-loss tests
     (tests/test_tutel.py:94-148 over examples/helloworld.py:126-146): fwd + bwd + SGD, fp32."""
@@ -286,15 +308,16 @@ def check_oracle_against_reference():
                 co, lo = O.extract_critical(scores, k, cf, normalize_gate=norm)
                 tag = f"{dts} T={T} E={E} k={k} cf={cf} norm={norm}"
                 same_idx = all(torch.equal(a, b) for a, b in zip(cr[1], co[1]))
-                if dtype in (torch.float32, torch.float64):
-                    expect(same_idx, "topk indices " + tag)  # tie-free: must equal torch.topk
-                if not same_idx:  # exact ties (bf16/fp16): compare everything downstream of the tie
-                    co, lo = O.extract_critical(scores, k, cf, normalize_gate=norm, topk_override=cr[1])
-                    # and the tie rule itself must only differ on rows that really tie
-                    oi = torch.stack(O.topk_indices(scores, k)); ri = torch.stack(cr[1])
-                    rows = (oi != ri).any(0)
-                    s_o = scores.gather(1, oi.t().long())[rows]; s_r = scores.gather(1, ri.t().long())[rows]
-                    expect(torch.equal(s_o.sort(1)[0], s_r.sort(1)[0]), "tie rows pick equal scores " + tag)
+                # every dtype, exact ties of the 16-bit scores included: the oracle's top-k IS the reference's CPU torch.topk
+                # (oracle/aten_topk.c restates ATen's kernel, tie order and all) -- no "downstream of the tie" escape any more
+                expect(same_idx, "topk indices " + tag)
+                if dtype in (torch.bfloat16, torch.float16) and T >= 512:
+                    top = torch.topk(scores.float(), min(k + 1, E), dim=1).values
+                    expect(bool((top[:, 1:] == top[:, :-1]).any()), "the 16-bit cases are meant to contain exact ties " + tag)
+                    li = torch.stack(O.topk_indices(scores, k, tie_rule="lowest")); ri = torch.stack(cr[1])
+                    rows = (li != ri).any(0)
+                    s_o = scores.gather(1, li.t().long())[rows]; s_r = scores.gather(1, ri.t().long())[rows]
+                    expect(torch.equal(s_o.sort(1)[0], s_r.sort(1)[0]), "the lowest-index rule differs on tied rows only " + tag)
                 expect(all(torch.equal(a, b) for a, b in zip(cr[2], co[2])), "locations " + tag)
                 expect(all(torch.equal(a, b) for a, b in zip(cr[3], co[3])), "gates " + tag)
                 expect(cr[4] == co[4], "capacity " + tag)
@@ -482,12 +505,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--only-headline-gate", action="store_true", help="(re)write only headline_gate_*.npz")
+    ap.add_argument("--only-headline-fp32-gate", action="store_true", help="(re)write only headline_fp32gate_*.npz")
     args = ap.parse_args()
     if args.only_headline_gate:
         for dts in ("bfloat16", "float16"):
             out = headline_low_precision_gate_case(dts)
             np.savez_compressed(os.path.join(HERE, f"headline_gate_{dts}.npz"), **out)
             print("wrote headline_gate", dts, int(out["capacity"][0]), float(out["l_aux"][0]))
+        return
+    if args.only_headline_fp32_gate:
+        for dts in ("bfloat16", "float16"):
+            out = headline_fp32_gate_case(dts)
+            np.savez_compressed(os.path.join(HERE, f"headline_fp32gate_{dts}.npz"), **out)
+            print("wrote headline_fp32gate", dts, int(out["capacity"][0]), float(out["l_aux"][0]), float(out["min_rel_gap"][0]))
         return
     if args.check:
         n = check_oracle_against_reference()
@@ -508,6 +538,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "headline_integers.npz"), **headline_integer_case())
     for dts in ("bfloat16", "float16"):
         np.savez_compressed(os.path.join(HERE, f"headline_gate_{dts}.npz"), **headline_low_precision_gate_case(dts))
+        np.savez_compressed(os.path.join(HERE, f"headline_fp32gate_{dts}.npz"), **headline_fp32_gate_case(dts))
     # batch-prioritised routing (fast_dispatch.py:138-141,155-157): tokens ranked by -max score get buckets first
     g = torch.Generator().manual_seed(31)
     bpr = {}

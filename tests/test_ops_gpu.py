@@ -82,17 +82,54 @@ def test_gate_topk_and_location_vs_oracle(oracle, dtype, T, E, k):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_gate_topk_ties_lowest_index(oracle, dtype):
-    """Exact ties (common in bf16, SURVEY hard part 1): the pinned rule is lowest expert index."""
+def test_gate_topk_ties_follow_the_reference_cpu_topk(oracle, dtype):
+    """Exact ties (2 % of the rows at the headline shape with a bf16 gate, SURVEY hard part 1): the expert ids are the ones the
+    reference's CPU path gets from torch.topk (fast_dispatch.py:146-148) -- compared here with LIVE torch.topk on the CPU, not only
+    with the oracle's restatement of it.  TUTEL_OPT_TIE_RULE = 0 is the lowest-index rule of rounds 1-5."""
+    from tutel_amd import _lib
     ops = _ops()
     scores = torch.full([130, 64], 1.0 / 64).to(dtype)
     scores[1, 5] = 0.5
     scores[2, 63] = 0.25
     scores[2, 0] = 0.25
-    idx, _, _, _ = ops.gate_topk(scores.cuda(), 3)
-    idx_o = torch.stack(oracle.topk_indices(scores, 3))
-    assert torch.equal(idx.cpu(), idx_o)
+    want = torch.topk(scores, 3, dim=1).indices.to(torch.int32).t()
+    idx, gates, _, _ = ops.gate_topk(scores.cuda(), 3)
+    assert torch.equal(idx.cpu(), want) and torch.equal(idx.cpu(), torch.stack(oracle.topk_indices(scores, 3)))
+    crit, _ = oracle.extract_critical(scores, 3, 1.0)
+    assert torch.equal(gates.cpu().float(), torch.stack(crit[3]).float())
+    ops.set_option(_lib.OPT_TIE_RULE, 0)
+    try:
+        idx, _, _, _ = ops.gate_topk(scores.cuda(), 3)
+    finally:
+        ops.set_option(_lib.OPT_TIE_RULE, -1)
+    assert torch.equal(idx.cpu(), torch.stack(oracle.topk_indices(scores, 3, tie_rule="lowest")))
     assert idx.cpu()[:, 0].tolist() == [0, 1, 2] and idx.cpu()[:, 1].tolist() == [5, 0, 1] and idx.cpu()[:, 2].tolist() == [0, 63, 1]
+
+
+@pytest.mark.parametrize("E", [1, 2, 3, 7, 16, 33, 64, 65, 96, 127, 128, 129, 192, 256, 300, 1024])
+def test_gate_topk_tie_heavy_rows_equal_torch_topk_on_the_cpu(oracle, E):
+    """Rows drawn from a handful of distinct values (nearly every row ties, many at the k / k+1 boundary, some hold NaNs) through both
+    top-k kernels (16 lanes per token for E <= 128, a wave per token above) and both of ATen's branches (partial_sort when k * 64 <= E,
+    nth_element + sort otherwise): idx must be torch.topk's CPU answer element for element, gates the scores at those ids, and the
+    locations built on them the oracle's."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(100 + E)
+    for k in [1, 2, 3, 4, 8, 16]:
+        if k > E or k * E > 8192:
+            continue
+        for levels, dt in [(1, torch.float32), (2, torch.bfloat16), (3, torch.float16), (5, torch.float32), (17, torch.bfloat16), (3, torch.float64)]:
+            T = 333
+            s = (torch.randint(0, levels, (T, E), generator=g).to(torch.float32) / 8).to(dt)
+            if levels == 3:
+                s[::5, E // 2] = float("nan")
+            want = torch.topk(s, k, dim=1).indices.to(torch.int32).t()
+            idx, gates, ws, _ = ops.gate_topk(s.cuda(), k, normalize_gate=False)
+            assert torch.equal(idx.cpu(), want), (E, k, levels, dt, int((idx.cpu() != want).sum()))
+            raw = torch.stack([s.gather(1, i.long().unsqueeze(-1)).squeeze(-1) for i in want])
+            assert torch.equal(gates.cpu().double().nan_to_num(-7.0), raw.double().nan_to_num(-7.0))
+            loc, cnt, *_ = ops.compute_location(idx, E, ws=ws, capacity=0)
+            loc_o, cnt_o = oracle.compute_locations(list(want), E)
+            assert torch.equal(loc.cpu(), torch.stack(loc_o)) and torch.equal(cnt.cpu(), cnt_o)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -138,9 +138,9 @@ def test_headline_integer_fixture(oracle):
 @pytest.mark.parametrize("dts", ["bfloat16", "float16"])
 def test_headline_low_precision_gate_fixture(oracle, dts):
     """BASELINE configs[1] with the gate as bench.py runs it (`fp32_gate=False`): the reference's own logits / scores / routing.
-    On the reference's scores the oracle's expert ids equal the reference's except on rows with EXACT score ties (torch.topk leaves
-    their order unspecified, the oracle takes the lowest index): every differing token is such a tie, and the count is what
-    DESIGN section 2 quotes (89 tokens / 120 of 8192 assignments in bf16, 15 / 20 in fp16)."""
+    On the reference's scores the oracle's expert ids, slots and counts EQUAL the reference's on every row -- including the 89 (bf16) /
+    15 (fp16) tokens whose 16-bit scores tie exactly at the k / k+1 boundary, where the answer is whatever ATen's CPU top-k leaves
+    (oracle/aten_topk.c).  The lowest-index rule of rounds 1-5 (tie_rule="lowest") differs on exactly those rows."""
     dtype = getattr(torch, dts)
     z = np.load(os.path.join(GOLD, f"headline_gate_{dts}.npz"))
     T, M, H, E, k, seed = [int(v) for v in z["meta"]]
@@ -148,14 +148,53 @@ def test_headline_low_precision_gate_fixture(oracle, dts):
     assert abs(float(z["in_checksum"][0]) - float(x.double().abs().sum() + wg.double().abs().sum())) < 1e-6 * float(z["in_checksum"][0])
     scores, idx_r = torch.from_numpy(z["scores"]).view(dtype), torch.from_numpy(z["idx"])
     crit, _ = oracle.extract_critical(scores, k, 1.0)
-    idx_o = torch.stack(crit[1]).to(torch.int32)
-    diff = torch.nonzero((idx_o != idx_r).any(0)).flatten().tolist()
+    assert torch.equal(torch.stack(crit[1]).to(torch.int32), idx_r)
+    assert torch.equal(torch.stack(crit[2]), torch.from_numpy(z["loc"])) and torch.equal(crit[5], torch.from_numpy(z["dispatch_count"]))
+    assert torch.equal(torch.stack(crit[3]).view(torch.int16), torch.from_numpy(z["gates"]))
+    idx_l = torch.stack(oracle.topk_indices(scores, k, tie_rule="lowest"))
+    diff = torch.nonzero((idx_l != idx_r).any(0)).flatten().tolist()
     for t in diff:
-        assert all(scores[t, idx_o[j, t]] == scores[t, idx_r[j, t]] for j in range(k)), f"token {t}: not a tie"
-    assert (len(diff), int((idx_o != idx_r).sum())) == ((89, 120) if dts == "bfloat16" else (15, 20))
-    # with the reference's own choice on the tied rows everything downstream is the reference's
-    loc_o, cnt_o = oracle.compute_locations([idx_r[j] for j in range(k)], E)
-    assert torch.equal(torch.stack(loc_o), torch.from_numpy(z["loc"])) and torch.equal(cnt_o, torch.from_numpy(z["dispatch_count"]))
+        assert all(scores[t, idx_l[j, t]] == scores[t, idx_r[j, t]] for j in range(k)), f"token {t}: not a tie"
+    assert (len(diff), int((idx_l != idx_r).sum())) == ((89, 120) if dts == "bfloat16" else (15, 20))
+
+
+@pytest.mark.parametrize("dts", ["bfloat16", "float16"])
+def test_headline_fp32_gate_fixture(oracle, dts):
+    """BASELINE configs[1] with fp32_gate=True: the reference's routing of make_problem's tokens through its own nn.Linear gate at
+    T = 4096, E = 64 (the fixture the HIP layer is compared with element-wise, tests/test_layer_gpu.py) equals the oracle's."""
+    dtype = getattr(torch, dts)
+    z = np.load(os.path.join(GOLD, f"headline_fp32gate_{dts}.npz"))
+    T, M, H, E, k, seed = [int(v) for v in z["meta"]]
+    x, wg, *_ = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed)
+    scores, _ = oracle.gate_scores(x, wg, True)
+    crit, l_aux = oracle.extract_critical(scores, k, 1.0)
+    assert torch.equal(torch.stack(crit[1]).to(torch.int32), torch.from_numpy(z["idx"])) and torch.equal(torch.stack(crit[2]), torch.from_numpy(z["loc"]))
+    assert torch.equal(crit[5], torch.from_numpy(z["dispatch_count"])) and crit[4] == int(z["capacity"][0])
+    assert abs(float(l_aux) - float(z["l_aux"][0])) < 1e-6 and float(z["min_rel_gap"][0]) > 1e-5
+
+
+def test_aten_topk_restatement_equals_torch_topk(oracle):
+    """oracle/aten_topk.c (ATen's CPU top-k + the libstdc++ routines under it, restated) against LIVE torch.topk of this box's torch --
+    the op the reference calls (fast_dispatch.py:146) -- on rows made of a few distinct values, so that nearly every row ties: both
+    branches (partial_sort for k * 64 <= E, nth_element + sort otherwise), every dtype the gate can have, NaNs (sorted first)."""
+    g = torch.Generator().manual_seed(0)
+    n = 0
+    for E in list(range(1, 40)) + [63, 64, 65, 96, 127, 128, 129, 192, 256, 300, 1024]:
+        for k in [1, 2, 3, 4, 8, 16]:
+            if k > E:
+                continue
+            for levels in [1, 2, 3, 17]:
+                for dt in [torch.float32, torch.bfloat16, torch.float16, torch.float64]:
+                    s = (torch.randint(0, levels, (48, E), generator=g).to(torch.float32) / 8).to(dt)
+                    if levels == 3:
+                        s[::5, E // 2] = float("nan")
+                    want = torch.topk(s, k, dim=1).indices.to(torch.int32).t()
+                    assert torch.equal(torch.stack(oracle.topk_indices(s, k)), want), (E, k, levels, dt)
+                    n += 1
+    s = torch.softmax(torch.randn(4096, 64, generator=g), 1).bfloat16()          # the headline's kind of row
+    assert torch.equal(torch.stack(oracle.topk_indices(s, 2)), torch.topk(s, 2, dim=1).indices.to(torch.int32).t())
+    assert not torch.equal(torch.stack(oracle.topk_indices(s, 2, tie_rule="lowest")), torch.topk(s, 2, dim=1).indices.to(torch.int32).t())
+    assert n > 3000
 
 
 def test_oracle_edge_cases(oracle):

@@ -39,6 +39,12 @@ struct StageScope {
 // arrived, reads them back with system-scope loads: a flag that overtook the rows of its own kernel (the failure the peer-store
 // protocol must never show, and the one a one-GPU lease cannot provoke) leaves canaries of the previous epoch behind and is
 // reported instead of being consumed silently.
+// What a matching canary does NOT prove: the words are written by the LAST min(grid, EP_NCAN) blocks after a block-local
+// barrier -- their own row stores have been ISSUED in front of them on the same path, the stores of the other blocks (dispatched
+// earlier, normally finished earlier) are not waited for.  A stale canary is therefore proof that a flag overtook rows; a fresh
+// one is strong evidence, not proof, that it did not.  It is a detector that turns the one failure this protocol must never show
+// into an error on the NEXT call -- not a fence; the ordering itself comes from the signal kernel running after the producer on
+// the same stream.  TUTEL_OPT_EP_CANARY must be set alike on every rank (a rank that checks words its peer never writes misfires).
 #define EP_NCAN 16
 struct PeerCanary {
   const uint32_t *epoch;  // device: epochs signalled so far for this (direction, stage); the producer publishes *epoch + 1 (nullptr: off)

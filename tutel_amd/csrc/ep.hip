@@ -1063,9 +1063,22 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
             (long long)k * T <= 15360 && m->fl_ws != nullptr && m->fl_ws_bytes >= (((size_t)k * T + 15) & ~(size_t)15) &&
             (a.dtype == TUTEL_BF16 || a.dtype == TUTEL_F16) && a.row_counts == nullptr && a.hid && a.send && a.zero_row && a.loc && a.w1 &&
             ((uintptr_t)m->fl_ws & 15) == 0;
-  if (fl)
+  // the fused-location branch calls tutel_gate_topk_launch directly, i.e. past the public entry point's argument checks: the same
+  // ones here (a C caller with an undersized `ws` got an out-of-bounds device write instead of an error)
+  if (fl) {
+    TUTEL_REQUIRE(k >= 1 && k <= E, "tutel_amd_moe_forward: need 1 <= k <= E (got k=%d, E=%d)", k, E);
+    TUTEL_REQUIRE(m->ws_bytes >= tutel_amd_routing_workspace_bytes(T, E, k), "tutel_amd_moe_forward: routing workspace too small (%zu bytes, need %zu)",
+                  m->ws_bytes, tutel_amd_routing_workspace_bytes(T, E, k));
+  }
+  if (fl) {
+    // eligibility query (loc == NULL: nothing is launched); a "no" is an answer, not an error -- last_error keeps what it held
+    char keep[512];
+    strncpy(keep, tutel_amd_last_error(), sizeof(keep) - 1);
+    keep[sizeof(keep) - 1] = 0;
     fl = tutel_expert_gemm_gather_fl(a.x, a.M, smap, T, a.zero_row, a.w1, (int64_t)Ho * a.M, a.M, a.b1, Ho, a.hid, (int64_t)a.capacity * Ho, Ho, E,
                                      a.capacity, Ho, a.M, a.dtype, a.act, (const uint8_t *)m->fl_ws, k * T, nullptr, (hipStream_t)stream) == 0;
+    if (!fl) tutel_set_error("%s", keep);
+  }
   if (fl) {
     hipStream_t st = (hipStream_t)stream;
     uint8_t *idx8 = (uint8_t *)m->fl_ws;

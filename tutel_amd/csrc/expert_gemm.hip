@@ -781,19 +781,20 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
   const uint16_t *a_src[4], *w_src[WPW];
   int gr4[4], slot4[4];
   // SG (round 5; the ring kernels with buffer-descriptor DMA): the slot-map entries of the fused fast_encode come through the SCALAR
-  // cache -- the wave's 32 token-tile rows are 32 consecutive map entries, 4 x s_buffer_load_dwordx8 (out-of-range entries read 0 and
-  // belong to rows past the row count, whose DMA is pointed out of range anyway) -- and the token-tile addresses are worked out only
-  // AFTER the weight pieces of the first tiles have been issued.  As vector loads the four lookups sat in front of the first DMA
-  // (s_waitcnt vmcnt(0) before any weight byte was requested: one dependent L2 round trip at the head of every block), and moving
-  // the weight issue above them would not have helped: vmcnt retires in order, so waiting for the lookups would have meant waiting
-  // for the weight data.  Scalar loads count on lgkmcnt.
+  // cache -- the wave's 32 token-tile rows are 32 consecutive map entries, 4 x s_load_dwordx8 -- and the token-tile addresses are
+  // worked out only AFTER the weight pieces of the first tiles have been issued.  As vector loads the four lookups sat in front of
+  // the first DMA (s_waitcnt vmcnt(0) before any weight byte was requested: one dependent L2 round trip at the head of every block),
+  // and moving the weight issue above them would not have helped: vmcnt retires in order, so waiting for the lookups would have meant
+  // waiting for the weight data.  Scalar loads count on lgkmcnt.  Round 6: they are ordinary loads from the constant
+  // address space at a wave-uniform address, so the COMPILER places -- and tracks -- the lgkmcnt wait in front of their first use
+  // (round 5 issued them from inline assembly with the wait in a second asm statement: nothing stopped hipcc from copying or
+  // spilling the destination registers in between).  A wave whose 32 entries would reach past the map takes the vector lookups.
   constexpr bool SG = BUF && NS == 3;
-  sgv8 sg_q[4];
+  typedef int sgv8u __attribute__((ext_vector_type(8), aligned(4)));
+  sgv8u sg_q[4];
   const bool fl_on = FL && p.fl_idx8 != nullptr;             // block-uniform
-  const bool sg_on = SG && p.a_rows != nullptr && p.sgather && !fl_on;  // block-uniform
-  const unsigned long long mb_ = (unsigned long long)reinterpret_cast<uintptr_t>(p.a_rows);
-  const sgv4 rs_m = {(int)(unsigned)mb_, (int)((mb_ >> 32) & 0xffff), (int)((unsigned)p.E_loc * (unsigned)p.R * 4u), 0x00020000};
-  const int mo_ = (e * p.R + m0 + 32 * wid) * 4;
+  const int mo_ = e * p.R + m0 + 32 * wid;                   // first map entry of this wave's rows (wave-uniform)
+  const bool sg_on = SG && p.a_rows != nullptr && p.sgather && !fl_on && mo_ + 32 <= p.E_loc * p.R;  // wave-uniform
 #pragma unroll
   for (int i = 0; i < 4; ++i) gr4[i] = min(m0 + 8 * (wid * 4 + i) + (lane >> 3), p.R - 1);
   if (!sg_on && !fl_on) gather_rows4(p, e, gr4, slot4);
@@ -993,14 +994,15 @@ __global__ __launch_bounds__(BM * 2, 2) void expert_gemm_big_kernel(GemmArgs p) 
       asm volatile("" ::"s"(reinterpret_cast<uintptr_t>(We)), "s"(rot), "s"(nk), "s"((int)w_once), "s"((int)(w_step * 2)));
 #pragma unroll
       for (int i = 0; i < WPW; ++i) asm volatile("" ::"v"(w_off[i]));
+      const __attribute__((address_space(4))) sgv8u *mp =
+          reinterpret_cast<const __attribute__((address_space(4))) sgv8u *>(reinterpret_cast<uintptr_t>(p.a_rows) + (size_t)mo_ * 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("s_buffer_load_dwordx8 %0, %1, %2" : "=&s"(sg_q[i]) : "s"(rs_m), "s"(mo_ + i * 32));
+      for (int i = 0; i < 4; ++i) sg_q[i] = mp[i];
     }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
       if (t < nk) GB_ISSUE_W(t, t);
-    if (sg_on) {  // the weight stream is on its way: now the slot-map entries and the token addresses
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sg_q[0]), "+s"(sg_q[1]), "+s"(sg_q[2]), "+s"(sg_q[3]));
+    if (sg_on) {  // the weight stream is on its way: now the slot-map entries (first use: hipcc waits here) and the token addresses
       const int rl_ = lane >> 3;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1647,8 +1649,10 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t st) {
   const bool ring256 = ring256_ok && (impl == 4 || (impl < 0 && (long long)a.E_loc * ((a.N + 255) / 256) >= 256));
   // Fused location FIRST: a request for it (or the eligibility query, fl_loc == NULL) must never fall into one of the launches
   // below -- only the 128 x 256 ring kernel has the fused form (capacity <= 128 rows per expert), and a query launches nothing.
+  // K >= 128: the prologue's `s_waitcnt vmcnt(16)` counts the weight DMA of TWO K-tiles behind the idx bytes (with one
+  // K-tile only 8 follow and the wait would not cover them).
   if (a.fl_idx8 != nullptr) {
-    if (!(ring256 && KM && big <= 0 && a.a_rows != nullptr && a.row_counts == nullptr && a.fl_n >= 1 && a.fl_n <= 15360 && a.E_loc <= 128)) {
+    if (!(ring256 && KM && big <= 0 && a.a_rows != nullptr && a.row_counts == nullptr && a.fl_n >= 1 && a.fl_n <= 15360 && a.E_loc <= 128 && a.K >= 2 * GL_BK)) {
       tutel_set_error("tutel_expert_gemm_gather_fl: this launch does not take the fused-location ring kernel");
       return TUTEL_AMD_ENOTSUP;
     }

@@ -21,6 +21,7 @@
 // per-op rounding in the scores dtype.
 #include "common.h"
 #include "routing_dev.h"
+#include "topk_ties.h"
 
 #define GT_THREADS 1024  // gate_topk: 16 waves per tile, 4 interleaved tokens per wave
 #define GT_WAVES 16
@@ -50,11 +51,15 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
     const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
-    int clear_n) {
+    int clear_n, int tie_mode) {
   using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);             // [k][E]
   float *s_col = reinterpret_cast<float *>(smem) + (size_t)k * E;  // [GT_WAVES][min(E, GT_COL_SLAB)]
+  // tie_mode (topk_ties.h): one row + one queue per wave.  Shares its bytes with s_col, which is only used after the token loop.
+  CT *s_tv = reinterpret_cast<CT *>(smem + (((size_t)k * E * 4 + 7) & ~(size_t)7)) + (size_t)(threadIdx.x >> 6) * E;  // [GT_WAVES][E]
+  uint16_t *s_tp = reinterpret_cast<uint16_t *>(reinterpret_cast<CT *>(smem + (((size_t)k * E * 4 + 7) & ~(size_t)7)) + (size_t)GT_WAVES * E) +
+                   (size_t)(threadIdx.x >> 6) * E;                                                                       // [GT_WAVES][E]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.x;
@@ -133,22 +138,28 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
           }
         }
     }
+    unsigned long long nanm[GT_BATCH];  // bit j: this lane's j-th expert holds a NaN
 #pragma unroll
-    for (int u = 0; u < GT_BATCH; ++u)
+    for (int u = 0; u < GT_BATCH; ++u) {
+      nanm[u] = 0;
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
         int e = lane + 64 * j;
         if (e < E && live[u]) colacc[j] += (float)v[u][j];  // token order u = 0..3: deterministic
-        if (v[u][j] != v[u][j]) v[u][j] = -INFINITY;  // NaN sorts last
+        if (v[u][j] != v[u][j]) { v[u][j] = -INFINITY; nanm[u] |= 1ull << j; }  // NaN sorts last here (tie_mode replays such rows: first, as in ATen)
       }
+    }
 
-    // k rounds of wave arg-max, order: score desc, expert index asc.
+    // k rounds of wave arg-max, order: score desc, expert index asc.  tie_mode: one more round finds the (k + 1)-th score -- two
+    // equal neighbours among the k + 1 largest is the only way this order can differ from torch.topk's.
     unsigned long long taken[GT_BATCH];   // bit j: this lane's j-th expert was picked in an earlier round (EPL <= 64)
-    CT myg[GT_BATCH];
+    CT myg[GT_BATCH], prev[GT_BATCH];
     int myidx[GT_BATCH];
+    bool tied[GT_BATCH];
 #pragma unroll
-    for (int u = 0; u < GT_BATCH; ++u) { taken[u] = 0; myg[u] = 0; myidx[u] = -1; }
-    for (int c = 0; c < k; ++c) {
+    for (int u = 0; u < GT_BATCH; ++u) { taken[u] = 0; myg[u] = 0; myidx[u] = -1; prev[u] = 0; tied[u] = false; }
+    const int rounds = tie_mode ? k + 1 : k;
+    for (int c = 0; c < rounds; ++c) {
       CT bv[GT_BATCH];
       int be[GT_BATCH];
 #pragma unroll
@@ -172,8 +183,42 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
         }
 #pragma unroll
       for (int u = 0; u < GT_BATCH; ++u) {
-        if ((be[u] & 63) == lane) taken[u] |= 1ull << (be[u] >> 6);
-        if (lane == c) { myg[u] = bv[u]; myidx[u] = be[u]; }
+        if (c > 0 && bv[u] == prev[u] && be[u] != 0x7fffffff) tied[u] = true;  // wave-uniform
+        prev[u] = bv[u];
+        if (c < k) {
+          if ((be[u] & 63) == lane) taken[u] |= 1ull << (be[u] >> 6);
+          if (lane == c) { myg[u] = bv[u]; myidx[u] = be[u]; }
+        }
+      }
+    }
+    if (tie_mode) {
+#pragma unroll
+      for (int u = 0; u < GT_BATCH; ++u) {
+        if (__ballot(nanm[u] != 0ull) != 0ull) tied[u] = true;
+        if (tied[u] && live[u]) {  // wave-uniform: lane 0 replays ATen's CPU top-k over the row
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) {
+            int e = lane + 64 * j;
+            if (e < E) {
+              s_tv[e] = ((nanm[u] >> j) & 1ull) ? (CT)NAN : v[u][j];
+              s_tp[e] = (uint16_t)e;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) {
+            AtenTopk<CT, uint16_t> ts{s_tv, s_tp};
+            ts.run(E, k);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (lane < k) {
+            myidx[u] = s_tp[lane];
+            myg[u] = s_tv[myidx[u]];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
     // gates: raw score, optionally normalised by clamp(((0+g0)+g1)+..., eps) in dtype T.
@@ -350,12 +395,15 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     const T *__restrict__ in, int apply_softmax, int Tn, int E, int k, int normalize, int tile,
     T *__restrict__ scores_out, int32_t *__restrict__ idx, T *__restrict__ gates,
     int32_t *__restrict__ ws_hist, float *__restrict__ ws_colsum, int32_t *__restrict__ clear_map,
-    int clear_n, const float *__restrict__ part, int nsplit, T *__restrict__ logits_out, uint8_t *__restrict__ idx8) {
+    int clear_n, const float *__restrict__ part, int nsplit, T *__restrict__ logits_out, uint8_t *__restrict__ idx8, int tie_mode) {
   using CT = typename Elem<T>::ct;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ES = GQ_LPT * EPQ + 1;                                    // padded row of the score tile
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);                // [k][E]
   float *s_sc = reinterpret_cast<float *>(smem) + (size_t)k * E;      // [64][ES]
+  // tie_mode (topk_ties.h): rows with a NaN or a tie among their k + 1 largest scores are replayed through ATen's CPU top-k by one lane
+  CT *s_tv = reinterpret_cast<CT *>(smem + ((((size_t)k * E + (size_t)64 * ES) * 4 + 7) & ~(size_t)7));   // [64][E] the row
+  uint16_t *s_tp = reinterpret_cast<uint16_t *>(s_tv + (size_t)64 * E);                                  // [64][E] the queue
 
   const int tid = threadIdx.x, q = tid & (GQ_LPT - 1), tl = tid / GQ_LPT;  // tl = token slot 0..63
   const int b = blockIdx.x;
@@ -456,16 +504,23 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       }
     }
     // score tile -> LDS for the deterministic column sums
+    uint32_t nanm = 0;  // bit j: element j is a NaN
 #pragma unroll
     for (int j = 0; j < EPQ; ++j) {
       int e = q * EPQ + j;
       if (e < E) s_sc[tl * ES + e] = live ? (float)v[j] : 0.f;
-      if (v[j] != v[j]) v[j] = -INFINITY;  // NaN sorts last
+      if (v[j] != v[j]) { v[j] = -INFINITY; nanm |= 1u << j; }  // NaN sorts last here (tie_mode: such rows are replayed below, where it sorts FIRST as in ATen)
     }
 
+    // k rounds of arg-max over the row's 16 lanes, order: score desc, expert index asc; choice c is parked on lane c of the row
+    // (k <= 16).  tie_mode: one more round finds the (k + 1)-th score -- two equal neighbours among the k + 1 largest is the only way
+    // the order above can differ from torch.topk's.
     uint32_t taken = 0;
-    CT myg = 0, denom = 0;
-    for (int c = 0; c < k; ++c) {
+    CT myg = 0, prev = 0;
+    int myidx = 0;
+    bool tied = false;
+    const int rounds = tie_mode ? k + 1 : k;  // block-uniform
+    for (int c = 0; c < rounds; ++c) {
       CT bv = -INFINITY;
       int be = 0x7fffffff;
 #pragma unroll
@@ -480,23 +535,58 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
         int oe = __shfl_xor(be, o, 64);
         if (ov > bv || (ov == bv && oe < be)) { bv = ov; be = oe; }
       }
-      if (be / EPQ == q) taken |= 1u << (be - q * EPQ);
-      denom = (c == 0) ? bv : round_to<T>(denom + bv);   // ((0+g0)+g1)+... rounded in dtype T
-      if (c == q) myg = bv;                              // choice c parked on lane c of the row (k <= 16)
-      if (q == 0 && live) {
-        idx[(size_t)c * Tn + t] = be;
-        if (idx8 != nullptr) idx8[(size_t)c * Tn + t] = (uint8_t)be;  // byte copy for the in-GEMM location scan (expert_gemm.hip, FL)
-        atomicAdd(&s_hist[c * E + be], 1);
+      if (c > 0 && bv == prev && be != 0x7fffffff) tied = true;  // (be == 0x7fffffff: the probe round of k == E found nothing)
+      prev = bv;
+      if (c < k) {
+        if (be / EPQ == q) taken |= 1u << (be - q * EPQ);
+        if (c == q) { myg = bv; myidx = be; }
       }
     }
-    if (q < k && live) {
-      CT g = myg;
-      if (normalize && k > 1) {
-        CT d = ct_max(denom, (CT)Elem<T>::eps());
-        if (denom != denom) d = denom;  // torch.clamp keeps NaN
-        g = g / d;
+    if (tie_mode) {
+      const int rowsh = (int)(threadIdx.x & 48);  // first lane of this row inside the wave
+      if ((__ballot(nanm != 0) >> rowsh) & 0xffffull) tied = true;
+      if (__ballot(tied && live) != 0ull) {  // wave-uniform: some row of this wave is replayed
+        if (tied) {
+#pragma unroll
+          for (int j = 0; j < EPQ; ++j) {
+            int e = q * EPQ + j;
+            if (e < E) {
+              s_tv[tl * E + e] = ((nanm >> j) & 1u) ? (CT)NAN : v[j];
+              s_tp[tl * E + e] = (uint16_t)e;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the row's 16 lanes share a wave: LDS operations of a wave complete in order
+        __builtin_amdgcn_wave_barrier();
+        if (tied && q == 0) {
+          AtenTopk<CT, uint16_t> ts{s_tv + tl * E, s_tp + tl * E};
+          ts.run(E, k);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (tied && q < k) {
+          myidx = s_tp[tl * E + q];
+          myg = s_tv[tl * E + myidx];
+        }
       }
-      gates[(size_t)q * Tn + t] = Elem<T>::from_f32(g);
+    }
+    // gates: raw score, optionally normalised by clamp(((0+g0)+g1)+..., eps), every sum rounded in dtype T
+    {
+      const int row0 = (int)(threadIdx.x & 48);
+      CT denom = __shfl(myg, row0, 64);
+      for (int c = 1; c < k; ++c) denom = round_to<T>(denom + __shfl(myg, row0 + c, 64));
+      if (q < k && live) {
+        CT g = myg;
+        if (normalize && k > 1) {
+          CT d = ct_max(denom, (CT)Elem<T>::eps());
+          if (denom != denom) d = denom;  // torch.clamp keeps NaN
+          g = g / d;
+        }
+        gates[(size_t)q * Tn + t] = Elem<T>::from_f32(g);
+        idx[(size_t)q * Tn + t] = myidx;
+        if (idx8 != nullptr) idx8[(size_t)q * Tn + t] = (uint8_t)myidx;  // byte copy for the in-GEMM location scan (expert_gemm.hip, FL)
+        atomicAdd(&s_hist[q * E + myidx], 1);
+      }
     }
     __syncthreads();
     if (tid < E) {
@@ -561,15 +651,31 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
   const int tile = rt_tile(Tn), nt = rt_ntiles(Tn);
   int32_t *ws_hist = (int32_t *)ws;
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
-  size_t lds = ((size_t)k * E + (size_t)GT_WAVES * (E < GT_COL_SLAB ? E : GT_COL_SLAB)) * 4;
+  using CTh = typename Elem<T>::ct;
+  // TUTEL_OPT_TIE_RULE: 1 / automatic = equal scores come out in the order of the reference's CPU torch.topk (topk_ties.h), 0 = lowest
+  // expert index first (rounds 1-5).  The replay needs one row + one queue in LDS per concurrently replayed token; launches whose
+  // expert count does not leave room for that (E > ~1024) keep the lowest-index order.
+  int tie_mode = tutel_get_option(TUTEL_OPT_TIE_RULE) != 0;
+  size_t lds = (size_t)k * E * 4 + 8;
+  {
+    const size_t col = (size_t)GT_WAVES * (E < GT_COL_SLAB ? E : GT_COL_SLAB) * 4, tie = (size_t)GT_WAVES * E * (sizeof(CTh) + 2);
+    if (lds + tie > 160 * 1024) tie_mode = 0;
+    lds += tie_mode && tie > col ? tie : col;
+  }
   if (E <= 128) {
     const int epq = (E + GQ_LPT - 1) / GQ_LPT;                 // 1..8
     const int epq_t = epq <= 1 ? 1 : (epq <= 2 ? 2 : (epq <= 4 ? 4 : 8));
-    const size_t lds_q = ((size_t)k * E + (size_t)64 * (GQ_LPT * epq_t + 1)) * 4;
+    const size_t lds_q = ((size_t)k * E + (size_t)64 * (GQ_LPT * epq_t + 1)) * 4 + 8 + (tie_mode ? (size_t)64 * E * (sizeof(CTh) + 2) : 0);
 #define GQ_LAUNCH(EPQ)                                                                         \
-    hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ>), dim3(nt), dim3(GQ_THREADS), lds_q, st,            \
-                       (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,          \
-                       idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, part, nsplit, (T *)logits_out, idx8)
+    do {                                                                                       \
+      if (lds_q > 65536) {                                                                     \
+        (void)hipFuncSetAttribute((const void *)gate_topk_quad_kernel<T, EPQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q); \
+        (void)hipGetLastError();                                                               \
+      }                                                                                        \
+      hipLaunchKernelGGL((gate_topk_quad_kernel<T, EPQ>), dim3(nt), dim3(GQ_THREADS), lds_q, st,            \
+                         (const T *)in, apply_softmax, Tn, E, k, normalize, tile, (T *)scores_out,          \
+                         idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, part, nsplit, (T *)logits_out, idx8, tie_mode); \
+    } while (0)
     if (epq_t == 1) GQ_LAUNCH(1);
     else if (epq_t == 2) GQ_LAUNCH(2);
     else if (epq_t == 4) GQ_LAUNCH(4);
@@ -589,7 +695,7 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
     }                                                                                           \
     hipLaunchKernelGGL((gate_topk_kernel<T, EPL, (EPL <= 4 ? 4 : (EPL <= 8 ? 2 : 1))>), dim3(nt), dim3(GT_THREADS), lds, st,         \
                        (const T *)in, apply_softmax, Tn, E, k, normalize, tile,                 \
-                       (T *)scores_out, idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n);  \
+                       (T *)scores_out, idx, (T *)gates, ws_hist, ws_col, clear_map, clear_n, tie_mode);  \
   } while (0)
   if (epl <= 1) GT_LAUNCH(1);
   else if (epl <= 2) GT_LAUNCH(2);

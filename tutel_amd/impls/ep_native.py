@@ -29,11 +29,16 @@ FAST_PATH = int(os.environ.get("TUTEL_AMD_FAST_PATH", "1")) != 0  # routing + pi
 _FUSED_LOCATION = int(os.environ.get("TUTEL_AMD_FUSED_LOCATION", "1")) != 0  # hand the one-call path its fused-location scratch (single rank)
 HOSTED = int(os.environ.get("TUTEL_AMD_NATIVE_HOSTED", "0")) != 0  # bring-up / tests: native pipeline over a gloo group, exchange staged by the host
 # How the bucket rows travel between the ranks of a node:
-#   "auto"  peer stores over xGMI (IPC transport, csrc/ep.hip) when every rank can map every other rank's segment and the tagged
-#           self-check passes on all of them; RCCL's all-to-all on the library communicator otherwise
-#   "ipc"   the same, and also for process groups that are not on the "nccl" backend (ranks that share one GPU: the tests)
+#   "auto"  RCCL's all-to-all on the library communicator (north_star's exchange: all_to_all_single on separate streams) for ranks on
+#           different devices -- since round 6: the peer-store transport below has only ever run between rank
+#           processes that SHARE one GPU, and the first multi-GPU run should not have to debug two transports at once.  Set
+#           TUTEL_AMD_EP_IPC_VERIFIED=1 once tests/test_multi_gpu_rccl.py has passed on the hardware in question to make "auto" prefer
+#           the peer stores again (attach + payload-sized self-check, RCCL when that fails)
+#   "ipc"   peer stores over xGMI (IPC transport, csrc/ep.hip) when every rank can map every other rank's segment and the tagged
+#           self-check passes on all of them; also for process groups that are not on the "nccl" backend (ranks that share one GPU: the tests)
 #   "rccl"  never attach the IPC transport
 TRANSPORT = os.environ.get("TUTEL_AMD_EP_TRANSPORT", "auto").lower()
+IPC_VERIFIED = os.environ.get("TUTEL_AMD_EP_IPC_VERIFIED", "0") == "1"
 # how long a wait kernel spins for a peer's flag before it gives up and the NEXT call reports which peer never arrived: the order of a
 # collective watchdog (NCCL's default is 10 minutes; 2 minutes here) -- ranks may legitimately be seconds to minutes apart (data loading, a first-call
 # code-object load with eight processes on one box)
@@ -403,7 +408,7 @@ def communicator(group, device):
                 c = None   # an IPC-only communicator without its transport cannot exchange anything
         else:
             c = _create(group, device)
-            if TRANSPORT != "rccl":
+            if TRANSPORT == "ipc" or (TRANSPORT == "auto" and (IPC_VERIFIED or c is None)):
                 if c is None:
                     c = _create_ipc_only(group, device)
                     if c is not None and not _attach_ipc(c, group, device):

@@ -302,6 +302,10 @@ class MOELayer(torch.nn.Module):
             return None
         if torch.is_autocast_enabled() or ops.gate_proj_splits(x.shape[0], x.shape[1], w.shape[0], x.dtype) == 0:
             return None
+        # the split-K kernel fetches 16-byte vectors: a contiguous but offset view (a slice of a larger buffer) stays on F.linear
+        # instead of raising from the forward.  Non-contiguous x is made contiguous (a fresh allocation) by the caller.
+        if w.data_ptr() % 16 or (x.is_contiguous() and x.data_ptr() % 16):
+            return None
         return w
 
     def _run_native_moe(self, x, logits, top_k, cf, degree, alignment, megablocks_size, gate_w=None):

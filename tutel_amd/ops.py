@@ -329,7 +329,7 @@ def expert_gemm_gather(x, smap, w, bias, w_kmajor, act, R, row_counts=None, row_
 _OPT_ENV = {_lib.OPT_GEMM_IMPL: "TUTEL_AMD_GEMM_IMPL", _lib.OPT_GEMM_TILE: "TUTEL_AMD_GEMM_BIG", _lib.OPT_DECODE: "TUTEL_AMD_DECODE",
             _lib.OPT_EP_STAGE_GRID: "TUTEL_AMD_EP_STAGE_GRID", _lib.OPT_GEMM_PERSIST: "TUTEL_AMD_GEMM_PERSIST", _lib.OPT_EP_STREAMS: "TUTEL_AMD_EP_STREAMS",
             _lib.OPT_EP_CANARY: "TUTEL_AMD_EP_CANARY", _lib.OPT_GEMM_SPLITK: "TUTEL_AMD_GEMM_SPLITK", _lib.OPT_GEMM_STORE: "TUTEL_AMD_GEMM_STORE",
-            _lib.OPT_GEMM_GATHER: "TUTEL_AMD_GEMM_GATHER", _lib.OPT_FUSED_LOCATION: "TUTEL_AMD_FUSED_LOCATION"}
+            _lib.OPT_GEMM_GATHER: "TUTEL_AMD_GEMM_GATHER", _lib.OPT_FUSED_LOCATION: "TUTEL_AMD_FUSED_LOCATION", _lib.OPT_TIE_RULE: "TUTEL_AMD_TIE_RULE"}
 _opts = {}
 
 
