@@ -316,8 +316,14 @@ def single_rank_parity(layer, step, T, M, k, dtype, dev, graphed):
     w1, b1 = ex.batched_fc1_w.detach().cpu(), ex.batched_fc1_bias.detach().cpu()
     w2, b2 = ex.batched_fc2_w.detach().cpu(), ex.batched_fc2_bias.detach().cpu()
     cf = float(layer.gates[0].capacity_factor)
+    from tutel_amd import _lib as _L
+    rule, O.TIE_RULE = O.TIE_RULE, ("lowest" if ops.get_option(_L.OPT_TIE_RULE) == 0 else "aten")   # the checker follows TUTEL_OPT_TIE_RULE
+    try:
+        with torch.no_grad():
+            crit, _ = O.extract_critical(scores, k, cf)
+    finally:
+        O.TIE_RULE = rule
     with torch.no_grad():
-        crit, _ = O.extract_critical(scores, k, cf)
         ok_idx = bool(torch.equal(torch.stack(crit[1]).to(torch.int32), idx.cpu())) and bool(torch.equal(torch.stack(crit[2]), loc.cpu()))
         ok_cnt = bool(torch.equal(cnt.cpu(), crit[5]))
         enc = O.fast_encode(x2.view(-1, M), crit)

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           if (lane == 0) {
-            AtenTopk<CT, uint16_t> ts{s_tv, s_tp};
+            LdsQueue<CT, uint16_t> lq{s_tv, s_tp};
+            AtenTopk<CT, LdsQueue<CT, uint16_t>> ts(lq);
             ts.run(E, k);
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -401,9 +402,12 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
   const int ES = GQ_LPT * EPQ + 1;                                    // padded row of the score tile
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);                // [k][E]
   float *s_sc = reinterpret_cast<float *>(smem) + (size_t)k * E;      // [64][ES]
-  // tie_mode (topk_ties.h): rows with a NaN or a tie among their k + 1 largest scores are replayed through ATen's CPU top-k by one lane
-  CT *s_tv = reinterpret_cast<CT *>(smem + ((((size_t)k * E + (size_t)64 * ES) * 4 + 7) & ~(size_t)7));   // [64][E] the row
-  uint16_t *s_tp = reinterpret_cast<uint16_t *>(s_tv + (size_t)64 * E);                                  // [64][E] the queue
+  // tie_mode (topk_ties.h): rows with a NaN or a tie among their k + 1 largest scores are replayed through ATen's CPU top-k, one row at
+  // a time by the whole wave (the queue in registers, one position per lane)
+  CT *s_tv = reinterpret_cast<CT *>(smem + ((((size_t)k * E + (size_t)64 * ES) * 4 + 7) & ~(size_t)7));   // [64][E] the rows to replay
+  uint8_t *s_sel = reinterpret_cast<uint8_t *>(s_tv + (size_t)64 * E) + (size_t)(threadIdx.x >> 6) * 256;   // [16 waves][256] rank -> position tables
+  __shared__ int s_nlist[2];   // rows handed to the replay in this pass / the next one
+  __shared__ int s_list[64];   // their token slots
 
   const int tid = threadIdx.x, q = tid & (GQ_LPT - 1), tl = tid / GQ_LPT;  // tl = token slot 0..63
   const int b = blockIdx.x;
@@ -415,10 +419,13 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     for (int i = c0 + tid; i < c1; i += GQ_THREADS) clear_map[i] = -1;
   }
   for (int i = tid; i < k * E; i += GQ_THREADS) s_hist[i] = 0;
+  if (tid < 2) s_nlist[tid] = 0;
   float colsum = 0.f;  // thread e < E accumulates column e over the tile, in token order
   __syncthreads();
 
+  int pass = -1;
   for (int ts = t0; ts < t1; ts += 64) {
+    ++pass;
     const int t = ts + tl;
     const bool live = t < t1;
     CT v[EPQ];
@@ -545,29 +552,14 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
     if (tie_mode) {
       const int rowsh = (int)(threadIdx.x & 48);  // first lane of this row inside the wave
       if ((__ballot(nanm != 0) >> rowsh) & 0xffffull) tied = true;
-      if (__ballot(tied && live) != 0ull) {  // wave-uniform: some row of this wave is replayed
-        if (tied) {
+      if (tied && live) {
+        // the row is handed to the replay below: its scores (NaNs restored) go to LDS, its token slot onto this pass's list
 #pragma unroll
-          for (int j = 0; j < EPQ; ++j) {
-            int e = q * EPQ + j;
-            if (e < E) {
-              s_tv[tl * E + e] = ((nanm >> j) & 1u) ? (CT)NAN : v[j];
-              s_tp[tl * E + e] = (uint16_t)e;
-            }
-          }
+        for (int j = 0; j < EPQ; ++j) {
+          int e = q * EPQ + j;
+          if (e < E) s_tv[tl * E + e] = ((nanm >> j) & 1u) ? (CT)NAN : v[j];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the row's 16 lanes share a wave: LDS operations of a wave complete in order
-        __builtin_amdgcn_wave_barrier();
-        if (tied && q == 0) {
-          AtenTopk<CT, uint16_t> ts{s_tv + tl * E, s_tp + tl * E};
-          ts.run(E, k);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (tied && q < k) {
-          myidx = s_tp[tl * E + q];
-          myg = s_tv[tl * E + myidx];
-        }
+        if (q == 0) s_list[atomicAdd(&s_nlist[pass & 1], 1)] = tl;
       }
     }
     // gates: raw score, optionally normalised by clamp(((0+g0)+g1)+..., eps), every sum rounded in dtype T
@@ -575,7 +567,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       const int row0 = (int)(threadIdx.x & 48);
       CT denom = __shfl(myg, row0, 64);
       for (int c = 1; c < k; ++c) denom = round_to<T>(denom + __shfl(myg, row0 + c, 64));
-      if (q < k && live) {
+      if (q < k && live && !(tie_mode && tied)) {
         CT g = myg;
         if (normalize && k > 1) {
           CT d = ct_max(denom, (CT)Elem<T>::eps());
@@ -593,6 +585,43 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       float s = colsum;
       for (int r = 0; r < 64; ++r) s += s_sc[r * ES + tid];
       colsum = s;
+    }
+    // ---- the replay of the tied rows (topk_ties.h): one row per wave at a time, by the waves that have no column to sum -- the
+    // column sums above are a 64-step dependent chain on the first E / 64 waves, so a block with up to ~15 tied rows (the headline
+    // shape has 2.7 per block on average) replays them in the shadow of work that was on its critical path anyway
+    if (tie_mode) {
+      const int wv = (int)(threadIdx.x >> 6), nbusy = (E + 63) >> 6, wl = (int)(threadIdx.x & 63);
+      constexpr int SL = (GQ_LPT * EPQ + 63) / 64;  // register slots per lane: queue position i = (lane i & 63, slot i >> 6)
+      const int nrep = s_nlist[pass & 1];
+      for (int ent = wv - nbusy; ent >= 0 && ent < nrep; ent += GQ_THREADS / 64 - nbusy) {  // wave-uniform
+        const int trow = s_list[ent], tt = ts + trow;
+        WaveQueue<CT, SL> wq;
+        wq.sel = s_sel;
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {
+          const int e = wl + 64 * sl;
+          wq.v[sl] = e < E ? s_tv[trow * E + e] : (CT)0;
+          wq.id[sl] = e;
+        }
+        AtenTopk<CT, WaveQueue<CT, SL>> tk(wq);
+        tk.run(E, k);
+        // choice c sits at queue position c: lane c, slot 0 (k <= 16)
+        CT denom = tk_readlane(wq.v[0], 0);
+        for (int c = 1; c < k; ++c) denom = round_to<T>(denom + tk_readlane(wq.v[0], c));
+        if (wl < k) {
+          CT g = wq.v[0];
+          if (normalize && k > 1) {
+            CT d = ct_max(denom, (CT)Elem<T>::eps());
+            if (denom != denom) d = denom;  // torch.clamp keeps NaN
+            g = g / d;
+          }
+          gates[(size_t)wl * Tn + tt] = Elem<T>::from_f32(g);
+          idx[(size_t)wl * Tn + tt] = wq.id[0];
+          if (idx8 != nullptr) idx8[(size_t)wl * Tn + tt] = (uint8_t)wq.id[0];
+          atomicAdd(&s_hist[wl * E + wq.id[0]], 1);
+        }
+      }
+      if (tid == 0) s_nlist[(pass + 1) & 1] = 0;  // the next pass's list (last used by the previous pass: its readers are past their barrier)
     }
     __syncthreads();
   }
@@ -665,7 +694,7 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
   if (E <= 128) {
     const int epq = (E + GQ_LPT - 1) / GQ_LPT;                 // 1..8
     const int epq_t = epq <= 1 ? 1 : (epq <= 2 ? 2 : (epq <= 4 ? 4 : 8));
-    const size_t lds_q = ((size_t)k * E + (size_t)64 * (GQ_LPT * epq_t + 1)) * 4 + 8 + (tie_mode ? (size_t)64 * E * (sizeof(CTh) + 2) : 0);
+    const size_t lds_q = ((size_t)k * E + (size_t)64 * (GQ_LPT * epq_t + 1)) * 4 + 8 + (tie_mode ? (size_t)64 * E * sizeof(CTh) + 16 * 256 : 0);
 #define GQ_LAUNCH(EPQ)                                                                         \
     do {                                                                                       \
       if (lds_q > 65536) {                                                                     \

@@ -8,123 +8,294 @@
 //     else        :  std::nth_element(q, q + k - 1, q + n, gt);  std::sort(q, q + k - 1, gt)
 // over q = [(value, index)] in index order: which of two equal scores comes out first is whatever libstdc++'s introselect / heap
 // select leave there -- a pure function of the row, so it can be reproduced.  The top-k kernels (routing.hip) keep their parallel
-// wave arg-max for the rows where the answer is unique and hand only the rows that carry a NaN or a tie among their k + 1 largest scores
-// (one extra arg-max round detects them) to ONE lane, which replays the two library routines below over the row in LDS: the queue is
-// kept as expert ids (`p`), values are looked up in the read-only row (`val`).  Statement-by-statement restatements of
-// <bits/stl_algo.h> / <bits/stl_heap.h> (GCC 11..14); the tests compare the kernels with live torch.topk on the CPU, element for
-// element, on tie-heavy rows (tests/test_ops_gpu.py).  k <= 16 here, so std::sort(q, q + k - 1) is its insertion-sort tail only (threshold 16).
+// arg-max for the rows where the answer is unique and replay the two library routines only over the rows that carry a NaN or a tie
+// among their k + 1 largest scores (one extra arg-max round detects them).  The routines below are statement-by-statement
+// restatements of <bits/stl_algo.h> / <bits/stl_heap.h> (GCC 11..14), written once over a QUEUE POLICY that says where the
+// (value, index) pairs live:
+//   WaveQueue  one wave works on one row, queue position i in lane i & 63 (register slot i >> 6): an element is fetched with
+//              v_readlane and stored with a one-lane move, all control flow wave-uniform -- and the two loops that walk the whole
+//              range, introselect's partition and heap_select's scan, are done for all positions AT ONCE with ballots (see
+//              partition()).  Measured at the headline shape (170 of 4096 rows replayed): queue in LDS under one lane 47 us for the
+//              top-k kernel (8 us without ties; every access a ~100-cycle dependent round trip), queue in registers with the
+//              sequential loops 36 us (instruction count: ~5 k dependent instructions per row).  Used for E <= 128.
+//   LdsQueue   one lane, queue of expert ids in LDS beside the read-only row: any E (the wave-per-token kernel, E > 128).
+// The tests compare the kernels with live torch.topk on the CPU, element for element, on tie-heavy rows (tests/test_ops_gpu.py).
+// k <= 16 here, so std::sort(q, q + k - 1) is its insertion-sort tail only (threshold 16).
 #pragma once
 #include "common.h"
 
-template <typename CT, typename IT> struct AtenTopk {
-  const CT *val;  // [n] the row
-  IT *p;          // [n] the queue: expert ids
+template <typename CT> struct TkElem { CT v; int id; };
 
-  __device__ __forceinline__ bool gt(int a, int b) const {  // a, b: expert ids
-    const CT x = val[a], y = val[b];
-    return ((x != x) && !(y != y)) || x > y;
+template <typename CT> __device__ __forceinline__ bool tk_gt(const TkElem<CT> &x, const TkElem<CT> &y) {
+  return ((x.v != x.v) && !(y.v != y.v)) || x.v > y.v;
+}
+
+// ---- queue policies ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tk_readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ double tk_readlane(double x, int l) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <typename CT, int SL> struct WaveQueue {  // every call is made by the whole wave with wave-uniform arguments
+  CT v[SL];
+  int id[SL];
+  uint8_t *sel;  // LDS scratch of this wave, 2 * n bytes (n <= 64 * SL <= 256 queue positions): see partition()
+  __device__ __forceinline__ TkElem<CT> get(int i) const {
+    TkElem<CT> e;
+    e.v = tk_readlane(v[0], i & 63);
+    e.id = __builtin_amdgcn_readlane(id[0], i & 63);
+#pragma unroll
+    for (int s = 1; s < SL; ++s)
+      if ((i >> 6) == s) {  // uniform
+        e.v = tk_readlane(v[s], i & 63);
+        e.id = __builtin_amdgcn_readlane(id[s], i & 63);
+      }
+    return e;
   }
-  // ---- <bits/stl_heap.h>
-  __device__ void push_heap(int first, int hole, int top, int value) {
+  __device__ __forceinline__ void set(int i, const TkElem<CT> &e) {
+    const bool me = (int)(threadIdx.x & 63) == (i & 63);
+#pragma unroll
+    for (int s = 0; s < SL; ++s)
+      if ((i >> 6) == s) {  // uniform
+        v[s] = me ? e.v : v[s];
+        id[s] = me ? e.id : id[s];
+      }
+  }
+  // smallest position i' in [i, last) whose element is gt(., top), or -1: one ballot per slot instead of a scan (heap_select)
+  __device__ __forceinline__ int next_gt(int i, int last, const TkElem<CT> &top) const {
+    const int lane = (int)(threadIdx.x & 63);
+    int found = -1;
+#pragma unroll
+    for (int s = SL - 1; s >= 0; --s) {
+      const int pos = lane + 64 * s;
+      TkElem<CT> e{v[s], id[s]};
+      const unsigned long long m = __ballot(pos >= i && pos < last && tk_gt(e, top));
+      if (m != 0ull) found = 64 * s + (int)__builtin_ctzll(m);
+    }
+    return found;
+  }
+  // libstdc++'s __unguarded_partition(first + 1, last, pivot = *first), all positions at once.  The sequential loop stops its left
+  // cursor at the successive positions A = {p : !gt(q[p], pivot)} in ascending order and its right cursor at B = {p : !gt(pivot, q[p])}
+  // in descending order, swapping the i-th of one with the i-th of the other while a_i < b_i; a cursor only ever examines positions
+  // no swap has touched, or -- as its guard -- the most recently swapped one.  So: both sets by ballot, the rank of every member by
+  // popcount, the partner through a rank -> position table in LDS, s = #{i : a_i < b_i} swaps done in one exchange, and the returned
+  // cut is min(a_s, b_{s-1}) (the next untouched stop of the left cursor, or the guard the last swap left behind).
+  __device__ __forceinline__ int partition(int first, int last, const TkElem<CT> &pivot) {
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long lt = (1ull << lane) - 1ull, gtm = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    unsigned long long mA[SL], mB[SL];
+    bool a[SL], b[SL];
+    int nA = 0, nB = 0;
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      const int pos = lane + 64 * s;
+      const bool inr = pos > first && pos < last;
+      TkElem<CT> e{v[s], id[s]};
+      a[s] = inr && !tk_gt(e, pivot);
+      b[s] = inr && !tk_gt(pivot, e);
+      mA[s] = __ballot(a[s]);
+      mB[s] = __ballot(b[s]);
+      nA += __popcll(mA[s]);
+      nB += __popcll(mB[s]);
+    }
+    uint8_t *selA = sel, *selB = sel + 64 * SL;
+    int rA[SL], rB[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      int ra = __popcll(mA[s] & lt), rb = __popcll(mB[s] & gtm);
+#pragma unroll
+      for (int s2 = 0; s2 < SL; ++s2) {
+        if (s2 < s) ra += __popcll(mA[s2]);
+        if (s2 > s) rb += __popcll(mB[s2]);
+      }
+      rA[s] = ra;
+      rB[s] = rb;
+      if (a[s]) selA[ra] = (uint8_t)(lane + 64 * s);
+      if (b[s]) selB[rb] = (uint8_t)(lane + 64 * s);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int pp[SL];      // partner position, or -1
+    int nsw = 0;
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      const int pos = lane + 64 * s;
+      pp[s] = -1;
+      bool swa = false;
+      if (a[s] && rA[s] < nB) {
+        const int pb = selB[rA[s]];
+        if (pos < pb) { pp[s] = pb; swa = true; }
+      }
+      if (b[s] && rB[s] < nA) {
+        const int pa = selA[rB[s]];
+        if (pa < pos) pp[s] = pa;
+      }
+      nsw += __popcll(__ballot(swa));
+    }
+    // the exchange: every new value is read from the OLD registers first
+    CT nv[SL];
+    int ni[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      nv[s] = v[s];
+      ni[s] = id[s];
+#pragma unroll
+      for (int s2 = 0; s2 < SL; ++s2) {
+        const CT fv = __shfl(v[s2], pp[s] & 63, 64);
+        const int fi = __shfl(id[s2], pp[s] & 63, 64);
+        if (pp[s] >= 0 && (pp[s] >> 6) == s2) { nv[s] = fv; ni[s] = fi; }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < SL; ++s) { v[s] = nv[s]; id[s] = ni[s]; }
+    int cut = 0x7fffffff;
+    if (nsw < nA) cut = selA[nsw];
+    if (nsw >= 1) { const int g = selB[nsw - 1]; cut = g < cut ? g : cut; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tables are rewritten by the next call
+    __builtin_amdgcn_wave_barrier();
+    return __builtin_amdgcn_readfirstlane(cut);
+  }
+};
+
+template <typename CT, typename IT> struct LdsQueue {
+  const CT *val;  // [n] the row (read only)
+  IT *p;          // [n] the queue: expert ids
+  __device__ __forceinline__ TkElem<CT> get(int i) const {
+    TkElem<CT> e;
+    e.id = p[i];
+    e.v = val[e.id];
+    return e;
+  }
+  __device__ __forceinline__ void set(int i, const TkElem<CT> &e) { p[i] = (IT)e.id; }
+  __device__ __forceinline__ int next_gt(int i, int last, const TkElem<CT> &top) const {
+    for (; i < last; ++i)
+      if (tk_gt(get(i), top)) return i;
+    return -1;
+  }
+  __device__ __forceinline__ int partition(int first, int last, const TkElem<CT> &pivot) {  // __unguarded_partition(first + 1, last, first)
+    int f = first + 1, l = last;
+    for (;;) {
+      while (tk_gt(get(f), pivot)) ++f;
+      --l;
+      while (tk_gt(pivot, get(l))) --l;
+      if (!(f < l)) return f;
+      const TkElem<CT> x = get(f), y = get(l);
+      set(f, y);
+      set(l, x);
+      ++f;
+    }
+  }
+};
+
+// ---- the library routines ---------------------------------------------------------------------------------------------------
+template <typename CT, typename Q> struct AtenTopk {
+  using E = TkElem<CT>;
+  Q &q;
+  __device__ __forceinline__ explicit AtenTopk(Q &queue) : q(queue) {}
+
+  // <bits/stl_heap.h>
+  __device__ __forceinline__ void push_heap(int first, int hole, int top, const E &value) {
     int parent = (hole - 1) / 2;
-    while (hole > top && gt(p[first + parent], value)) {
-      p[first + hole] = p[first + parent];
+    while (hole > top) {
+      const E pe = q.get(first + parent);
+      if (!tk_gt(pe, value)) break;
+      q.set(first + hole, pe);
       hole = parent;
       parent = (hole - 1) / 2;
     }
-    p[first + hole] = (IT)value;
+    q.set(first + hole, value);
   }
-  __device__ void adjust_heap(int first, int hole, int len, int value) {
+  __device__ __forceinline__ void adjust_heap(int first, int hole, int len, const E &value) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
       child = 2 * (child + 1);
-      if (gt(p[first + child], p[first + child - 1])) child--;
-      p[first + hole] = p[first + child];
+      E c = q.get(first + child);
+      const E c1 = q.get(first + child - 1);
+      if (tk_gt(c, c1)) { child--; c = c1; }
+      q.set(first + hole, c);
       hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2) {
       child = 2 * (child + 1);
-      p[first + hole] = p[first + child - 1];
+      q.set(first + hole, q.get(first + child - 1));
       hole = child - 1;
     }
     push_heap(first, hole, top, value);
   }
-  __device__ void make_heap(int first, int last) {
+  __device__ __forceinline__ void make_heap(int first, int last) {
     const int len = last - first;
     if (len < 2) return;
     int parent = (len - 2) / 2;
     for (;;) {
-      adjust_heap(first, parent, len, p[first + parent]);
+      adjust_heap(first, parent, len, q.get(first + parent));
       if (parent == 0) return;
       parent--;
     }
   }
-  __device__ void pop_heap(int first, int last, int result) {
-    const int value = p[result];
-    p[result] = p[first];
+  __device__ __forceinline__ void pop_heap(int first, int last, int result) {
+    const E value = q.get(result);
+    q.set(result, q.get(first));
     adjust_heap(first, 0, last - first, value);
   }
-  __device__ void heap_select(int first, int middle, int last) {
+  __device__ __forceinline__ void heap_select(int first, int middle, int last) {
     make_heap(first, middle);
-    for (int i = middle; i < last; ++i)
-      if (gt(p[i], p[first])) pop_heap(first, middle, i);
+    // for (i = middle; i < last; ++i) if (gt(q[i], q[first])) pop_heap(first, middle, i) -- positions >= i are untouched originals
+    for (int i = middle;;) {
+      i = q.next_gt(i, last, q.get(first));
+      if (i < 0) break;
+      pop_heap(first, middle, i);
+      ++i;
+    }
   }
-  __device__ void partial_sort(int first, int middle, int last) {
+  __device__ __forceinline__ void partial_sort(int first, int middle, int last) {
     heap_select(first, middle, last);
     while (middle - first > 1) {  // __sort_heap
       --middle;
       pop_heap(first, middle, middle);
     }
   }
-  // ---- <bits/stl_algo.h>
+  // <bits/stl_algo.h>
   __device__ __forceinline__ void swap(int a, int b) {
-    const IT t = p[a];
-    p[a] = p[b];
-    p[b] = t;
+    const E x = q.get(a), y = q.get(b);
+    q.set(a, y);
+    q.set(b, x);
   }
-  __device__ void insertion_sort(int first, int last) {
+  __device__ __forceinline__ void insertion_sort(int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
-      const int v = p[i];
-      if (gt(v, p[first])) {
-        for (int j = i; j != first; --j) p[j] = p[j - 1];
-        p[first] = (IT)v;
+      const E v = q.get(i);
+      if (tk_gt(v, q.get(first))) {
+        for (int j = i; j != first; --j) q.set(j, q.get(j - 1));
+        q.set(first, v);
       } else {  // __unguarded_linear_insert
         int l = i, nx = i - 1;
-        while (gt(v, p[nx])) {
-          p[l] = p[nx];
+        for (;;) {
+          const E ne = q.get(nx);
+          if (!tk_gt(v, ne)) break;
+          q.set(l, ne);
           l = nx;
           --nx;
         }
-        p[l] = (IT)v;
+        q.set(l, v);
       }
     }
   }
-  __device__ int partition_pivot(int first, int last) {  // __unguarded_partition_pivot
+  __device__ __forceinline__ int partition_pivot(int first, int last) {  // __unguarded_partition_pivot
     const int mid = first + (last - first) / 2;
     {  // __move_median_to_first(first, first + 1, mid, last - 1)
       const int a = first + 1, b = mid, c = last - 1;
-      if (gt(p[a], p[b])) {
-        if (gt(p[b], p[c])) swap(first, b);
-        else if (gt(p[a], p[c])) swap(first, c);
-        else swap(first, a);
-      } else if (gt(p[a], p[c])) swap(first, a);
-      else if (gt(p[b], p[c])) swap(first, c);
-      else swap(first, b);
+      const E ea = q.get(a), eb = q.get(b), ec = q.get(c);
+      int s;
+      if (tk_gt(ea, eb)) s = tk_gt(eb, ec) ? b : (tk_gt(ea, ec) ? c : a);
+      else s = tk_gt(ea, ec) ? a : (tk_gt(eb, ec) ? c : b);
+      swap(first, s);
     }
-    int f = first + 1, l = last;
-    const int pivot = p[first];  // (the pivot element itself is never moved by the loop below)
-    for (;;) {
-      while (gt(p[f], pivot)) ++f;
-      --l;
-      while (gt(pivot, p[l])) --l;
-      if (!(f < l)) return f;
-      swap(f, l);
-      ++f;
-    }
+    return q.partition(first, last, q.get(first));  // (the pivot element itself is never moved by the partition)
   }
-  __device__ void nth_element(int nth, int n) {  // std::nth_element(q, q + nth, q + n)
+  __device__ __forceinline__ void nth_element(int nth, int n) {  // std::nth_element(q, q + nth, q + n)
     if (n == 0 || nth == n) return;
     int first = 0, last = n, depth = 0;
     for (int m = n; m > 1; m >>= 1) ++depth;
@@ -142,8 +313,8 @@ template <typename CT, typename IT> struct AtenTopk {
     }
     insertion_sort(first, last);
   }
-  // ATen topk_impl_loop, largest = sorted = true; on return p[0 .. k) are the chosen expert ids in torch.topk's order
-  __device__ __noinline__ void run(int n, int k) {
+  // ATen topk_impl_loop, largest = sorted = true; on return queue positions [0, k) hold the chosen experts in torch.topk's order
+  __device__ __forceinline__ void run(int n, int k) {
     if (k * 64 <= n) {
       partial_sort(0, k, n);
     } else {
