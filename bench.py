@@ -38,7 +38,7 @@ every launch (`stages`) -- all live, inside this script, on the same tensors.
 `roofline`: the dominant kernel is the fc1 grouped GEMM.  N = 1 (128 rows per expert):
 expert_gemm_big_kernel<bf16,k-major,relu,128 x 256 tile on a three-slot LDS-DMA ring> (round 4; rounds 1-3:
 expert_gemm_glds_kernel, 128 x 128) -- since round 5 its FL form, which also does fast_encode's row gather and the location step
-(no compute_location launch; `extra.round5_features_ms_per_step` switches that, the scalar slot-map lookups and the split-K gate
+(no compute_location launch; `extra.feature_ab_ms_per_step` switches that, the scalar slot-map lookups and the split-K gate
 projection off one at a time) --, HBM-bound; achieved = algorithmic bytes per launch
 (E_loc*H*M weights + E_loc*R*M tokens + E_loc*R*H hidden out, x2 bytes) / its average duration.
 256 rows or more per expert and launch (N > 1, --tokens 65536): expert_gemm_pp_kernel, MFMA-bound; achieved = flop
@@ -524,7 +524,7 @@ def modelled_scaling(M, H, T, E, k, C, dtype, dev):
 
 
 def round5_features(layer, x, fwd_kw, gate_timer):
-    """round 5's four changes to the headline path, each switched off in turn: ms per step of the HIP-graph replay of the same forward
+    """the changes of rounds 5 and 6 to the headline path, each switched in turn: ms per step of the HIP-graph replay of the same forward
     (median of 3 x 20 steps).  bench.py runs it in a child process (`--round5_features`): every capture brings a stream of its own."""
     from tutel_amd import _lib, ops
     from tutel_amd.impls import moe_layer as _ML
@@ -533,17 +533,22 @@ def round5_features(layer, x, fwd_kw, gate_timer):
     names = ["all on (as timed)", "location kernel instead of the in-GEMM scan",
              "fused location off + vector slot-map lookups in front of the weight DMA",
              "gate projection by F.linear (hipBLASLt) instead of the split-K kernel",
-             "plain (write-back) output stores in the expert GEMMs instead of write-through"]
-    # (TUTEL_OPT_FUSED_LOCATION, TUTEL_OPT_GEMM_GATHER, native gate, TUTEL_OPT_GEMM_STORE)
-    settings = [(-1, -1, True, -1), (0, -1, True, -1), (0, 0, True, -1), (-1, -1, False, -1), (-1, -1, True, 0)]
+             "plain (write-back) output stores in the expert GEMMs instead of write-through",
+             "round 6: exact ties by lowest expert index instead of the reference's CPU torch.topk order (TUTEL_OPT_TIE_RULE = 0; NOT the reference's assignment)",
+             "round 6: fc1 -> activation -> fc2 in one persistent launch (TUTEL_OPT_FFN_FUSED = 1; opt-in, same bits)"]
+    # (TUTEL_OPT_FUSED_LOCATION, TUTEL_OPT_GEMM_GATHER, native gate, TUTEL_OPT_GEMM_STORE, TUTEL_OPT_TIE_RULE, TUTEL_OPT_FFN_FUSED)
+    settings = [(-1, -1, True, -1, -1, -1), (0, -1, True, -1, -1, -1), (0, 0, True, -1, -1, -1), (-1, -1, False, -1, -1, -1), (-1, -1, True, 0, -1, -1),
+                (-1, -1, True, -1, 0, -1), (-1, -1, True, -1, -1, 1)]
     graphs = []
     try:
         # one capture per setting (the kernel choice is made at capture time, each graph keeps its own workspace), then the
         # graphs are replayed INTERLEAVED, three rounds: clocks and neighbours drift by more than the differences being measured
-        for fl, ga, ng, st in settings:
+        for fl, ga, ng, st, tr, ff in settings:
             ops.set_option(_lib.OPT_FUSED_LOCATION, fl)
             ops.set_option(_lib.OPT_GEMM_GATHER, ga)
             ops.set_option(_lib.OPT_GEMM_STORE, st)
+            ops.set_option(_lib.OPT_TIE_RULE, tr)
+            ops.set_option(_lib.OPT_FFN_FUSED, ff)
             _ML._NATIVE_GATE = ng
             layer.__dict__.pop("_ep_workspaces", None)
             with torch.no_grad():
@@ -564,9 +569,8 @@ def round5_features(layer, x, fwd_kw, gate_timer):
         feat["error"] = f"{type(ex).__name__}: {str(ex)[:200]}"
     finally:
         _ML._NATIVE_GATE = True
-        ops.set_option(_lib.OPT_GEMM_GATHER, -1)
-        ops.set_option(_lib.OPT_FUSED_LOCATION, -1)
-        ops.set_option(_lib.OPT_GEMM_STORE, -1)
+        for key in (_lib.OPT_GEMM_GATHER, _lib.OPT_FUSED_LOCATION, _lib.OPT_GEMM_STORE, _lib.OPT_TIE_RULE, _lib.OPT_FFN_FUSED):
+            ops.set_option(key, -1)
         layer.__dict__.pop("_ep_workspaces", None)
     return feat
 
@@ -888,6 +892,8 @@ def main():
             "metric": "MoE-layer fwd tokens/sec, 4096 tok x H=2048 x E=64 top-2",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "settle": args.settle, "launch": launch,
+            "warmup_note": f"the driver's --warmup {args.warmup} untimed steps run right before the timed region; BEFORE them come {args.settle} more untimed `--settle` "
+                           "passes of this script's own (allocator, weight pre-layout, graph capture, clocks) and the parity canary: nothing of either is inside the timed K steps",
             "value_eager": round(value, 1) if launch == "eager" else (round(world * T / (other / args.steps), 1) if other is not None else None),
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dname, "data": "synthetic" if not share else "synthetic; TEST HOOK: all ranks share one GPU (IPC transport between the rank processes) -- not a measurement",
@@ -990,9 +996,9 @@ def main():
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--round5_features", "--settle", "0", "--no_extra", "--no_cpu_baseline"],
                                    capture_output=True, text=True, timeout=300)
                 ln = [l for l in r.stdout.splitlines() if l.startswith("ROUND5_FEATURES ")]
-                out["extra"]["round5_features_ms_per_step"] = json.loads(ln[-1][len("ROUND5_FEATURES "):]) if ln else {"error": (r.stderr or r.stdout)[-300:]}
+                out["extra"]["feature_ab_ms_per_step"] = json.loads(ln[-1][len("ROUND5_FEATURES "):]) if ln else {"error": (r.stderr or r.stdout)[-300:]}
             except Exception as ex:   # noqa: BLE001
-                out["extra"]["round5_features_ms_per_step"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+                out["extra"]["feature_ab_ms_per_step"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, M, H, E, k)
         print(json.dumps(out), flush=True)

@@ -214,6 +214,31 @@ int tutel_amd_expert_gemm_gather(const void *X, int ldx, const int32_t *slot_map
                                  int E_loc, int R, int N, int K, int dtype, int act,
                                  const int32_t *row_counts, int row_align, tutel_stream_t stream);
 
+/* The whole expert FFN in ONE persistent launch (round 6; csrc/expert_ffn.hip) -- OPT-IN: TUTEL_OPT_FFN_FUSED = 1.
+ *     hid[e] = act(A[e] @ W1[e]^T + b1[e]),   D[e] = hid[e] @ W2[e]^T + b2[e]        e < E_loc, R rows per expert
+ * -- what FusedExpertsNetwork.forward computes with two batched matmuls, two bias adds and the activation
+ * (tutel/experts/ffn.py:114-120), and what two calls of tutel_amd_expert_gemm compute here: the same tiles in the same k order
+ * (bit-identical results), handed out by a device-side ticket to one resident workgroup per CU, an expert's fc2 tiles waiting for
+ * its fc1 tiles through a per-expert counter.  Measured at the headline shape: 224 us against 209.8 us for the two launches (the
+ * regime is bound by HBM + Infinity Cache bandwidth, which the two launches already saturate; the file comment has the numbers), so
+ * with the option at its default EVERY call answers TUTEL_AMD_ENOTSUP and the callers run the two launches.
+ *   A    [E_loc, R, M] (x_stride_e elements between experts, rows ldx apart) -- or, with slot_map != NULL, the TOKEN array X [T, M]
+ *        gathered through slot_map [E_loc * R] as in tutel_amd_expert_gemm_gather (fast_encode fused; zero_row: >= M zeros)
+ *   W1   [E_loc, H, M] k-major (batched_fc1_w as stored), b1 [E_loc, H] or NULL
+ *   hid  [E_loc, R, H] scratch (written and read by the launch)
+ *   W2   [E_loc, M_out, H] k-major (the eval-mode copy of batched_fc2_w), b2 [E_loc, M_out] or NULL
+ *   D    [E_loc, R, M_out]
+ * Covered: R <= 128 rows per expert (every row of an expert in one M-tile: the weight-streaming regime), H and M_out >= 256,
+ * M and H multiples of 64, enough tiles to cover the chip (E_loc * ceil(N / 256) >= 256 for both GEMMs), 16-byte aligned rows.
+ * Anything else returns TUTEL_AMD_ENOTSUP with NOTHING launched -- the caller then issues the two tutel_amd_expert_gemm launches.
+ * The first call on a stream allocates a few hundred bytes of control words (not allowed while that stream is being captured:
+ * ENOTSUP then; run one eager call first). */
+int tutel_amd_expert_ffn(const void *A, int64_t x_stride_e, int ldx, const int32_t *slot_map, int T, const void *zero_row,
+                         const void *W1, int64_t w1_stride_e, int ldw1, const void *b1, int64_t b1_stride_e, void *hid,
+                         int64_t hid_stride_e, int ldh, const void *W2, int64_t w2_stride_e, int ldw2, const void *b2,
+                         int64_t b2_stride_e, void *D, int64_t d_stride_e, int ldd, int E_loc, int R, int M, int H, int M_out,
+                         int dtype, int act, tutel_stream_t stream);
+
 /* Gated (GLU) form: D = act(A @ op(W) + bias) * G, elementwise, rounded once to `dtype`.
  * Replaces the matmul + elementwise product of the SwiGLU expert,
  * `y = activation_fn(y1) * y2` with y2 = x @ W_fc2 (experts/llama_ffn.py:38-40): the caller first
@@ -454,7 +479,7 @@ int tutel_amd_marks_report(double *delta_us, int n);
 
 /* ---- tuning knobs (A/B measurements and tests; never needed for correctness) ---------------------
  * value -1 = automatic (default; the environment variables TUTEL_AMD_GEMM_IMPL / TUTEL_AMD_GEMM_BIG / TUTEL_AMD_DECODE /
- * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS / TUTEL_AMD_EP_CANARY / TUTEL_AMD_GEMM_SPLITK / TUTEL_AMD_GEMM_GATHER / TUTEL_AMD_FUSED_LOCATION / TUTEL_AMD_GEMM_STORE / TUTEL_AMD_TIE_RULE seed it once), >= 0 = force.  Every choice computes bit-identical results (excepted: TUTEL_OPT_EP_CANARY = 2 provokes the error it tests; TUTEL_OPT_GEMM_SPLITK changes the fp32 summation order; TUTEL_OPT_TIE_RULE = 0 changes which of two EXACTLY equal scores is chosen).
+ * TUTEL_AMD_EP_STAGE_GRID / TUTEL_AMD_GEMM_PERSIST / TUTEL_AMD_EP_STREAMS / TUTEL_AMD_EP_CANARY / TUTEL_AMD_GEMM_SPLITK / TUTEL_AMD_GEMM_GATHER / TUTEL_AMD_FUSED_LOCATION / TUTEL_AMD_GEMM_STORE / TUTEL_AMD_TIE_RULE / TUTEL_AMD_FFN_FUSED seed it once), >= 0 = force.  Every choice computes bit-identical results (excepted: TUTEL_OPT_EP_CANARY = 2 provokes the error it tests; TUTEL_OPT_GEMM_SPLITK changes the fp32 summation order; TUTEL_OPT_TIE_RULE = 0 changes which of two EXACTLY equal scores is chosen).
  *   TUTEL_OPT_GEMM_IMPL  kernels of the <= 128-rows-per-expert regime: 0 register-staged 128 x 128, 1 LDS-DMA 128 x 128, 4 the
  *                        128 x 256 tile on a three-slot LDS-DMA ring (k-major weights; automatic when its grid covers the chip)
  *   TUTEL_OPT_GEMM_TILE  0 never use the 256-row tiles, 1 always the plain 256 x 256 kernel, 2 / 3 always 256 x 128
@@ -487,6 +512,10 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *                        (tutel/impls/fast_dispatch.py:146-148; ATen's nth_element / partial_sort over (value, index) pairs replayed per
  *                        tied row, csrc/topk_ties.h; launches of more than ~1024 experts keep the order below), 0 = descending score,
  *                        lowest expert index first (rounds 1-5)
+ *   TUTEL_OPT_FFN_FUSED  the expert FFN where tutel_amd_expert_ffn covers the shape (one rank, <= 128 rows per expert, k-major fc2): 0 /
+ *                        automatic = the two launches of rounds 1-5 (measured faster: 209.8 vs 224 us at the headline shape), 1 = one
+ *                        persistent launch for fc1 -> activation -> fc2 (work queues per hardware XCC id), 2 = the same with queues by
+ *                        blockIdx & 7, 3 = the same with the next ticket fetched after each item instead of inside it (A/B).  Same bits
  *   TUTEL_OPT_EP_CANARY  IPC transport: epoch canaries behind every exchanged block (1 / automatic = written by the producers and
  *                        checked by the wait kernels; 0 = off; 2 = TEST INJECTION: this rank publishes the previous epoch, as if
  *                        its rows had not landed when its flag did -- the peers must report it)
@@ -503,7 +532,8 @@ int tutel_amd_marks_report(double *delta_us, int n);
 #define TUTEL_OPT_FUSED_LOCATION 9
 #define TUTEL_OPT_GEMM_STORE 10
 #define TUTEL_OPT_TIE_RULE 11
-#define TUTEL_OPT_COUNT 12
+#define TUTEL_OPT_FFN_FUSED 12
+#define TUTEL_OPT_COUNT 13
 int tutel_amd_set_option(int key, int value);
 
 /* ---- self-test helpers (used by tests / smoke only) ---------------------------------------

@@ -79,7 +79,7 @@ def test_round3_entry_points_reject_bad_arguments(L):
     hdr = open(os.path.join(ROOT, "include", "tutel_amd.h")).read()
     keys = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define TUTEL_OPT_(\w+) (\d+)", hdr)}
     count = keys.pop("COUNT")
-    assert sorted(keys.values()) == list(range(count)) and keys["TIE_RULE"] == _lib.OPT_TIE_RULE == count - 1
+    assert sorted(keys.values()) == list(range(count)) and keys["FFN_FUSED"] == _lib.OPT_FFN_FUSED == count - 1
     for name, key in keys.items():
         assert L.tutel_amd_set_option(key, -1) == 0, name
         assert getattr(_lib, "OPT_" + name) == key, name

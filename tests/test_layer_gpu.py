@@ -1108,7 +1108,9 @@ def test_fused_location_keeps_every_bit(oracle, shape, dtype):
         ops.stage_timing(0)
         ops.set_option(_lib.OPT_FUSED_LOCATION, -1)
         ops.set_option(_lib.OPT_GEMM_IMPL, -1)
-    eligible = k * ((T + E - 1) // E) * cf <= 128 and k * T <= 15360
+    # (M >= 128: the fused form's prologue counts the weight DMA of TWO K-tiles behind the idx bytes -- ADVICE r5: with M = 64 there is
+    # one, the wait would not cover the scan's input; such shapes take the location kernel, as the (777, 64, ...) case checks)
+    eligible = k * ((T + E - 1) // E) * cf <= 128 and k * T <= 15360 and M >= 128
     assert got[0]["location_launches"] == 1 and got[-1]["location_launches"] == (0 if eligible else 1), "the fused path runs exactly where it applies"
     for name in ("y", "l_aux", "cnt", "idx", "loc", "smap", "logits"):
         assert torch.equal(got[0][name], got[-1][name]), name

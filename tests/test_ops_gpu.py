@@ -448,6 +448,73 @@ def test_expert_gemm_kernels_are_bit_identical(kmajor):
         assert bool((err <= 2 ** -7 * ref.abs() + 2e-3).all()), float(err.max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_expert_ffn_one_persistent_launch_equals_the_two_launches_bit_for_bit(dtype):
+    """tutel_amd_expert_ffn (csrc/expert_ffn.hip; opt-in, TUTEL_OPT_FFN_FUSED = 1 -- measured slower than the two launches at the headline
+    shape, see the file comment): fc1 -> activation -> fc2 of every expert in ONE persistent launch -- device-side tickets,
+    per-expert completion counters, the hidden activation handed from the fc1 tiles to the fc2 tiles inside the launch -- must produce the
+    bits of the two tutel_amd_expert_gemm launches (ffn.py:114-120's two bmm): the headline shape and three ragged ones (fewer rows than a
+    tile, tile counts that are not multiples of the 8 work queues, M != M_out), plain rows and the fused fast_encode gather, four
+    activations, called repeatedly (the control words are reset by the launch itself) and on a side stream; and the fp32 reference at the
+    dtype's bar.  Shapes the persistent kernel does not take answer None (ENOTSUP) and launch nothing."""
+    from tutel_amd import ops, _lib
+    g = torch.Generator().manual_seed(29)
+    shapes = [(64, 128, 2048, 2048, 2048, "relu"), (64, 96, 1024, 1024, 1024, "gelu"), (130, 64, 512, 768, 512, "silu"), (43, 128, 256, 1536, 1792, "none")]
+    for E, R, M, H, Mo, act in shapes:
+        x = torch.randn([E, R, M], generator=g).to(dtype).cuda()
+        w1 = ((torch.rand([E, H, M], generator=g) * 2 - 1) / 16).to(dtype).cuda()
+        w2 = ((torch.rand([E, Mo, H], generator=g) * 2 - 1) / 16).to(dtype).cuda()      # k-major fc2
+        b1, b2 = torch.randn([E, H], generator=g).to(dtype).cuda(), torch.randn([E, Mo], generator=g).to(dtype).cuda()
+        try:
+            ops.set_option(_lib.OPT_FFN_FUSED, -1)
+            assert ops.expert_ffn(x, w1, b1, w2, b2, act) is None, "the persistent launch is opt-in: automatic answers ENOTSUP (two launches)"
+            want = ops.expert_gemm(ops.expert_gemm(x, w1, b1, True, act=act), w2, b2, True)
+            ops.set_option(_lib.OPT_FFN_FUSED, 1)
+            got = [ops.expert_ffn(x, w1, b1, w2, b2, act) for _ in range(3)]
+            ops.set_option(_lib.OPT_FFN_FUSED, 2)                                      # work queues by blockIdx instead of the hardware XCC id
+            got.append(ops.expert_ffn(x, w1, b1, w2, b2, act))
+            ops.set_option(_lib.OPT_FFN_FUSED, 3)                                      # the next ticket fetched after the item, not inside it
+            got.append(ops.expert_ffn(x, w1, b1, w2, b2, act))
+            ops.set_option(_lib.OPT_FFN_FUSED, 1)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                got.append(ops.expert_ffn(x, w1, b1, w2, b2, act))
+                got.append(ops.expert_ffn(x, w1, None, w2, None, act))                 # no biases
+            torch.cuda.current_stream().wait_stream(side)
+            want_nb = ops.expert_gemm(ops.expert_gemm(x, w1, None, True, act=act), w2, None, True)
+        finally:
+            ops.set_option(_lib.OPT_FFN_FUSED, -1)
+        assert all(o is not None for o in got), (E, R, M, H, Mo)
+        assert all(torch.equal(want, o) for o in got[:-1]) and torch.equal(want_nb, got[-1]), (E, R, M, H, Mo, act)
+        fn = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, "silu": torch.nn.functional.silu, "none": lambda t: t}[act]
+        hid = fn(torch.matmul(x.float(), w1.float().transpose(1, 2)) + b1.float().unsqueeze(1)).to(dtype).float()
+        ref = torch.matmul(hid, w2.float().transpose(1, 2)) + b2.float().unsqueeze(1)
+        err = (want.float() - ref).abs()
+        assert bool((err <= (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) * ref.abs() + 4e-3 * float(ref.abs().max()) / 8).all()), float(err.max())
+        # the fused fast_encode: rows gathered from a token array through a slot map with empty slots
+        T = 4 * R
+        tok = torch.randn([T, M], generator=g).to(dtype).cuda()
+        smap = torch.randint(0, 2 * T, [E * R], generator=g, dtype=torch.int32)
+        smap[torch.rand([E * R], generator=g) < 0.1] = -1
+        smap = smap.cuda()
+        want_g = ops.expert_gemm(ops.expert_gemm_gather(tok, smap, w1, b1, True, act, R), w2, b2, True)
+        try:
+            ops.set_option(_lib.OPT_FFN_FUSED, 1)
+            got_g = ops.expert_ffn(tok, w1, b1, w2, b2, act, R=R, smap=smap)
+        finally:
+            ops.set_option(_lib.OPT_FFN_FUSED, -1)
+        assert got_g is not None and torch.equal(want_g, got_g), (E, R, M, H, Mo, act, "gather")
+    # not covered -> None, nothing launched: more than 128 rows per expert; too few tiles to cover the chip; H < 256
+    try:
+        ops.set_option(_lib.OPT_FFN_FUSED, 1)
+        for E, R, M, H, Mo in ((8, 256, 512, 512, 512), (8, 128, 512, 512, 512), (64, 128, 512, 128, 512)):
+            x = torch.zeros([E, R, M], dtype=dtype, device="cuda")
+            assert ops.expert_ffn(x, torch.zeros([E, H, M], dtype=dtype, device="cuda"), None, torch.zeros([E, Mo, H], dtype=dtype, device="cuda"), None, "relu") is None
+    finally:
+        ops.set_option(_lib.OPT_FFN_FUSED, -1)
+
+
 def test_expert_gemm_store_policies_keep_every_bit():
     """TUTEL_OPT_GEMM_STORE (round 5): the output tile of the LDS-epilogue kernels (128 x 256 ring, 256 x 128 ring, 256 x 256 ping-pong)
     leaves with write-through (1) or non-temporal (2) buffer stores instead of plain stores -- same values at the same addresses: plain

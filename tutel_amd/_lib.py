@@ -14,7 +14,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, F16, BF16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
-OPT_GEMM_IMPL, OPT_GEMM_TILE, OPT_DECODE, OPT_EP_STAGE_GRID, OPT_GEMM_PERSIST, OPT_EP_STREAMS, OPT_EP_CANARY, OPT_GEMM_SPLITK, OPT_GEMM_GATHER, OPT_FUSED_LOCATION, OPT_GEMM_STORE, OPT_TIE_RULE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+OPT_GEMM_IMPL, OPT_GEMM_TILE, OPT_DECODE, OPT_EP_STAGE_GRID, OPT_GEMM_PERSIST, OPT_EP_STREAMS, OPT_EP_CANARY, OPT_GEMM_SPLITK, OPT_GEMM_GATHER, OPT_FUSED_LOCATION, OPT_GEMM_STORE, OPT_TIE_RULE, OPT_FFN_FUSED = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -39,6 +39,8 @@ SIGNATURES = {
                                    _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "tutel_amd_expert_gemm_gather": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i, _vp, _i64, _vp, _i64, _i,
                                           _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "tutel_amd_expert_ffn": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i64, _i, _vp, _i64, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _vp, _i64, _i,
+                                  _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tutel_amd_expert_gemm_glu": (_i, [_vp, _i64, _i64, _i, _i, _vp, _i, _i64, _i, _vp, _i64, _vp, _vp, _i64,
                                        _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "tutel_amd_set_option": (_i, [_i, _i]),

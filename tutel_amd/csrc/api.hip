@@ -18,10 +18,10 @@ extern "C" const char *tutel_amd_target_arch(void) { return "gfx950"; }
 extern "C" const char *tutel_amd_last_error(void) { return g_err; }
 
 // ---- tuning knobs (A/B runs and tests; defaults come from the environment once) -----------------
-static int g_opt[TUTEL_OPT_COUNT] = {-2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};  // indexed by TUTEL_OPT_*; -2 = not initialised, -1 = automatic
+static int g_opt[TUTEL_OPT_COUNT] = {-2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2, -2};  // indexed by TUTEL_OPT_*; -2 = not initialised, -1 = automatic
 static const char *const g_opt_env[TUTEL_OPT_COUNT] = {"TUTEL_AMD_GEMM_IMPL", "TUTEL_AMD_GEMM_BIG", "TUTEL_AMD_DECODE", "TUTEL_AMD_EP_STAGE_GRID",
                                                        "TUTEL_AMD_GEMM_PERSIST", "TUTEL_AMD_EP_STREAMS", "TUTEL_AMD_EP_CANARY", "TUTEL_AMD_GEMM_SPLITK",
-                                                       "TUTEL_AMD_GEMM_GATHER", "TUTEL_AMD_FUSED_LOCATION", "TUTEL_AMD_GEMM_STORE", "TUTEL_AMD_TIE_RULE"};
+                                                       "TUTEL_AMD_GEMM_GATHER", "TUTEL_AMD_FUSED_LOCATION", "TUTEL_AMD_GEMM_STORE", "TUTEL_AMD_TIE_RULE", "TUTEL_AMD_FFN_FUSED"};
 
 int tutel_get_option(int key) {
   if (key < 0 || key >= TUTEL_OPT_COUNT) return -1;

@@ -73,6 +73,13 @@ int tutel_expert_gemm_peer(const void *A, int64_t a_stride_e, int64_t a_stride_w
 int tutel_expert_gemm_gather_fl(const void *X, int ldx, int32_t *slot_map, int T, const void *zero_row, const void *W, int64_t w_stride_e,
                                 int ldw, const void *bias, int64_t bias_stride_e, void *D, int64_t d_stride_e, int ldd, int E_loc, int R,
                                 int N, int K, int dtype, int act, const uint8_t *idx8, int n, int32_t *loc, hipStream_t st);
+// expert_ffn.hip: fc1 -> activation -> fc2 in one persistent launch.  idx8 != NULL: fused location (loc out).  query != 0: answers only.
+// TUTEL_AMD_ENOTSUP: this shape / layout takes the two-launch path (nothing was launched)
+int tutel_expert_ffn(const void *X, int64_t x_stride_e, int ldx, const int32_t *slot_map, int T, const void *zero_row, const void *W1,
+                     int64_t w1_stride_e, int ldw1, const void *b1, int64_t b1_stride_e, void *hid, int64_t hid_stride_e, int ldh,
+                     const void *W2, int64_t w2_stride_e, int ldw2, const void *b2, int64_t b2_stride_e, void *D, int64_t d_stride_e, int ldd,
+                     int E_loc, int R, int M, int H, int M_out, int dtype, int act, const uint8_t *idx8, int n, int32_t *loc, int query,
+                     hipStream_t st);
 // dispatch.hip: fast_decode + the routing finish (routing_dev.h) in one launch
 struct RouteFinish;
 void tutel_route_finish_args(int T, int E, int k, void *ws, RouteFinish *out);  // routing.hip

@@ -820,15 +820,19 @@ extern "C" int tutel_amd_ep_forward(tutel_amd_ep_comm_t *c, const tutel_amd_ep_a
   // single rank, no communicator, pure-copy encode: fc1 gathers its rows from the tokens (no bucket array at all)
   if (c == nullptr && a->degree <= 1 && a->is_postscore && a->fuse_encode) {
     TUTEL_REQUIRE(a->hid && a->send && a->zero_row, "tutel_amd_ep_forward: null workspace");
-    int rc;
-    {
+    int rc = TUTEL_AMD_ENOTSUP;
+    if (rcnt == nullptr && a->w2_kmajor) {  // fc1 -> activation -> fc2 in one persistent launch where the shape takes it (expert_ffn.hip)
+      Range r("tutel_amd.expert_ffn");
+      rc = tutel_expert_ffn(a->x, 0, M, a->slot_map, T, a->zero_row, a->w1, (int64_t)H * M, M, a->b1, H, a->hid, (int64_t)C * H, H, a->w2,
+                            (int64_t)H * Mo, H, a->b2, Mo, a->send, (int64_t)C * Mo, Mo, E_loc, C, M, H, Mo, a->dtype, a->act, nullptr, 0, nullptr, 0, cur);
+      if (rc != 0 && rc != TUTEL_AMD_ENOTSUP) return rc;
+    }
+    if (rc == TUTEL_AMD_ENOTSUP) {
       Range r("tutel_amd.expert_fc1");
       rc = tutel_amd_expert_gemm_gather(a->x, M, a->slot_map, T, a->zero_row, a->w1, 1, (int64_t)H * M, M, a->b1, H, a->hid,
                                         (int64_t)C * H, H, E_loc, C, H, M, a->dtype, a->act, rcnt, ralign, cur);
       if (rc) return rc;
-    }
-    {
-      Range r("tutel_amd.expert_fc2");
+      Range r2("tutel_amd.expert_fc2");
       rc = tutel_amd_expert_gemm(a->hid, (int64_t)C * H, 0, C, H, a->w2, a->w2_kmajor, (int64_t)H * Mo, a->w2_kmajor ? H : Mo, a->b2,
                                  Mo, a->send, (int64_t)C * Mo, 0, C, Mo, E_loc, C, Mo, H, a->dtype, TUTEL_ACT_NONE, rcnt, ralign, cur);
       if (rc) return rc;
@@ -1091,14 +1095,20 @@ extern "C" int tutel_amd_moe_forward(tutel_amd_ep_comm_t *c, const tutel_amd_moe
                                 m->ws, nullptr, 0, idx8, st);
     if (rc) return rc;
     if (m->capacity_out != nullptr) *m->capacity_out = a.capacity;
-    {
+    rc = TUTEL_AMD_ENOTSUP;
+    if (a.w2_kmajor) {  // fc1 (gather + fused location) -> activation -> fc2 in one persistent launch where the shape takes it (expert_ffn.hip)
+      Range r("tutel_amd.expert_ffn");
+      rc = tutel_expert_ffn(a.x, 0, a.M, smap, T, a.zero_row, a.w1, (int64_t)Ho * a.M, a.M, a.b1, Ho, a.hid, (int64_t)a.capacity * Ho, Ho, a.w2,
+                            (int64_t)Ho * Mo, Ho, a.b2, Mo, a.send, (int64_t)a.capacity * Mo, Mo, E, a.capacity, a.M, Ho, Mo, a.dtype, a.act, idx8, k * T,
+                            const_cast<int32_t *>(a.loc), 0, st);
+      if (rc != 0 && rc != TUTEL_AMD_ENOTSUP) return rc;
+    }
+    if (rc == TUTEL_AMD_ENOTSUP) {
       Range r("tutel_amd.expert_fc1");
       rc = tutel_expert_gemm_gather_fl(a.x, a.M, smap, T, a.zero_row, a.w1, (int64_t)Ho * a.M, a.M, a.b1, Ho, a.hid, (int64_t)a.capacity * Ho, Ho,
                                        E, a.capacity, Ho, a.M, a.dtype, a.act, idx8, k * T, const_cast<int32_t *>(a.loc), st);
       if (rc) return rc;
-    }
-    {
-      Range r("tutel_amd.expert_fc2");
+      Range r2("tutel_amd.expert_fc2");
       rc = tutel_amd_expert_gemm(a.hid, (int64_t)a.capacity * Ho, 0, a.capacity, Ho, a.w2, a.w2_kmajor, (int64_t)Ho * Mo, a.w2_kmajor ? Ho : Mo,
                                  a.b2, Mo, a.send, (int64_t)a.capacity * Mo, 0, a.capacity, Mo, E, a.capacity, Mo, Ho, a.dtype, TUTEL_ACT_NONE,
                                  nullptr, 1, stream);

@@ -547,6 +547,12 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       if (c < k) {
         if (be / EPQ == q) taken |= 1u << (be - q * EPQ);
         if (c == q) { myg = bv; myidx = be; }
+        // the expert ids leave as soon as they are known, their store latency under the next round's shuffles (a row that turns out
+        // to be tied is stored again by its replay, after the block barrier that orders the two)
+        if (q == 0 && live) {
+          idx[(size_t)c * Tn + t] = be;
+          if (idx8 != nullptr) idx8[(size_t)c * Tn + t] = (uint8_t)be;  // byte copy for the in-GEMM location scan (expert_gemm.hip, FL)
+        }
       }
     }
     if (tie_mode) {
@@ -575,8 +581,6 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
           g = g / d;
         }
         gates[(size_t)q * Tn + t] = Elem<T>::from_f32(g);
-        idx[(size_t)q * Tn + t] = myidx;
-        if (idx8 != nullptr) idx8[(size_t)q * Tn + t] = (uint8_t)myidx;  // byte copy for the in-GEMM location scan (expert_gemm.hip, FL)
         atomicAdd(&s_hist[q * E + myidx], 1);
       }
     }
@@ -595,30 +599,31 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       const int nrep = s_nlist[pass & 1];
       for (int ent = wv - nbusy; ent >= 0 && ent < nrep; ent += GQ_THREADS / 64 - nbusy) {  // wave-uniform
         const int trow = s_list[ent], tt = ts + trow;
-        WaveQueue<CT, SL> wq;
+        using Rep = typename TkRepOf<T>::type;   // 16-bit scores: value and index packed into one register
+        WaveQueue<CT, SL, Rep> wq;
         wq.sel = s_sel;
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) {
           const int e = wl + 64 * sl;
-          wq.v[sl] = e < E ? s_tv[trow * E + e] : (CT)0;
-          wq.id[sl] = e;
+          wq.load(sl, e < E ? s_tv[trow * E + e] : (CT)0, e);
         }
-        AtenTopk<CT, WaveQueue<CT, SL>> tk(wq);
+        AtenTopk<CT, WaveQueue<CT, SL, Rep>> tk(wq);
         tk.run(E, k);
+        const TkElem<CT> res = wq.mine(0);
         // choice c sits at queue position c: lane c, slot 0 (k <= 16)
-        CT denom = tk_readlane(wq.v[0], 0);
-        for (int c = 1; c < k; ++c) denom = round_to<T>(denom + tk_readlane(wq.v[0], c));
+        CT denom = tk_readlane(res.v, 0);
+        for (int c = 1; c < k; ++c) denom = round_to<T>(denom + tk_readlane(res.v, c));
         if (wl < k) {
-          CT g = wq.v[0];
+          CT g = res.v;
           if (normalize && k > 1) {
             CT d = ct_max(denom, (CT)Elem<T>::eps());
             if (denom != denom) d = denom;  // torch.clamp keeps NaN
             g = g / d;
           }
           gates[(size_t)wl * Tn + tt] = Elem<T>::from_f32(g);
-          idx[(size_t)wl * Tn + tt] = wq.id[0];
-          if (idx8 != nullptr) idx8[(size_t)wl * Tn + tt] = (uint8_t)wq.id[0];
-          atomicAdd(&s_hist[wl * E + wq.id[0]], 1);
+          idx[(size_t)wl * Tn + tt] = res.id;
+          if (idx8 != nullptr) idx8[(size_t)wl * Tn + tt] = (uint8_t)res.id;
+          atomicAdd(&s_hist[wl * E + res.id], 1);
         }
       }
       if (tid == 0) s_nlist[(pass + 1) & 1] = 0;  // the next pass's list (last used by the previous pass: its readers are past their barrier)

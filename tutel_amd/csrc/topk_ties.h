@@ -12,8 +12,9 @@
 // among their k + 1 largest scores (one extra arg-max round detects them).  The routines below are statement-by-statement
 // restatements of <bits/stl_algo.h> / <bits/stl_heap.h> (GCC 11..14), written once over a QUEUE POLICY that says where the
 // (value, index) pairs live:
-//   WaveQueue  one wave works on one row, queue position i in lane i & 63 (register slot i >> 6): an element is fetched with
-//              v_readlane and stored with a one-lane move, all control flow wave-uniform -- and the two loops that walk the whole
+//   WaveQueue  one wave works on one row, queue position i in lane i & 63 (register slot i >> 6; value and index in two registers, or
+//              packed into one for 16-bit score dtypes): an element is fetched with v_readlane and stored with a one-lane move, all
+//              control flow wave-uniform -- and the two loops that walk the whole
 //              range, introselect's partition and heap_select's scan, are done for all positions AT ONCE with ballots (see
 //              partition()).  Measured at the headline shape (170 of 4096 rows replayed): queue in LDS under one lane 47 us for the
 //              top-k kernel (8 us without ties; every access a ~100-cycle dependent round trip), queue in registers with the
@@ -38,30 +39,54 @@ __device__ __forceinline__ double tk_readlane(double x, int l) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-template <typename CT, int SL> struct WaveQueue {  // every call is made by the whole wave with wave-uniform arguments
-  CT v[SL];
-  int id[SL];
-  uint8_t *sel;  // LDS scratch of this wave, 2 * n bytes (n <= 64 * SL <= 256 queue positions): see partition()
+// how one queue element sits in a lane's registers: value + index in two registers, or -- scores of a 16-bit dtype (where ties
+// actually occur) -- both in ONE (the value's 16 bits above the index): half the v_readlane / ds_bpermute / v_cndmask per access
+template <typename CT> struct TkWide {
+  CT v;
+  int id;
+  __device__ __forceinline__ static TkWide pack(const TkElem<CT> &e) { return TkWide{e.v, e.id}; }
+  __device__ __forceinline__ TkElem<CT> unpack() const { return TkElem<CT>{v, id}; }
+  __device__ __forceinline__ TkWide lane(int l) const { return TkWide{tk_readlane(v, l), __builtin_amdgcn_readlane(id, l)}; }   // uniform l
+  __device__ __forceinline__ TkWide from(int l) const { return TkWide{__shfl(v, l, 64), __shfl(id, l, 64)}; }                    // per-lane l
+  __device__ __forceinline__ static TkWide pick(bool c, const TkWide &a, const TkWide &b) { return TkWide{c ? a.v : b.v, c ? a.id : b.id}; }
+};
+template <typename T> struct TkPacked {  // T = bf16_t / f16_t: the score is exactly its 16 bits
+  uint32_t w;
+  __device__ __forceinline__ static TkPacked pack(const TkElem<float> &e) {
+    const T t = Elem<T>::from_f32(e.v);
+    uint16_t b;
+    __builtin_memcpy(&b, &t, 2);
+    return TkPacked{((uint32_t)b << 16) | (uint32_t)(e.id & 0xffff)};
+  }
+  __device__ __forceinline__ TkElem<float> unpack() const {
+    const uint16_t b = (uint16_t)(w >> 16);
+    T t;
+    __builtin_memcpy(&t, &b, 2);
+    return TkElem<float>{Elem<T>::to_f32(t), (int)(w & 0xffff)};
+  }
+  __device__ __forceinline__ TkPacked lane(int l) const { return TkPacked{(uint32_t)__builtin_amdgcn_readlane((int)w, l)}; }
+  __device__ __forceinline__ TkPacked from(int l) const { return TkPacked{(uint32_t)__shfl((int)w, l, 64)}; }
+  __device__ __forceinline__ static TkPacked pick(bool c, const TkPacked &a, const TkPacked &b) { return TkPacked{c ? a.w : b.w}; }
+};
+
+template <typename CT, int SL, typename Rep = TkWide<CT>> struct WaveQueue {  // every call is made by the whole wave with wave-uniform arguments
+  Rep r[SL];
+  uint8_t *sel;  // LDS scratch of this wave, 2 * 64 * SL bytes: see partition()
+  __device__ __forceinline__ void load(int s, CT v, int id) { r[s] = Rep::pack(TkElem<CT>{v, id}); }   // this lane's element of slot s
+  __device__ __forceinline__ TkElem<CT> mine(int s) const { return r[s].unpack(); }
   __device__ __forceinline__ TkElem<CT> get(int i) const {
-    TkElem<CT> e;
-    e.v = tk_readlane(v[0], i & 63);
-    e.id = __builtin_amdgcn_readlane(id[0], i & 63);
+    Rep x = r[0].lane(i & 63);
 #pragma unroll
     for (int s = 1; s < SL; ++s)
-      if ((i >> 6) == s) {  // uniform
-        e.v = tk_readlane(v[s], i & 63);
-        e.id = __builtin_amdgcn_readlane(id[s], i & 63);
-      }
-    return e;
+      if ((i >> 6) == s) x = r[s].lane(i & 63);  // uniform
+    return x.unpack();
   }
   __device__ __forceinline__ void set(int i, const TkElem<CT> &e) {
     const bool me = (int)(threadIdx.x & 63) == (i & 63);
+    const Rep x = Rep::pack(e);
 #pragma unroll
     for (int s = 0; s < SL; ++s)
-      if ((i >> 6) == s) {  // uniform
-        v[s] = me ? e.v : v[s];
-        id[s] = me ? e.id : id[s];
-      }
+      if ((i >> 6) == s) r[s] = Rep::pick(me, x, r[s]);  // uniform
   }
   // smallest position i' in [i, last) whose element is gt(., top), or -1: one ballot per slot instead of a scan (heap_select)
   __device__ __forceinline__ int next_gt(int i, int last, const TkElem<CT> &top) const {
@@ -70,8 +95,7 @@ template <typename CT, int SL> struct WaveQueue {  // every call is made by the 
 #pragma unroll
     for (int s = SL - 1; s >= 0; --s) {
       const int pos = lane + 64 * s;
-      TkElem<CT> e{v[s], id[s]};
-      const unsigned long long m = __ballot(pos >= i && pos < last && tk_gt(e, top));
+      const unsigned long long m = __ballot(pos >= i && pos < last && tk_gt(r[s].unpack(), top));
       if (m != 0ull) found = 64 * s + (int)__builtin_ctzll(m);
     }
     return found;
@@ -81,7 +105,8 @@ template <typename CT, int SL> struct WaveQueue {  // every call is made by the 
   // in descending order, swapping the i-th of one with the i-th of the other while a_i < b_i; a cursor only ever examines positions
   // no swap has touched, or -- as its guard -- the most recently swapped one.  So: both sets by ballot, the rank of every member by
   // popcount, the partner through a rank -> position table in LDS, s = #{i : a_i < b_i} swaps done in one exchange, and the returned
-  // cut is min(a_s, b_{s-1}) (the next untouched stop of the left cursor, or the guard the last swap left behind).
+  // cut is min(a_s, b_{s-1}) (the next untouched stop of the left cursor, or the guard the last swap left behind) -- the members of
+  // rank s / s - 1, found by ballot again.
   __device__ __forceinline__ int partition(int first, int last, const TkElem<CT> &pivot) {
     const int lane = (int)(threadIdx.x & 63);
     const unsigned long long lt = (1ull << lane) - 1ull, gtm = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
@@ -92,7 +117,7 @@ template <typename CT, int SL> struct WaveQueue {  // every call is made by the 
     for (int s = 0; s < SL; ++s) {
       const int pos = lane + 64 * s;
       const bool inr = pos > first && pos < last;
-      TkElem<CT> e{v[s], id[s]};
+      const TkElem<CT> e = r[s].unpack();
       a[s] = inr && !tk_gt(e, pivot);
       b[s] = inr && !tk_gt(pivot, e);
       mA[s] = __ballot(a[s]);
@@ -117,7 +142,7 @@ template <typename CT, int SL> struct WaveQueue {  // every call is made by the 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int pp[SL];      // partner position, or -1
+    int pp[SL];  // partner position, or -1
     int nsw = 0;
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
@@ -134,30 +159,40 @@ template <typename CT, int SL> struct WaveQueue {  // every call is made by the 
       }
       nsw += __popcll(__ballot(swa));
     }
-    // the exchange: every new value is read from the OLD registers first
-    CT nv[SL];
-    int ni[SL];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the tables are rewritten by the next call)
+    // the cut: the A member of rank nsw, or the B member of rank nsw - 1, whichever is further left
+    int cut = 0x7fffffff;
+#pragma unroll
+    for (int s = SL - 1; s >= 0; --s) {
+      const unsigned long long ma = __ballot(a[s] && rA[s] == nsw);
+      if (ma != 0ull) cut = 64 * s + (int)__builtin_ctzll(ma);
+    }
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
-      nv[s] = v[s];
-      ni[s] = id[s];
+      const unsigned long long mb = __ballot(b[s] && rB[s] == nsw - 1);
+      if (mb != 0ull) { const int g = 64 * s + (int)__builtin_ctzll(mb); cut = g < cut ? g : cut; }
+    }
+    // the exchange: every new value is read from the OLD registers first
+    Rep nr[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      nr[s] = r[s];
 #pragma unroll
       for (int s2 = 0; s2 < SL; ++s2) {
-        const CT fv = __shfl(v[s2], pp[s] & 63, 64);
-        const int fi = __shfl(id[s2], pp[s] & 63, 64);
-        if (pp[s] >= 0 && (pp[s] >> 6) == s2) { nv[s] = fv; ni[s] = fi; }
+        const Rep f = r[s2].from(pp[s] & 63);
+        nr[s] = Rep::pick(pp[s] >= 0 && (pp[s] >> 6) == s2, f, nr[s]);
       }
     }
 #pragma unroll
-    for (int s = 0; s < SL; ++s) { v[s] = nv[s]; id[s] = ni[s]; }
-    int cut = 0x7fffffff;
-    if (nsw < nA) cut = selA[nsw];
-    if (nsw >= 1) { const int g = selB[nsw - 1]; cut = g < cut ? g : cut; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tables are rewritten by the next call
-    __builtin_amdgcn_wave_barrier();
-    return __builtin_amdgcn_readfirstlane(cut);
+    for (int s = 0; s < SL; ++s) r[s] = nr[s];
+    return cut;
   }
 };
+
+// the register representation the top-k kernels use for scores of dtype T
+template <typename T> struct TkRepOf { using type = TkWide<typename Elem<T>::ct>; };
+template <> struct TkRepOf<bf16_t> { using type = TkPacked<bf16_t>; };
+template <> struct TkRepOf<f16_t> { using type = TkPacked<f16_t>; };
 
 template <typename CT, typename IT> struct LdsQueue {
   const CT *val;  // [n] the row (read only)

@@ -5,13 +5,16 @@ Parameters keep the reference's names and shapes (checkpoint compatible, SURVEY 
     batched_fc2_w    [E_loc, H/s, M_out]    batched_fc2_bias [E_loc, ceil(M_out/s)]
 
 Forward, y = act(x @ W1^T + b1) @ W2 + b2 per local expert, x [E_loc, R, M]:
-  * bf16 / fp16, no autograd, recognised activation -> two launches of the MFMA grouped GEMM
-    (tutel_amd_expert_gemm): bias + activation fused into the first, bias into the second,
-    dropless row counts honoured on device.  W2 is stored [H, M_out] (checkpoint format); the kernel
-    takes that layout as is (training-mode modules) or, in eval mode, a k-major copy laid out once
-    (KMajorCache below);
-  * anything else (fp32/fp64 experts, training, arbitrary python activation, sharded experts)
-    -> ATen batched matmul (rocBLAS / hipBLASLt library GEMMs), op for op as the reference.
+  * bf16 / fp16, no autograd, recognised activation -> the MFMA grouped GEMM kernels: two launches of
+    tutel_amd_expert_gemm -- bias + activation fused into the first, bias into the second, dropless row counts honoured
+    on device (or, opt-in with TUTEL_AMD_FFN_FUSED=1, ONE persistent launch for fc1 -> activation -> fc2,
+    tutel_amd_expert_ffn: bit-identical, measured slower at the headline shape).  W2 is stored [H, M_out] (checkpoint format); the kernel takes that layout as is
+    (training-mode modules) or, in eval mode, a k-major copy laid out once (KMajorCache below);
+  * the gathered-weight modes -- adaptive_r = 0 (every rank's experts all-gathered, ffn.py:83-89) and sharded experts
+    (num_local_experts < 0, ffn.py:91-109) -- run on the SAME MFMA grouped GEMM, fed the gathered [E, H', M] tensors
+    (forward(), below the gathers);
+  * only fp32 / fp64 experts, weight gradients, and arbitrary python activations stay on ATen batched matmul (rocBLAS /
+    hipBLASLt), op for op as the reference.
 """
 import os
 
@@ -24,6 +27,11 @@ from .. import net, ops
 _PREPACK = int(os.environ.get("TUTEL_AMD_PREPACK", "1")) != 0
 # training: forward + data gradients of the bf16 / fp16 ReLU FFN on the MFMA grouped GEMM (weight gradients stay on ATen); 0 disables
 _TRAIN_FUSED = int(os.environ.get("TUTEL_AMD_TRAIN_FUSED", "1")) != 0
+
+
+def _FFN_FUSED_ON():
+    from .. import _lib
+    return ops.get_option(_lib.OPT_FFN_FUSED) > 0
 
 
 class _FFNTrain(torch.autograd.Function):
@@ -257,7 +265,8 @@ class FusedExpertsNetwork(torch.nn.Module):
         return None
 
     def can_fuse(self, x, ctx):
-        """the plain fused route: this rank's own local experts (no weight gathering), no autograd, MFMA-able shapes"""
+        """the plain fused route: this rank's own local experts (no weight gathering), no autograd, MFMA-able shapes.  (False does NOT
+        mean ATen: adaptive_r = 0 / sharded experts gather their weights in forward() and run the same MFMA kernel on the result.)"""
         if self.skip_expert or not x.is_cuda or not self._no_autograd(x):
             return False
         if getattr(ctx, "adaptive_degree", 1) == 0 or getattr(ctx, "sharded_count", 1) > 1:
@@ -312,6 +321,12 @@ class FusedExpertsNetwork(torch.nn.Module):
             b1 = b1[lo:hi] if b1 is not None else None
             b2 = b2[lo:hi] if b2 is not None else None
             assert counts is None, "megablocks row counts are not sliced"
+        # TUTEL_OPT_FFN_FUSED = 1 (opt-in; the two launches below measured faster): one persistent launch for fc1 -> activation -> fc2
+        # where the library takes the shape (<= 128 rows per expert, k-major fc2, plain [E_loc, R, *] operands) -- same tiles, same bits
+        if _FFN_FUSED_ON() and w2_kmajor and counts is None and out is None and a_layout is None and d_layout is None and (slot_map is not None or x.dim() == 3):
+            y = ops.expert_ffn(x, w1, b1, w2, b2, self.fused_activation(), R=R, smap=slot_map)
+            if y is not None:
+                return y
         if slot_map is not None:
             h = ops.expert_gemm_gather(x, slot_map, w1, b1, True, self.fused_activation(), R,
                                        row_counts=counts, row_align=align)

@@ -326,10 +326,45 @@ def expert_gemm_gather(x, smap, w, bias, w_kmajor, act, R, row_counts=None, row_
     return out
 
 
+def expert_ffn(x, w1, b1, w2_kmajor, b2, act, R=None, smap=None, hid=None):
+    """fc1 -> activation -> fc2 of every local expert in ONE persistent launch (tutel_amd_expert_ffn, csrc/expert_ffn.hip):
+    x [E_loc, R, M] -- or the token array [T, M] with smap [E_loc * R] (fast_encode fused) -- w1 [E_loc, H, M], w2_kmajor
+    [E_loc, M_out, H] (the k-major copy of batched_fc2_w) -> [E_loc, R, M_out].  Returns None when the library answers ENOTSUP
+    (shape / layout not covered, or TUTEL_OPT_FFN_FUSED at its default: the persistent launch is opt-in, the two launches measured
+    faster): the caller then runs two expert_gemm launches -- same bits."""
+    _dev(x, w1, b1, w2_kmajor, b2, smap)
+    assert w1.dim() == 3 and w2_kmajor.dim() == 3 and w1.is_contiguous() and w2_kmajor.is_contiguous() and w1.dtype == x.dtype == w2_kmajor.dtype
+    E_loc, H, M = w1.shape
+    M_out = w2_kmajor.shape[1]
+    assert w2_kmajor.shape == (E_loc, M_out, H) and x.is_contiguous()
+    if smap is None:
+        assert x.dim() == 3 and x.shape[0] == E_loc and x.shape[2] == M
+        R = x.shape[1]
+        xs, ldx, T, z = R * M, M, 0, None
+    else:
+        assert x.dim() == 2 and x.shape[1] == M and smap.dtype == torch.int32 and smap.numel() == E_loc * R
+        key = (x.device, x.dtype)
+        z = _zero_rows.get(key)
+        if z is None or z.numel() < M:
+            z = _zero_rows[key] = torch.zeros([max(M, 8192)], dtype=x.dtype, device=x.device)
+        xs, ldx, T = 0, x.stride(0), x.shape[0]
+    if hid is None:
+        hid = torch.empty([E_loc, R, H], dtype=x.dtype, device=x.device)
+    out = torch.empty([E_loc, R, M_out], dtype=x.dtype, device=x.device)
+    rc = _lib.lib().tutel_amd_expert_ffn(_ptr(x), xs, ldx, _ptr(smap), T, _ptr(z), _ptr(w1), w1.stride(0), w1.stride(1), _ptr(b1),
+                                         (b1.stride(0) if b1 is not None else 0), _ptr(hid), R * H, H, _ptr(w2_kmajor), w2_kmajor.stride(0),
+                                         w2_kmajor.stride(1), _ptr(b2), (b2.stride(0) if b2 is not None else 0), _ptr(out), R * M_out, M_out,
+                                         E_loc, R, M, H, M_out, _code(x), ACT_CODES[act], _stream())
+    if rc == _lib.ENOTSUP:
+        return None
+    _lib.check(rc, "tutel_amd_expert_ffn")
+    return out
+
+
 _OPT_ENV = {_lib.OPT_GEMM_IMPL: "TUTEL_AMD_GEMM_IMPL", _lib.OPT_GEMM_TILE: "TUTEL_AMD_GEMM_BIG", _lib.OPT_DECODE: "TUTEL_AMD_DECODE",
             _lib.OPT_EP_STAGE_GRID: "TUTEL_AMD_EP_STAGE_GRID", _lib.OPT_GEMM_PERSIST: "TUTEL_AMD_GEMM_PERSIST", _lib.OPT_EP_STREAMS: "TUTEL_AMD_EP_STREAMS",
             _lib.OPT_EP_CANARY: "TUTEL_AMD_EP_CANARY", _lib.OPT_GEMM_SPLITK: "TUTEL_AMD_GEMM_SPLITK", _lib.OPT_GEMM_STORE: "TUTEL_AMD_GEMM_STORE",
-            _lib.OPT_GEMM_GATHER: "TUTEL_AMD_GEMM_GATHER", _lib.OPT_FUSED_LOCATION: "TUTEL_AMD_FUSED_LOCATION", _lib.OPT_TIE_RULE: "TUTEL_AMD_TIE_RULE"}
+            _lib.OPT_GEMM_GATHER: "TUTEL_AMD_GEMM_GATHER", _lib.OPT_FUSED_LOCATION: "TUTEL_AMD_FUSED_LOCATION", _lib.OPT_TIE_RULE: "TUTEL_AMD_TIE_RULE", _lib.OPT_FFN_FUSED: "TUTEL_AMD_FFN_FUSED"}
 _opts = {}
 
 
