@@ -119,7 +119,7 @@ def source_sha():
     """sha256 of the grouped-GEMM kernel source the library is built from (stamps profiles/traffic.json)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("expert_gemm.hip", "common.h"):
+    for f in ("expert_gemm.hip", "gemm_dev.h", "common.h"):   # (round 6: the ring tile lives in gemm_dev.h)
         h.update(open(os.path.join(ROOT, "tutel_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
