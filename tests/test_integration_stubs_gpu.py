@@ -105,6 +105,35 @@ def test_b3_expert_gemm_stub(ns, oracle):
             assert torch.equal(h2[e, :c], h[e, :c])
 
 
+def test_b3_expert_ffn_stub(ns):
+    """B.3's opt-in one-launch FFN stub (tutel_amd_expert_ffn), executed verbatim from the markdown: 1001 (ENOTSUP, nothing launched) while
+    TUTEL_OPT_FFN_FUSED is at its default, and with the option on the same bits as the two `_gemm` calls it stands for."""
+    from tutel_amd import _lib, ops
+    blocks = _blocks("B.3")
+    env = dict(ns)
+    exec(compile(blocks[0], "INTEGRATION.md:B.3[0]", "exec"), env)
+    stub = [b for b in blocks if "tutel_amd_expert_ffn(" in b]
+    assert len(stub) == 1
+    g = torch.Generator().manual_seed(21)
+    dtype = torch.bfloat16
+    E_loc, R, M, H, M_out = 64, 96, 512, 1024, 1024
+    x = torch.randn([E_loc, R, M], generator=g).to(dtype).cuda()
+    w1 = (torch.randn([E_loc, H, M], generator=g) / M ** 0.5).to(dtype).cuda()
+    w2t = (torch.randn([E_loc, M_out, H], generator=g) / H ** 0.5).to(dtype).cuda()
+    b1, b2 = torch.randn([E_loc, H], generator=g).to(dtype).cuda(), torch.randn([E_loc, M_out], generator=g).to(dtype).cuda()
+    env.update(x=x, w1=w1, b1=b1, w2t=w2t, b2=b2, E_loc=E_loc, R=R, M=M, H=H, M_out=M_out)
+    want = env["_gemm"](env["_gemm"](x, w1, b1, True, 1), w2t, b2, True, 0)
+    exec(compile(stub[0], "INTEGRATION.md:B.3[ffn]", "exec"), env)
+    assert env["rc"] == _lib.ENOTSUP, "opt-in: the default answers ENOTSUP"
+    try:
+        ops.set_option(_lib.OPT_FFN_FUSED, 1)
+        exec(compile(stub[0], "INTEGRATION.md:B.3[ffn]", "exec"), env)
+    finally:
+        ops.set_option(_lib.OPT_FFN_FUSED, -1)
+    torch.cuda.synchronize()
+    assert env["rc"] == 0 and torch.equal(env["y"], want)
+
+
 def test_b6_gate_projection_stub(ns, oracle):
     """B.6: the gate projection of a 16-bit gate through the split-K kernel + top-k on its partial sums, executed verbatim from the
     markdown: the logits it returns equal x @ wg^T to an ulp of the dtype, and idx / gates equal the oracle's routing on those logits."""
