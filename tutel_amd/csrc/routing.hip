@@ -208,7 +208,7 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
           __builtin_amdgcn_wave_barrier();
           if (lane == 0) {
             LdsQueue<CT, uint16_t> lq{s_tv, s_tp};
-            AtenTopk<CT, LdsQueue<CT, uint16_t>> ts(lq);
+            AtenTopk<LdsQueue<CT, uint16_t>> ts(lq);
             ts.run(E, k);
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -599,17 +599,19 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
       const int nrep = s_nlist[pass & 1];
       for (int ent = wv - nbusy; ent >= 0 && ent < nrep; ent += GQ_THREADS / 64 - nbusy) {  // wave-uniform
         const int trow = s_list[ent], tt = ts + trow;
-        using Rep = typename TkRepOf<T>::type;   // 16-bit scores: value and index packed into one register
-        WaveQueue<CT, SL, Rep> wq;
+        using Rep = typename TkRepOf<T>::type;   // 16-bit scores: an order-preserving key and the index packed into one register
+        WaveQueue<SL, Rep> wq;
         wq.sel = s_sel;
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) {
           const int e = wl + 64 * sl;
-          wq.load(sl, e < E ? s_tv[trow * E + e] : (CT)0, e);
+          wq.r[sl] = Rep::make(e < E ? s_tv[trow * E + e] : (CT)0, e);
         }
-        AtenTopk<CT, WaveQueue<CT, SL, Rep>> tk(wq);
+        AtenTopk<WaveQueue<SL, Rep>> tk(wq);
         tk.run(E, k);
-        const TkElem<CT> res = wq.mine(0);
+        TkElem<CT> res;
+        res.id = Rep::id_of(wq.r[0].unpack());
+        res.v = s_tv[trow * E + (wl < k ? res.id : 0)];   // the score itself comes from the row (the queue may hold only its key)
         // choice c sits at queue position c: lane c, slot 0 (k <= 16)
         CT denom = tk_readlane(res.v, 0);
         for (int c = 1; c < k; ++c) denom = round_to<T>(denom + tk_readlane(res.v, c));

@@ -12,9 +12,11 @@
 // among their k + 1 largest scores (one extra arg-max round detects them).  The routines below are statement-by-statement
 // restatements of <bits/stl_algo.h> / <bits/stl_heap.h> (GCC 11..14), written once over a QUEUE POLICY that says where the
 // (value, index) pairs live:
-//   WaveQueue  one wave works on one row, queue position i in lane i & 63 (register slot i >> 6; value and index in two registers, or
-//              packed into one for 16-bit score dtypes): an element is fetched with v_readlane and stored with a one-lane move, all
-//              control flow wave-uniform -- and the two loops that walk the whole
+//   WaveQueue  one wave works on one row, queue position i in lane i & 63 (register slot i >> 6).  An element is value + index in two
+//              registers -- or, for scores of a 16-bit dtype (where ties actually occur), ONE register: a 16-bit KEY above the index,
+//              the key an order-preserving map of the score under ATen's comparator (NaN above everything, -0 = +0), so that gt() is
+//              one unsigned compare and the scalar parts of the routines stay on the scalar unit.  Single elements move with
+//              v_readlane / a one-lane move, all control flow is wave-uniform -- and the two loops that walk the whole
 //              range, introselect's partition and heap_select's scan, are done for all positions AT ONCE with ballots (see
 //              partition()).  Measured at the headline shape (170 of 4096 rows replayed): queue in LDS under one lane 47 us for the
 //              top-k kernel (8 us without ties; every access a ~100-cycle dependent round trip), queue in registers with the
@@ -25,13 +27,12 @@
 #pragma once
 #include "common.h"
 
+// ---- elements and how they compare ------------------------------------------------------------------------------------------
+// ATen: gt(x, y) = (isnan(x) && !isnan(y)) || x > y, on the VALUE only
 template <typename CT> struct TkElem { CT v; int id; };
-
 template <typename CT> __device__ __forceinline__ bool tk_gt(const TkElem<CT> &x, const TkElem<CT> &y) {
   return ((x.v != x.v) && !(y.v != y.v)) || x.v > y.v;
 }
-
-// ---- queue policies ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float tk_readlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ __forceinline__ double tk_readlane(double x, int l) {
   const long long b = __double_as_longlong(x);
@@ -39,49 +40,62 @@ __device__ __forceinline__ double tk_readlane(double x, int l) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// how one queue element sits in a lane's registers: value + index in two registers, or -- scores of a 16-bit dtype (where ties
-// actually occur) -- both in ONE (the value's 16 bits above the index): half the v_readlane / ds_bpermute / v_cndmask per access
+// value + index in two registers (fp32 / fp64 scores)
 template <typename CT> struct TkWide {
+  using E = TkElem<CT>;   // an element as the routines hold it (wave-uniform when it came from get())
   CT v;
   int id;
-  __device__ __forceinline__ static TkWide pack(const TkElem<CT> &e) { return TkWide{e.v, e.id}; }
-  __device__ __forceinline__ TkElem<CT> unpack() const { return TkElem<CT>{v, id}; }
+  __device__ __forceinline__ static bool gt(const E &x, const E &y) { return tk_gt(x, y); }
+  __device__ __forceinline__ static int id_of(const E &e) { return e.id; }
+  __device__ __forceinline__ static TkWide make(CT v, int id) { return TkWide{v, id}; }
+  __device__ __forceinline__ static TkWide pack(const E &e) { return TkWide{e.v, e.id}; }
+  __device__ __forceinline__ E unpack() const { return E{v, id}; }
   __device__ __forceinline__ TkWide lane(int l) const { return TkWide{tk_readlane(v, l), __builtin_amdgcn_readlane(id, l)}; }   // uniform l
   __device__ __forceinline__ TkWide from(int l) const { return TkWide{__shfl(v, l, 64), __shfl(id, l, 64)}; }                    // per-lane l
   __device__ __forceinline__ static TkWide pick(bool c, const TkWide &a, const TkWide &b) { return TkWide{c ? a.v : b.v, c ? a.id : b.id}; }
 };
-template <typename T> struct TkPacked {  // T = bf16_t / f16_t: the score is exactly its 16 bits
+// one register: (key16 << 16) | index, for scores that are exactly their 16 bits (T = bf16_t / f16_t).  key16 orders the scores as
+// ATen's comparator does: every NaN -> 0xffff (all NaNs are equivalent and above +inf), -0 -> +0 (they compare equal), negative
+// values -> the complement of their bits, the rest -> bits | 0x8000; equal keys <=> neither element is gt the other.
+template <typename T> struct TkKeyed {
+  using E = uint32_t;
   uint32_t w;
-  __device__ __forceinline__ static TkPacked pack(const TkElem<float> &e) {
-    const T t = Elem<T>::from_f32(e.v);
+  __device__ __forceinline__ static bool gt(E x, E y) { return (x >> 16) > (y >> 16); }
+  __device__ __forceinline__ static int id_of(E e) { return (int)(e & 0xffff); }
+  __device__ __forceinline__ static TkKeyed make(float v, int id) {
+    const T t = Elem<T>::from_f32(v);   // (v is a T-typed score held in fp32: exact)
     uint16_t b;
     __builtin_memcpy(&b, &t, 2);
-    return TkPacked{((uint32_t)b << 16) | (uint32_t)(e.id & 0xffff)};
+    if (b == 0x8000) b = 0;
+    uint32_t key = (b & 0x8000) ? (uint32_t)(uint16_t)~b : (uint32_t)(b | 0x8000);
+    if (v != v) key = 0xffff;
+    return TkKeyed{(key << 16) | (uint32_t)(id & 0xffff)};
   }
-  __device__ __forceinline__ TkElem<float> unpack() const {
-    const uint16_t b = (uint16_t)(w >> 16);
-    T t;
-    __builtin_memcpy(&t, &b, 2);
-    return TkElem<float>{Elem<T>::to_f32(t), (int)(w & 0xffff)};
-  }
-  __device__ __forceinline__ TkPacked lane(int l) const { return TkPacked{(uint32_t)__builtin_amdgcn_readlane((int)w, l)}; }
-  __device__ __forceinline__ TkPacked from(int l) const { return TkPacked{(uint32_t)__shfl((int)w, l, 64)}; }
-  __device__ __forceinline__ static TkPacked pick(bool c, const TkPacked &a, const TkPacked &b) { return TkPacked{c ? a.w : b.w}; }
+  __device__ __forceinline__ static TkKeyed pack(E e) { return TkKeyed{e}; }
+  __device__ __forceinline__ E unpack() const { return w; }
+  __device__ __forceinline__ TkKeyed lane(int l) const { return TkKeyed{(uint32_t)__builtin_amdgcn_readlane((int)w, l)}; }
+  __device__ __forceinline__ TkKeyed from(int l) const { return TkKeyed{(uint32_t)__shfl((int)w, l, 64)}; }
+  __device__ __forceinline__ static TkKeyed pick(bool c, const TkKeyed &a, const TkKeyed &b) { return TkKeyed{c ? a.w : b.w}; }
 };
+// the register representation the top-k kernels use for scores of dtype T
+template <typename T> struct TkRepOf { using type = TkWide<typename Elem<T>::ct>; };
+template <> struct TkRepOf<bf16_t> { using type = TkKeyed<bf16_t>; };
+template <> struct TkRepOf<f16_t> { using type = TkKeyed<f16_t>; };
 
-template <typename CT, int SL, typename Rep = TkWide<CT>> struct WaveQueue {  // every call is made by the whole wave with wave-uniform arguments
+// ---- queue policies ---------------------------------------------------------------------------------------------------------
+template <int SL, typename Rep> struct WaveQueue {  // every call is made by the whole wave with wave-uniform arguments
+  using E = typename Rep::E;
   Rep r[SL];
   uint8_t *sel;  // LDS scratch of this wave, 2 * 64 * SL bytes: see partition()
-  __device__ __forceinline__ void load(int s, CT v, int id) { r[s] = Rep::pack(TkElem<CT>{v, id}); }   // this lane's element of slot s
-  __device__ __forceinline__ TkElem<CT> mine(int s) const { return r[s].unpack(); }
-  __device__ __forceinline__ TkElem<CT> get(int i) const {
+  __device__ __forceinline__ static bool gt(const E &x, const E &y) { return Rep::gt(x, y); }
+  __device__ __forceinline__ E get(int i) const {
     Rep x = r[0].lane(i & 63);
 #pragma unroll
     for (int s = 1; s < SL; ++s)
       if ((i >> 6) == s) x = r[s].lane(i & 63);  // uniform
     return x.unpack();
   }
-  __device__ __forceinline__ void set(int i, const TkElem<CT> &e) {
+  __device__ __forceinline__ void set(int i, const E &e) {
     const bool me = (int)(threadIdx.x & 63) == (i & 63);
     const Rep x = Rep::pack(e);
 #pragma unroll
@@ -89,13 +103,13 @@ template <typename CT, int SL, typename Rep = TkWide<CT>> struct WaveQueue {  //
       if ((i >> 6) == s) r[s] = Rep::pick(me, x, r[s]);  // uniform
   }
   // smallest position i' in [i, last) whose element is gt(., top), or -1: one ballot per slot instead of a scan (heap_select)
-  __device__ __forceinline__ int next_gt(int i, int last, const TkElem<CT> &top) const {
+  __device__ __forceinline__ int next_gt(int i, int last, const E &top) const {
     const int lane = (int)(threadIdx.x & 63);
     int found = -1;
 #pragma unroll
     for (int s = SL - 1; s >= 0; --s) {
       const int pos = lane + 64 * s;
-      const unsigned long long m = __ballot(pos >= i && pos < last && tk_gt(r[s].unpack(), top));
+      const unsigned long long m = __ballot(pos >= i && pos < last && Rep::gt(r[s].unpack(), top));
       if (m != 0ull) found = 64 * s + (int)__builtin_ctzll(m);
     }
     return found;
@@ -107,9 +121,9 @@ template <typename CT, int SL, typename Rep = TkWide<CT>> struct WaveQueue {  //
   // popcount, the partner through a rank -> position table in LDS, s = #{i : a_i < b_i} swaps done in one exchange, and the returned
   // cut is min(a_s, b_{s-1}) (the next untouched stop of the left cursor, or the guard the last swap left behind) -- the members of
   // rank s / s - 1, found by ballot again.
-  __device__ __forceinline__ int partition(int first, int last, const TkElem<CT> &pivot) {
+  __device__ __forceinline__ int partition(int first, int last, const E &pivot) {
     const int lane = (int)(threadIdx.x & 63);
-    const unsigned long long lt = (1ull << lane) - 1ull, gtm = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned long long mA[SL], mB[SL];
     bool a[SL], b[SL];
     int nA = 0, nB = 0;
@@ -117,28 +131,28 @@ template <typename CT, int SL, typename Rep = TkWide<CT>> struct WaveQueue {  //
     for (int s = 0; s < SL; ++s) {
       const int pos = lane + 64 * s;
       const bool inr = pos > first && pos < last;
-      const TkElem<CT> e = r[s].unpack();
-      a[s] = inr && !tk_gt(e, pivot);
-      b[s] = inr && !tk_gt(pivot, e);
+      const E e = r[s].unpack();
+      a[s] = inr && !Rep::gt(e, pivot);
+      b[s] = inr && !Rep::gt(pivot, e);
       mA[s] = __ballot(a[s]);
       mB[s] = __ballot(b[s]);
       nA += __popcll(mA[s]);
       nB += __popcll(mB[s]);
     }
     uint8_t *selA = sel, *selB = sel + 64 * SL;
-    int rA[SL], rB[SL];
+    int rA[SL], rB[SL];  // rank of this position among A from the left / among B from the right
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
-      int ra = __popcll(mA[s] & lt), rb = __popcll(mB[s] & gtm);
+      int ra = __popcll(mA[s] & lt), rbl = __popcll(mB[s] & lt);
 #pragma unroll
-      for (int s2 = 0; s2 < SL; ++s2) {
-        if (s2 < s) ra += __popcll(mA[s2]);
-        if (s2 > s) rb += __popcll(mB[s2]);
+      for (int s2 = 0; s2 < s; ++s2) {
+        ra += __popcll(mA[s2]);
+        rbl += __popcll(mB[s2]);
       }
       rA[s] = ra;
-      rB[s] = rb;
+      rB[s] = nB - 1 - rbl;
       if (a[s]) selA[ra] = (uint8_t)(lane + 64 * s);
-      if (b[s]) selB[rb] = (uint8_t)(lane + 64 * s);
+      if (b[s]) selB[rB[s]] = (uint8_t)(lane + 64 * s);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -189,34 +203,31 @@ template <typename CT, int SL, typename Rep = TkWide<CT>> struct WaveQueue {  //
   }
 };
 
-// the register representation the top-k kernels use for scores of dtype T
-template <typename T> struct TkRepOf { using type = TkWide<typename Elem<T>::ct>; };
-template <> struct TkRepOf<bf16_t> { using type = TkPacked<bf16_t>; };
-template <> struct TkRepOf<f16_t> { using type = TkPacked<f16_t>; };
-
 template <typename CT, typename IT> struct LdsQueue {
+  using E = TkElem<CT>;
   const CT *val;  // [n] the row (read only)
   IT *p;          // [n] the queue: expert ids
-  __device__ __forceinline__ TkElem<CT> get(int i) const {
-    TkElem<CT> e;
+  __device__ __forceinline__ static bool gt(const E &x, const E &y) { return tk_gt(x, y); }
+  __device__ __forceinline__ E get(int i) const {
+    E e;
     e.id = p[i];
     e.v = val[e.id];
     return e;
   }
-  __device__ __forceinline__ void set(int i, const TkElem<CT> &e) { p[i] = (IT)e.id; }
-  __device__ __forceinline__ int next_gt(int i, int last, const TkElem<CT> &top) const {
+  __device__ __forceinline__ void set(int i, const E &e) { p[i] = (IT)e.id; }
+  __device__ __forceinline__ int next_gt(int i, int last, const E &top) const {
     for (; i < last; ++i)
       if (tk_gt(get(i), top)) return i;
     return -1;
   }
-  __device__ __forceinline__ int partition(int first, int last, const TkElem<CT> &pivot) {  // __unguarded_partition(first + 1, last, first)
+  __device__ __forceinline__ int partition(int first, int last, const E &pivot) {  // __unguarded_partition(first + 1, last, first)
     int f = first + 1, l = last;
     for (;;) {
       while (tk_gt(get(f), pivot)) ++f;
       --l;
       while (tk_gt(pivot, get(l))) --l;
       if (!(f < l)) return f;
-      const TkElem<CT> x = get(f), y = get(l);
+      const E x = get(f), y = get(l);
       set(f, y);
       set(l, x);
       ++f;
@@ -225,17 +236,18 @@ template <typename CT, typename IT> struct LdsQueue {
 };
 
 // ---- the library routines ---------------------------------------------------------------------------------------------------
-template <typename CT, typename Q> struct AtenTopk {
-  using E = TkElem<CT>;
+template <typename Q> struct AtenTopk {
+  using E = typename Q::E;
   Q &q;
   __device__ __forceinline__ explicit AtenTopk(Q &queue) : q(queue) {}
+  __device__ __forceinline__ static bool gt(const E &x, const E &y) { return Q::gt(x, y); }
 
   // <bits/stl_heap.h>
   __device__ __forceinline__ void push_heap(int first, int hole, int top, const E &value) {
     int parent = (hole - 1) / 2;
     while (hole > top) {
       const E pe = q.get(first + parent);
-      if (!tk_gt(pe, value)) break;
+      if (!gt(pe, value)) break;
       q.set(first + hole, pe);
       hole = parent;
       parent = (hole - 1) / 2;
@@ -249,7 +261,7 @@ template <typename CT, typename Q> struct AtenTopk {
       child = 2 * (child + 1);
       E c = q.get(first + child);
       const E c1 = q.get(first + child - 1);
-      if (tk_gt(c, c1)) { child--; c = c1; }
+      if (gt(c, c1)) { child--; c = c1; }
       q.set(first + hole, c);
       hole = child;
     }
@@ -302,14 +314,14 @@ template <typename CT, typename Q> struct AtenTopk {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
       const E v = q.get(i);
-      if (tk_gt(v, q.get(first))) {
+      if (gt(v, q.get(first))) {
         for (int j = i; j != first; --j) q.set(j, q.get(j - 1));
         q.set(first, v);
       } else {  // __unguarded_linear_insert
         int l = i, nx = i - 1;
         for (;;) {
           const E ne = q.get(nx);
-          if (!tk_gt(v, ne)) break;
+          if (!gt(v, ne)) break;
           q.set(l, ne);
           l = nx;
           --nx;
@@ -320,15 +332,16 @@ template <typename CT, typename Q> struct AtenTopk {
   }
   __device__ __forceinline__ int partition_pivot(int first, int last) {  // __unguarded_partition_pivot
     const int mid = first + (last - first) / 2;
-    {  // __move_median_to_first(first, first + 1, mid, last - 1)
-      const int a = first + 1, b = mid, c = last - 1;
-      const E ea = q.get(a), eb = q.get(b), ec = q.get(c);
-      int s;
-      if (tk_gt(ea, eb)) s = tk_gt(eb, ec) ? b : (tk_gt(ea, ec) ? c : a);
-      else s = tk_gt(ea, ec) ? a : (tk_gt(eb, ec) ? c : b);
-      swap(first, s);
-    }
-    return q.partition(first, last, q.get(first));  // (the pivot element itself is never moved by the partition)
+    // __move_median_to_first(first, first + 1, mid, last - 1), then the partition around *first (which the partition never moves)
+    const int a = first + 1, b = mid, c = last - 1;
+    const E ea = q.get(a), eb = q.get(b), ec = q.get(c), ef = q.get(first);
+    int s;
+    if (gt(ea, eb)) s = gt(eb, ec) ? b : (gt(ea, ec) ? c : a);
+    else s = gt(ea, ec) ? a : (gt(eb, ec) ? c : b);
+    const E es = s == a ? ea : (s == b ? eb : ec);
+    q.set(first, es);
+    q.set(s, ef);
+    return q.partition(first, last, es);
   }
   __device__ __forceinline__ void nth_element(int nth, int n) {  // std::nth_element(q, q + nth, q + n)
     if (n == 0 || nth == n) return;
