@@ -206,16 +206,33 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          if (lane == 0) {
-            LdsQueue<CT, uint16_t> lq{s_tv, s_tp};
-            AtenTopk<LdsQueue<CT, uint16_t>> ts(lq);
-            ts.run(E, k);
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          if (lane < k) {
-            myidx[u] = s_tp[lane];
-            myg[u] = s_tv[myidx[u]];
+          if constexpr (EPL <= 4) {
+            // up to 256 experts: the whole wave replays the row with the queue in registers -- expert e already sits in lane e & 63,
+            // slot e >> 6, which IS the queue's layout (topk_ties.h, WaveQueue); the rank tables take the bytes behind the row's copy
+            using Rep = typename TkRepOf<T>::type;
+            WaveQueue<EPL, Rep> wq;
+            wq.sel = reinterpret_cast<uint8_t *>(s_tp);   // [E] uint16 per wave = the 2 * E bytes of the two tables
+            wq.seln = E;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) wq.r[j] = Rep::make(((nanm[u] >> j) & 1ull) ? (CT)NAN : v[u][j], lane + 64 * j);
+            AtenTopk<WaveQueue<EPL, Rep>> tsw(wq);
+            tsw.run(E, k);
+            if (lane < k) {
+              myidx[u] = Rep::id_of(wq.r[0].unpack());   // choice c: queue position c = lane c, slot 0
+              myg[u] = s_tv[myidx[u]];
+            }
+          } else {
+            if (lane == 0) {
+              LdsQueue<CT, uint16_t> lq{s_tv, s_tp};
+              AtenTopk<LdsQueue<CT, uint16_t>> ts(lq);
+              ts.run(E, k);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < k) {
+              myidx[u] = s_tp[lane];
+              myg[u] = s_tv[myidx[u]];
+            }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -602,6 +619,7 @@ __global__ __launch_bounds__(GQ_THREADS) void gate_topk_quad_kernel(
         using Rep = typename TkRepOf<T>::type;   // 16-bit scores: an order-preserving key and the index packed into one register
         WaveQueue<SL, Rep> wq;
         wq.sel = s_sel;
+        wq.seln = E;
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) {
           const int e = wl + 64 * sl;

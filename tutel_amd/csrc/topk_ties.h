@@ -86,7 +86,8 @@ template <> struct TkRepOf<f16_t> { using type = TkKeyed<f16_t>; };
 template <int SL, typename Rep> struct WaveQueue {  // every call is made by the whole wave with wave-uniform arguments
   using E = typename Rep::E;
   Rep r[SL];
-  uint8_t *sel;  // LDS scratch of this wave, 2 * 64 * SL bytes: see partition()
+  uint8_t *sel;  // LDS scratch of this wave, 2 * seln bytes: see partition()
+  int seln;      // queue length n (the two rank -> position tables hold at most n entries each)
   __device__ __forceinline__ static bool gt(const E &x, const E &y) { return Rep::gt(x, y); }
   __device__ __forceinline__ E get(int i) const {
     Rep x = r[0].lane(i & 63);
@@ -139,7 +140,7 @@ template <int SL, typename Rep> struct WaveQueue {  // every call is made by the
       nA += __popcll(mA[s]);
       nB += __popcll(mB[s]);
     }
-    uint8_t *selA = sel, *selB = sel + 64 * SL;
+    uint8_t *selA = sel, *selB = sel + seln;
     int rA[SL], rB[SL];  // rank of this position among A from the left / among B from the right
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
