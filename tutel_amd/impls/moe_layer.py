@@ -107,21 +107,11 @@ class MOELayer(torch.nn.Module):
         else:
             self.sharded_count = 1
 
-        self.auto_parallel, self.adaptive_degree, self.use_model_parallel = False, self.sharded_count, True
-        self.valid_rs = [0] + [i for i in range(1, self.sharded_count + 1) if self.sharded_count % i == 0]
-        if parallel_type.startswith("adaptive:"):
-            r = int(parallel_type[parallel_type.index(":") + 1:])
-            self.adaptive_degree = min(max(r, 0), self.sharded_count)
-            if self.adaptive_degree not in self.valid_rs:
-                raise Exception("Unexpected value of adaptive_degree: %d, expecting a candidate within %s." % (self.adaptive_degree, self.valid_rs))
-        elif self.sharded_count == 1:
-            pass
-        elif parallel_type in ("data", "model"):
-            self.adaptive_degree = 1 if parallel_type == "data" else self.sharded_count
-        elif parallel_type == "auto":
-            self.adaptive_degree = 1
-        else:
-            raise Exception("Unrecognized parallel type specified: %s" % parallel_type)
+        # how the ranks that share one expert split its work (moe_layer.py:150-166 upstream): r = 0 gathers the expert's parameters and
+        # keeps every token local; 1 <= r <= sharded_count, a divisor of it, replicates a token bucket r times across hidden-dim shards
+        self.auto_parallel, self.use_model_parallel = False, True
+        self.valid_rs = [0] + [d for d in range(1, self.sharded_count + 1) if self.sharded_count % d == 0]
+        self.adaptive_degree = self._degree_of_parallel_type(parallel_type)
 
         if seeds is not None and seeds[1] is not None:
             torch.manual_seed(seeds[1])
@@ -331,6 +321,38 @@ class MOELayer(torch.nn.Module):
         return y, l_aux
 
     # ---- forward ------------------------------------------------------------------------
+    def _degree_of_parallel_type(self, parallel_type):
+        """`parallel_type` ("data" | "model" | "auto" | "adaptive:<r>") -> the initial adaptive_degree (same values and error texts as upstream)"""
+        if parallel_type.startswith("adaptive:"):
+            wanted = int(parallel_type.split(":", 1)[1])
+            degree = sorted((0, wanted, self.sharded_count))[1]   # clamped into [0, sharded_count]
+            if degree not in self.valid_rs:
+                raise Exception("Unexpected value of adaptive_degree: %d, expecting a candidate within %s." % (degree, self.valid_rs))
+            return degree
+        if self.sharded_count == 1:
+            return 1                      # nothing to split: any spelling is accepted, as upstream
+        by_name = {"data": 1, "auto": 1, "model": self.sharded_count}
+        if parallel_type not in by_name:
+            raise Exception("Unrecognized parallel type specified: %s" % parallel_type)
+        return by_name[parallel_type]
+
+    def _spread_over_shards(self, y):
+        """fewer experts than ranks: [E, C, M] buckets -> one [*, M] block per rank, each bucket replicated adaptive_degree times when the
+        hidden dimension is what is split (every shard then sees every row), cut into world_size / E row blocks otherwise"""
+        if self.num_global_experts >= self.world_size:
+            return y
+        if self.use_model_parallel:
+            y = y.repeat(1, self.adaptive_degree, 1)
+        return y.view(self.world_size, -1, y.size(2))
+
+    def _collect_from_shards(self, y):
+        """inverse of _spread_over_shards on the experts' outputs: the hidden-dim shards' partial products are summed"""
+        if self.num_global_experts >= self.world_size:
+            return y
+        if self.use_model_parallel:
+            return y.view(self.num_global_experts, self.adaptive_degree, -1, y.size(2)).sum(dim=1)
+        return y.view(self.num_global_experts, -1, y.size(2))
+
     def forward(self, input, gate_index=0, capacity_factor=None, top_k=None, a2a_ffn_overlap_degree=None,
                 reserve_dims=1, inequivalent_tokens=False, adaptive_r=None, megablocks_size=0):
         if self.skip_moe:
@@ -458,11 +480,7 @@ class MOELayer(torch.nn.Module):
         else:
             if self.auto_parallel:
                 self.use_model_parallel = (y.numel() * (self.sharded_count - 1) * 2 < sum(p.numel() for p in self.experts.parameters()))
-            if self.num_global_experts < self.world_size:
-                if self.use_model_parallel:
-                    y = y.repeat(1, self.adaptive_degree, 1).view(self.world_size, -1, y.size(2))
-                else:
-                    y = y.view(self.world_size, -1, y.size(2))
+            y = self._spread_over_shards(y)
 
             fused = (isinstance(self.experts, FusedExpertsNetwork) and self.world_size > 1 and len(reserve_shape) == 1
                      and self.num_global_experts >= self.world_size and not C.SKIP_A2A and self.experts.can_fuse(y, self))
@@ -481,11 +499,7 @@ class MOELayer(torch.nn.Module):
                 y = self.expert_local(y, reserve_shape)
                 y = C.all_to_all(y, 0, 1, use_2dh=self.use_2dh, group=self.group)
 
-            if self.num_global_experts < self.world_size:
-                if self.use_model_parallel:
-                    y = torch.sum(y.view(self.num_global_experts, self.adaptive_degree, -1, y.size(2)), dim=1)
-                else:
-                    y = y.view(self.num_global_experts, -1, y.size(2))
+            y = self._collect_from_shards(y)
 
         # decode: the kernel multiplies/accumulates in fp32 and rounds ONCE to its output dtype.  With an
         # fp32 gate and low-precision experts the reference casts the buckets to fp32, combines in fp32 and
