@@ -63,8 +63,8 @@ size_t tutel_amd_routing_workspace_bytes(int T, int E, int k);
 /* in[T,E] (dtype): scores, or logits when apply_softmax != 0 (softmax over E in fp32, rounded
  * to dtype, as F.softmax on a `dtype` tensor does).  Outputs:
  *   scores_out [T,E] dtype  (optional, may be NULL; only meaningful with apply_softmax)
- *   idx   [k,T] int32  descending score; EXACT ties -> lowest expert index (torch.topk leaves
- *                      tie order unspecified; SURVEY section 7 hard part 1)
+ *   idx   [k,T] int32  descending score; EXACTLY equal scores in the order the reference's CPU torch.topk returns them
+ *                      (TUTEL_OPT_TIE_RULE below; 0 there = lowest expert index first)
  *   gates [k,T] dtype  scores[t, idx_k[t]], divided by clamp(sum_k, eps(dtype)) when
  *                      normalize_gate != 0 and k > 1, each step rounded in `dtype` exactly as
  *                      fast_dispatch.py:151,173-175 does.
@@ -510,7 +510,7 @@ int tutel_amd_marks_report(double *delta_us, int n);
  *                        after the last wave: rounds 1-4), 2 = non-temporal; buffer stores through a descriptor, same values and addresses
  *   TUTEL_OPT_TIE_RULE   top-k among EXACTLY equal scores: 1 / automatic = the expert ids the reference's CPU path gets from torch.topk
  *                        (tutel/impls/fast_dispatch.py:146-148; ATen's nth_element / partial_sort over (value, index) pairs replayed per
- *                        tied row, csrc/topk_ties.h; launches of more than ~1024 experts keep the order below), 0 = descending score,
+ *                        tied row, csrc/topk_ties.h; every expert count the routing kernels take), 0 = descending score,
  *                        lowest expert index first (rounds 1-5)
  *   TUTEL_OPT_FFN_FUSED  the expert FFN where tutel_amd_expert_ffn covers the shape (one rank, <= 128 rows per expert, k-major fc2): 0 /
  *                        automatic = the two launches of rounds 1-5 (measured faster: 209.8 vs 224 us at the headline shape), 1 = one

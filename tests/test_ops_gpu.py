@@ -106,7 +106,7 @@ def test_gate_topk_ties_follow_the_reference_cpu_topk(oracle, dtype):
     assert idx.cpu()[:, 0].tolist() == [0, 1, 2] and idx.cpu()[:, 1].tolist() == [5, 0, 1] and idx.cpu()[:, 2].tolist() == [0, 63, 1]
 
 
-@pytest.mark.parametrize("E", [1, 2, 3, 7, 16, 33, 64, 65, 96, 127, 128, 129, 192, 256, 300, 1024])
+@pytest.mark.parametrize("E", [1, 2, 3, 7, 16, 33, 64, 65, 96, 127, 128, 129, 192, 256, 300, 1024, 1600, 2048, 4096])
 def test_gate_topk_tie_heavy_rows_equal_torch_topk_on_the_cpu(oracle, E):
     """Rows drawn from a handful of distinct values (nearly every row ties, many at the k / k+1 boundary, some hold NaNs) through both
     top-k kernels (16 lanes per token for E <= 128, a wave per token above) and both of ATen's branches (partial_sort when k * 64 <= E,
@@ -118,9 +118,7 @@ def test_gate_topk_tie_heavy_rows_equal_torch_topk_on_the_cpu(oracle, E):
         if k > E or k * E > 8192:
             continue
         for levels, dt in [(1, torch.float32), (2, torch.bfloat16), (3, torch.float16), (5, torch.float32), (17, torch.bfloat16), (3, torch.float64)]:
-            if E * 16 * (dt.itemsize if dt == torch.float64 else 4) + E * 32 + k * E * 4 > 160 * 1024:
-                continue   # the replay's per-wave row + queue no longer fit in LDS: that launch keeps the lowest-index order (include/tutel_amd.h)
-            T = 333
+            T = 333 if E <= 1024 else 97   # (past ~1000 experts the block's waves share the replay slots LDS still holds: routing.hip)
             s = (torch.randint(0, levels, (T, E), generator=g).to(torch.float32) / 8).to(dt)
             if levels == 3:
                 s[::5, E // 2] = float("nan")

@@ -56,10 +56,14 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *s_hist = reinterpret_cast<int32_t *>(smem);             // [k][E]
   float *s_col = reinterpret_cast<float *>(smem) + (size_t)k * E;  // [GT_WAVES][min(E, GT_COL_SLAB)]
-  // tie_mode (topk_ties.h): one row + one queue per wave.  Shares its bytes with s_col, which is only used after the token loop.
-  CT *s_tv = reinterpret_cast<CT *>(smem + (((size_t)k * E * 4 + 7) & ~(size_t)7)) + (size_t)(threadIdx.x >> 6) * E;  // [GT_WAVES][E]
-  uint16_t *s_tp = reinterpret_cast<uint16_t *>(reinterpret_cast<CT *>(smem + (((size_t)k * E * 4 + 7) & ~(size_t)7)) + (size_t)GT_WAVES * E) +
-                   (size_t)(threadIdx.x >> 6) * E;                                                                       // [GT_WAVES][E]
+  // tie_mode (topk_ties.h) = the number of replay slots LDS holds, one row + one queue each: GT_WAVES (every wave its own) up to
+  // ~1000 experts, fewer past that -- the waves wid % slots of a slot then take turns (s_lock).  The slots share their bytes with s_col,
+  // which is only used after the token loop.
+  const int tie_slots = tie_mode > 0 ? tie_mode : GT_WAVES, tie_slot = (int)(threadIdx.x >> 6) % tie_slots;
+  CT *s_tv = reinterpret_cast<CT *>(smem + (((size_t)k * E * 4 + 7) & ~(size_t)7)) + (size_t)tie_slot * E;               // [slots][E]
+  uint16_t *s_tp = reinterpret_cast<uint16_t *>(reinterpret_cast<CT *>(smem + (((size_t)k * E * 4 + 7) & ~(size_t)7)) + (size_t)tie_slots * E) +
+                   (size_t)tie_slot * E;                                                                                 // [slots][E]
+  __shared__ int s_lock[GT_WAVES];   // 1: a wave is replaying a row in this slot
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.x;
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
   }
 
   for (int i = tid; i < k * E; i += GT_THREADS) s_hist[i] = 0;
+  if (tid < GT_WAVES) s_lock[tid] = 0;
   __syncthreads();
 
   float colacc[EPL];
@@ -196,6 +201,15 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
       for (int u = 0; u < GT_BATCH; ++u) {
         if (__ballot(nanm[u] != 0ull) != 0ull) tied[u] = true;
         if (tied[u] && live[u]) {  // wave-uniform: lane 0 replays ATen's CPU top-k over the row
+          const bool shared_slot = tie_slots < GT_WAVES;   // block-uniform
+          if (shared_slot) {
+            // the slot is another wave's too: taken with an LDS compare-and-swap by lane 0 (the holder never waits on anything inside,
+            // so the spin ends), the slot's previous contents ordered before ours by the acquire
+            if (lane == 0)
+              while (atomicCAS(&s_lock[tie_slot], 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+          }
 #pragma unroll
           for (int j = 0; j < EPL; ++j) {
             int e = lane + 64 * j;
@@ -236,6 +250,11 @@ __global__ __launch_bounds__(GT_THREADS) void gate_topk_kernel(
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
+          if (shared_slot) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's reads of the slot are done (lgkmcnt(0)) before it is handed on
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_store(&s_lock[tie_slot], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
       }
     }
@@ -707,14 +726,20 @@ static int launch_gate_topk(const void *in, int apply_softmax, int Tn, int E, in
   float *ws_col = (float *)(ws_hist + (size_t)nt * k * E);
   using CTh = typename Elem<T>::ct;
   // TUTEL_OPT_TIE_RULE: 1 / automatic = equal scores come out in the order of the reference's CPU torch.topk (topk_ties.h), 0 = lowest
-  // expert index first (rounds 1-5).  The replay needs one row + one queue in LDS per concurrently replayed token; launches whose
-  // expert count does not leave room for that (E > ~1024) keep the lowest-index order.
+  // expert index first (rounds 1-5).  The replay needs one row + one queue in LDS per concurrently replayed token: every wave of the
+  // wave-per-token kernel has its own up to ~1000 experts (fp32 scores), past that the kernel is told how many slots fit and its waves
+  // share them (at the limits of this file -- 4096 experts, k * E = 8192, fp64 scores -- three slots of 40 KB).
   int tie_mode = tutel_get_option(TUTEL_OPT_TIE_RULE) != 0;
   size_t lds = (size_t)k * E * 4 + 8;
   {
-    const size_t col = (size_t)GT_WAVES * (E < GT_COL_SLAB ? E : GT_COL_SLAB) * 4, tie = (size_t)GT_WAVES * E * (sizeof(CTh) + 2);
-    if (lds + tie > 160 * 1024) tie_mode = 0;
-    lds += tie_mode && tie > col ? tie : col;
+    const size_t col = (size_t)GT_WAVES * (E < GT_COL_SLAB ? E : GT_COL_SLAB) * 4, slot = (size_t)E * (sizeof(CTh) + 2);
+    const size_t room = (size_t)160 * 1024 - lds - 256;   // (256: the kernel's static LDS)
+    int slots = (int)(room / slot);
+    if (slots > GT_WAVES) slots = GT_WAVES;
+    if (slots < 1) tie_mode = 0;                          // (cannot happen for E <= RT_MAX_E, k * E <= 8192)
+    const size_t tie = tie_mode ? (size_t)slots * slot : 0;
+    lds += tie > col ? tie : col;
+    if (tie_mode && E > 128) tie_mode = slots;            // the wave-per-token kernel's tie_mode is its slot count
   }
   if (E <= 128) {
     const int epq = (E + GQ_LPT - 1) / GQ_LPT;                 // 1..8
