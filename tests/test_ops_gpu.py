@@ -656,8 +656,8 @@ def test_ring256_kernel_of_the_128_row_regime(oracle, dtype):
 def test_routing_randomized_shapes_vs_oracle(oracle):
     """A seeded sweep of 60 random (T, E, k, capacity_factor, dtype, normalize) problems: top-k, locations,
     dispatch_count, capacity and the encode -> decode round trip against the oracle, bit for bit on every
-    integer; tie rows (low-precision scores) are compared through the oracle's own tie rule, which the
-    kernel implements (lowest expert index)."""
+    integer; tie rows (low-precision scores) follow the reference's CPU torch.topk order in both the oracle
+    (oracle/aten_topk.c) and the kernel (csrc/topk_ties.h).  tests/test_fuzz_gpu.py is the wide form."""
     import random
     ops = _ops()
     from tutel import moe
