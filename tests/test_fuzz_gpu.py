@@ -1,7 +1,7 @@
 """A wide seeded fuzz of the routing -> dispatch -> combine chain against the oracle: the form of
 test_ops_gpu.py::test_routing_randomized_shapes_vs_oracle with expert counts up to the kernels' 4096, k up to 16, capacity alignment, fp64
 scores, tie-heavy rows in every dtype -- every integer, every gate, every encoded / decoded element bit for bit.  150 cases in the default run,
-1500 with --runslow; `python tests/test_fuzz_gpu.py [cases] [seed] [routing|gemm]` runs any length and writes gpurun_out/r6_<what>_fuzz_<seed>.json
+1500 with --runslow; `python tests/test_fuzz_gpu.py [cases] [seed] [routing|gemm|layer]` runs any length and writes gpurun_out/r6_<what>_fuzz_<seed>.json
 (round 6: two seeds x 1500 cases are on record in profiles/)."""
 import json
 import os
@@ -134,6 +134,67 @@ def run_gemm_fuzz(n_cases, seed, verbose=False):
     return bad
 
 
+def run_layer_fuzz(oracle, n_cases, seed, verbose=False):
+    """random single-rank MOELayer forwards (eval): the routing the forward really used (`_keep_routing`) must equal the oracle's on the
+    scores the kernels derived -- ids, slots, counts, capacity, element for element -- and y the oracle's encode -> fp32-accumulating FFN
+    -> decode on that routing, within the rounding bound of test_layer_gpu._close.  The shapes cross every eligibility edge of the
+    one-call path (capacity 128, k * T = 15 360, model_dim 128, E = 128, dims that are no multiple of 64 -> the ATen experts)."""
+    from test_layer_gpu import make_layer, _close
+    from tutel_amd import ops
+    rnd = random.Random(seed)
+    bad, t0 = [], time.time()
+    for case in range(n_cases):
+        E = rnd.choice([1, 2, 3, 4, 6, 8, 16, 16, 32, 64, 64, 128, 130, 256])
+        T = rnd.choice([1, 3, 64, 100, 127, 128, 129, 500, 1000, 1024, 2000, 4096, 5000, 7680, 7681, 8192])
+        k = min(E, rnd.choice([1, 2, 2, 2, 3, 4]))
+        M = rnd.choice([64, 128, 128, 192, 256, 256, 512, 1024, 40, 100])
+        H = rnd.choice([64, 128, 256, 256, 320, 512, 1024, 72, 200])
+        cf = rnd.choice([1.0, 1.0, 1.0, 0.5, 2.0, 1.25, 0.0, 0.0, -1.5])
+        dtype = rnd.choice([torch.bfloat16, torch.bfloat16, torch.float16, torch.float32])
+        fp32_gate = rnd.random() < 0.5
+        norm, post = rnd.random() < 0.7, rnd.random() < 0.7
+        while k * max(1, (T + E - 1) // E) * max(abs(cf), 1.0) * E * M * H > (1 << 32):   # keeps the CPU side of a case near a second
+            T = max(1, T // 2)
+        tag = f"layer case {case}: T={T} M={M} H={H} E={E} k={k} cf={cf} {dtype} fp32_gate={fp32_gate} norm={norm} post={post}"
+        try:
+            x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed * 31 + case)
+            layer = make_layer(M, H, E, k, cf, dtype, weights, gate={"fp32_gate": fp32_gate}, normalize_gate=norm, is_postscore=post).eval()
+            layer._keep_routing, layer.last_logits = True, None
+            xd = x.cuda()
+            if (k * int(cf * ((T + E - 1) // E)) if cf > 0 else 1) == 0:
+                # capacity 0: upstream's forward fails on an ambiguous reshape of the empty buckets (moe_layer.py:218 / fast_dispatch.py:214),
+                # and so does this one -- the same RuntimeError, not a silent result
+                with pytest.raises(RuntimeError, match="cannot reshape tensor of 0 elements"), torch.no_grad():
+                    layer(xd)
+                continue
+            with torch.no_grad():
+                y = layer(xd)
+                logits = layer.last_logits if layer.last_logits is not None else layer.gates[0](xd)
+                scores = ops.gate_topk(logits.contiguous(), k, apply_softmax=True, want_scores=True)[3].cpu()
+            crit, l_o = oracle.extract_critical(scores, k, cf, normalize_gate=norm)
+            idx, loc = layer.last_routing
+            assert torch.equal(idx.cpu(), torch.stack([t.to(torch.int32) for t in crit[1]])), "idx"
+            assert torch.equal(loc.cpu(), torch.stack([t.to(torch.int32) for t in crit[2]])), "loc"
+            assert torch.equal(layer.dispatch_count.cpu(), crit[5]), "dispatch_count"
+            assert int(layer.protected_shape[1]) == crit[4] or crit[4] == 0, f"capacity {int(layer.protected_shape[1])} vs {crit[4]}"
+            assert abs(float(y.l_aux) - float(l_o)) <= (1e-5 if scores.dtype == torch.float32 else 2e-2) * max(1.0, abs(float(l_o))), "l_aux"
+            w1, b1, w2, b2 = weights[1:]
+            enc = oracle.fast_encode(x.to(scores.dtype), crit, post).to(dtype)
+            # dims that are multiples of 64 run the MFMA grouped GEMM (fp32 accumulation, one rounding of the hidden activation and of the
+            # output); the others run upstream's own ATen ops, which round after every op -- each against the oracle form that states it
+            mfma = dtype != torch.float32 and M % 64 == 0 and H % 64 == 0
+            ffn = oracle.expert_ffn(enc, w1, b1, w2, b2, accum_fp32=mfma)
+            yo = oracle.fast_decode(ffn.to(scores.dtype), crit, post).to(dtype)
+            _close(y.view(T, -1), yo, dtype, vs_lowprec_reference=not mfma)
+        except Exception as ex:  # noqa: BLE001
+            bad.append(tag + " :: " + (str(ex) or type(ex).__name__)[:300].replace("\n", " "))
+            if verbose:
+                print("FAIL", bad[-1], flush=True)
+        if verbose and (case + 1) % 50 == 0:
+            print(f"{case + 1} layer cases, {len(bad)} failed, {time.time() - t0:.0f} s", flush=True)
+    return bad
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_cases", [150, pytest.param(1500, marks=pytest.mark.slow)])
 def test_routing_dispatch_combine_fuzz_vs_oracle(oracle, n_cases):
@@ -148,13 +209,21 @@ def test_grouped_gemm_fuzz_vs_fp32_reference_and_across_kernels(n_cases):
     assert not bad, "\n".join(bad[:20])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cases", [60, pytest.param(600, marks=pytest.mark.slow)])
+def test_layer_forward_fuzz_vs_oracle(oracle, n_cases):
+    bad = run_layer_fuzz(oracle, n_cases, seed=6062)
+    assert not bad, "\n".join(bad[:20])
+
+
 if __name__ == "__main__":
     from oracle import moe_oracle
     moe_oracle._lib()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 6060
     what = sys.argv[3] if len(sys.argv) > 3 else "routing"
-    failed = run_gemm_fuzz(n, sd, verbose=True) if what == "gemm" else run_routing_fuzz(moe_oracle, n, sd, verbose=True)
+    failed = (run_gemm_fuzz(n, sd, verbose=True) if what == "gemm" else run_layer_fuzz(moe_oracle, n, sd, verbose=True) if what == "layer"
+              else run_routing_fuzz(moe_oracle, n, sd, verbose=True))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"r6_{what}_fuzz_{sd}.json"), "w") as f:
         json.dump(dict(source="tests/test_fuzz_gpu.py", cases=n, seed=sd, failed=failed), f, indent=1)
