@@ -1,7 +1,7 @@
 """A wide seeded fuzz of the routing -> dispatch -> combine chain against the oracle: the form of
 test_ops_gpu.py::test_routing_randomized_shapes_vs_oracle with expert counts up to the kernels' 4096, k up to 16, capacity alignment, fp64
 scores, tie-heavy rows in every dtype -- every integer, every gate, every encoded / decoded element bit for bit.  150 cases in the default run,
-1500 with --runslow; `python tests/test_fuzz_gpu.py [cases] [seed] [routing|gemm|layer]` runs any length and writes gpurun_out/r6_<what>_fuzz_<seed>.json
+1500 with --runslow; `python tests/test_fuzz_gpu.py [cases] [seed] [routing|gemm|layer|train]` runs any length and writes gpurun_out/r6_<what>_fuzz_<seed>.json
 (round 6: two seeds x 1500 cases are on record in profiles/)."""
 import json
 import os
@@ -195,6 +195,66 @@ def run_layer_fuzz(oracle, n_cases, seed, verbose=False):
     return bad
 
 
+def run_training_fuzz(oracle, n_cases, seed, verbose=False):
+    """random TRAINING steps (forward + backward through the layer: dispatch / combine backward kernels, gate gradients, the MFMA data-gradient
+    GEMMs where the dims allow, ATen elsewhere): output and ALL gradients of the 16-bit layer against the same layer in fp32 (same
+    routing: fp32 gate on the same rounded inputs).  The bar is the reference's own: the same step with the experts on upstream's ATen
+    op sequence (experts/ffn.py::_TRAIN_FUSED = False) is measured against fp32 too, and the kernels may not be further from fp32
+    than twice that distance (or the fixed bars of test_training_forward_and_data_gradients_on_the_mfma_gemm, whichever is larger:
+    fp16 steps with pre-scored buckets sit at 1 - 2e-2 relative on dx on EITHER path)."""
+    from test_layer_gpu import make_layer
+    from tutel_amd.experts import ffn
+    rnd = random.Random(seed)
+    bad, t0 = [], time.time()
+    for case in range(n_cases):
+        E = rnd.choice([1, 2, 4, 8, 8, 16, 32, 64])
+        T = rnd.choice([64, 100, 256, 500, 1024, 2048])
+        k = min(E, rnd.choice([1, 2, 2, 3]))
+        M = rnd.choice([64, 128, 256, 256, 512, 100])
+        H = rnd.choice([64, 128, 256, 384, 512, 72])
+        cf = rnd.choice([1.0, 1.0, 2.0, 0.5, 1.25])
+        dtype = rnd.choice([torch.bfloat16, torch.float16])
+        norm, post = rnd.random() < 0.7, rnd.random() < 0.7
+        if k * int(cf * ((T + E - 1) // E)) == 0:
+            continue
+        tag = f"train case {case}: T={T} M={M} H={H} E={E} k={k} cf={cf} {dtype} norm={norm} post={post}"
+        fused_was = ffn._TRAIN_FUSED
+        try:
+            x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed * 37 + case)
+
+            def run(dt, fused):
+                ffn._TRAIN_FUSED = fused
+                layer = make_layer(M, H, E, k, cf, dt, [t.to(dt) for t in weights], gate={"fp32_gate": True}, normalize_gate=norm, is_postscore=post).train()
+                xin = x.to(dt).cuda().requires_grad_(True)
+                y = layer(xin)
+                loss = (y.float() * torch.linspace(-1, 1, M, device="cuda")).sum() + y.l_aux.float()
+                loss.backward()
+                ex = layer.experts
+                return [y.detach().float().cpu()] + [g.float().cpu() for g in (xin.grad, ex.batched_fc1_w.grad, ex.batched_fc1_bias.grad, ex.batched_fc2_w.grad,
+                                                                             ex.batched_fc2_bias.grad, layer.gates[0].wg.weight.grad)], layer.dispatch_count.cpu()
+            r_k, c_k = run(dtype, True)
+            r_a, c_a = run(dtype, False)
+            r_r, c_r = run(torch.float32, False)
+            assert torch.equal(c_k, c_r) and torch.equal(c_a, c_r), "dispatch_count of the three runs"
+            eps = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+            for name, a, u, b in zip(("y", "dx", "dfc1_w", "dfc1_bias", "dfc2_w", "dfc2_bias", "dgate_w"), r_k, r_a, r_r):
+                mult = 4 if name == "y" else 8
+                scale, nb = float(b.abs().max()), b.norm().clamp_min(1e-12)
+                fro, fro_aten = float((a - b).norm() / nb), float((u - b).norm() / nb)
+                assert fro <= max(mult * eps, 2 * fro_aten), f"{name}: relative Frobenius error {fro:.3e} (ATen path: {fro_aten:.3e})"
+                mx, mx_aten = float((a - b).abs().max()), float((u - b).abs().max())
+                assert mx <= max(12 * mult * eps * scale + 1e-6, 2 * mx_aten), f"{name}: max error {mx:.3e} (ATen path: {mx_aten:.3e}) at scale {scale:.3e}"
+        except Exception as ex:  # noqa: BLE001
+            bad.append(tag + " :: " + (str(ex) or type(ex).__name__)[:300].replace("\n", " "))
+            if verbose:
+                print("FAIL", bad[-1], flush=True)
+        finally:
+            ffn._TRAIN_FUSED = fused_was
+        if verbose and (case + 1) % 50 == 0:
+            print(f"{case + 1} training cases, {len(bad)} failed, {time.time() - t0:.0f} s", flush=True)
+    return bad
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_cases", [150, pytest.param(1500, marks=pytest.mark.slow)])
 def test_routing_dispatch_combine_fuzz_vs_oracle(oracle, n_cases):
@@ -216,6 +276,13 @@ def test_layer_forward_fuzz_vs_oracle(oracle, n_cases):
     assert not bad, "\n".join(bad[:20])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cases", [40, pytest.param(400, marks=pytest.mark.slow)])
+def test_training_step_fuzz_vs_fp32_layer(oracle, n_cases):
+    bad = run_training_fuzz(oracle, n_cases, seed=6063)
+    assert not bad, "\n".join(bad[:20])
+
+
 if __name__ == "__main__":
     from oracle import moe_oracle
     moe_oracle._lib()
@@ -223,6 +290,7 @@ if __name__ == "__main__":
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 6060
     what = sys.argv[3] if len(sys.argv) > 3 else "routing"
     failed = (run_gemm_fuzz(n, sd, verbose=True) if what == "gemm" else run_layer_fuzz(moe_oracle, n, sd, verbose=True) if what == "layer"
+              else run_training_fuzz(moe_oracle, n, sd, verbose=True) if what == "train"
               else run_routing_fuzz(moe_oracle, n, sd, verbose=True))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"r6_{what}_fuzz_{sd}.json"), "w") as f:
