@@ -1,7 +1,7 @@
 """A wide seeded fuzz of the routing -> dispatch -> combine chain against the oracle: the form of
 test_ops_gpu.py::test_routing_randomized_shapes_vs_oracle with expert counts up to the kernels' 4096, k up to 16, capacity alignment, fp64
 scores, tie-heavy rows in every dtype -- every integer, every gate, every encoded / decoded element bit for bit.  150 cases in the default run,
-1500 with --runslow; `python tests/test_fuzz_gpu.py [cases] [seed] [routing|gemm|layer|train]` runs any length and writes gpurun_out/r6_<what>_fuzz_<seed>.json
+1500 with --runslow; `python tests/test_fuzz_gpu.py [cases] [seed] [routing|gemm|layer|train|ext]` runs any length and writes gpurun_out/r6_<what>_fuzz_<seed>.json
 (round 6: two seeds x 1500 cases are on record in profiles/)."""
 import json
 import os
@@ -71,6 +71,19 @@ def run_routing_fuzz(oracle, n_cases, seed, verbose=False):
         if verbose and (case + 1) % 100 == 0:
             print(f"{case + 1} cases, {len(bad)} failed, {time.time() - t0:.0f} s", flush=True)
     return bad
+
+
+def _close_at_scale(y, ref, dtype):
+    """test_layer_gpu._close for outputs whose magnitude is not pinned below 1: every element within 2 ulps of its own magnitude plus ONE
+    ulp at the tensor's scale (what a 1-ulp flip of an expert output contributes where a token's k choices cancel -- the bar of
+    test_ep_ranks_one_gpu.py), and all but 0.2 % of the elements within the 2 ulps + the small absolute floor alone."""
+    y, ref = y.double().cpu(), ref.double().cpu()
+    eps = {torch.bfloat16: 2 ** -7, torch.float16: 2 ** -10}.get(dtype, 1e-5)
+    floor = {torch.bfloat16: 2e-3, torch.float16: 3e-4}.get(dtype, 1e-6)
+    err, scale = (y - ref).abs(), float(ref.abs().max())
+    assert bool((err <= eps * ref.abs() + max(floor, eps * scale)).all()), f"max error {float(err.max()):.3e} at scale {scale:.3f}"
+    over = float((err > eps * ref.abs() + floor).double().mean())
+    assert over <= 2e-3, f"{over:.2%} of the elements beyond 2 ulps + {floor}"
 
 
 def run_gemm_fuzz(n_cases, seed, verbose=False):
@@ -255,6 +268,60 @@ def run_training_fuzz(oracle, n_cases, seed, verbose=False):
     return bad
 
 
+def run_ext_layer_fuzz(oracle, n_cases, seed, verbose=False):
+    """random forwards of the cosine top-k gate (gates/cosine_top.py) over SwiGLU experts (experts/llama_ffn.py: silu fused into W_fc1's GEMM,
+    the gating product into W_fc2's): logits against the oracle's restatement of the gate, the routing really used against the oracle's on the
+    kernels' own scores element for element, y against the oracle's encode -> SwiGLU -> decode on that routing."""
+    from test_layer_gpu import make_ext_layer
+    from tutel_amd import ops
+    rnd = random.Random(seed)
+    bad, t0 = [], time.time()
+    for case in range(n_cases):
+        E = rnd.choice([1, 2, 4, 6, 8, 16, 32, 64])
+        T = rnd.choice([1, 64, 100, 300, 1000, 1024, 4096])
+        k = min(E, rnd.choice([1, 2, 2, 3]))
+        M = rnd.choice([64, 128, 256, 512, 100])
+        H = rnd.choice([64, 128, 256, 320, 512, 72])
+        P = rnd.choice([16, 32, 64])
+        cf = rnd.choice([1.0, 1.0, 2.0, 0.5, 1.25, 0.0])
+        dtype = rnd.choice([torch.bfloat16, torch.float16, torch.float32])
+        fp32_gate = rnd.random() < 0.6
+        if (k * int(cf * ((T + E - 1) // E)) if cf > 0 else 1) == 0:
+            continue
+        tag = f"ext case {case}: T={T} M={M} H={H} E={E} P={P} k={k} cf={cf} {dtype} fp32_gate={fp32_gate}"
+        try:
+            tensors = oracle.make_problem_ext(T, M, H, E, P, dtype=dtype, seed=seed * 41 + case)
+            x, pw, pb, sim, temp, w1, w2, w3 = tensors
+            layer = make_ext_layer(M, H, E, P, k, cf, dtype, fp32_gate, tensors)
+            layer._keep_routing, layer.last_logits = True, None
+            xd = x.cuda()
+            with torch.no_grad():
+                y = layer(xd)
+                logits = layer.gates[0](xd)
+                scores = ops.gate_topk(logits.contiguous(), k, apply_softmax=True, want_scores=True)[3].cpu()
+            want_logits = oracle.cosine_gate_logits(x, pw, pb, sim, temp, fp32_gate)
+            ltol = dict(rtol=1e-5, atol=1e-6) if want_logits.dtype == torch.float32 else dict(rtol=2 ** -6, atol=2 ** -6)
+            torch.testing.assert_close(logits.cpu(), want_logits, **ltol)
+            crit, l_o = oracle.extract_critical(scores, k, cf)
+            idx, loc = layer.last_routing
+            assert torch.equal(idx.cpu(), torch.stack([t.to(torch.int32) for t in crit[1]])), "idx"
+            assert torch.equal(loc.cpu(), torch.stack([t.to(torch.int32) for t in crit[2]])), "loc"
+            assert torch.equal(layer.dispatch_count.cpu(), crit[5]), "dispatch_count"
+            assert abs(float(y.l_aux) - float(l_o)) <= (1e-5 if scores.dtype == torch.float32 else 2e-2) * max(1.0, abs(float(l_o))), "l_aux"
+            mfma = dtype != torch.float32 and M % 64 == 0 and H % 64 == 0
+            enc = oracle.fast_encode(x.to(scores.dtype), crit).to(dtype)
+            ffn = oracle.expert_llama_ffn(enc, w1, w2, w3, accum_fp32=mfma)
+            yo = oracle.fast_decode(ffn.to(scores.dtype), crit).to(dtype)
+            _close_at_scale(y.view(T, -1), yo, dtype)
+        except Exception as ex:  # noqa: BLE001
+            bad.append(tag + " :: " + (str(ex) or type(ex).__name__)[:300].replace("\n", " "))
+            if verbose:
+                print("FAIL", bad[-1], flush=True)
+        if verbose and (case + 1) % 50 == 0:
+            print(f"{case + 1} ext cases, {len(bad)} failed, {time.time() - t0:.0f} s", flush=True)
+    return bad
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_cases", [150, pytest.param(1500, marks=pytest.mark.slow)])
 def test_routing_dispatch_combine_fuzz_vs_oracle(oracle, n_cases):
@@ -283,6 +350,13 @@ def test_training_step_fuzz_vs_fp32_layer(oracle, n_cases):
     assert not bad, "\n".join(bad[:20])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cases", [40, pytest.param(400, marks=pytest.mark.slow)])
+def test_cosine_gate_swiglu_expert_layer_fuzz_vs_oracle(oracle, n_cases):
+    bad = run_ext_layer_fuzz(oracle, n_cases, seed=6064)
+    assert not bad, "\n".join(bad[:20])
+
+
 if __name__ == "__main__":
     from oracle import moe_oracle
     moe_oracle._lib()
@@ -291,6 +365,7 @@ if __name__ == "__main__":
     what = sys.argv[3] if len(sys.argv) > 3 else "routing"
     failed = (run_gemm_fuzz(n, sd, verbose=True) if what == "gemm" else run_layer_fuzz(moe_oracle, n, sd, verbose=True) if what == "layer"
               else run_training_fuzz(moe_oracle, n, sd, verbose=True) if what == "train"
+              else run_ext_layer_fuzz(moe_oracle, n, sd, verbose=True) if what == "ext"
               else run_routing_fuzz(moe_oracle, n, sd, verbose=True))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"r6_{what}_fuzz_{sd}.json"), "w") as f:
