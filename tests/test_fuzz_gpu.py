@@ -166,9 +166,10 @@ def run_layer_fuzz(oracle, n_cases, seed, verbose=False):
         dtype = rnd.choice([torch.bfloat16, torch.bfloat16, torch.float16, torch.float32])
         fp32_gate = rnd.random() < 0.5
         norm, post = rnd.random() < 0.7, rnd.random() < 0.7
+        mega = rnd.choice([0, 0, 1, 2, 4]) if cf == 0.0 else 0   # dropless: the experts skip the rows past their own count (megablocks_size)
         while k * max(1, (T + E - 1) // E) * max(abs(cf), 1.0) * E * M * H > (1 << 32):   # keeps the CPU side of a case near a second
             T = max(1, T // 2)
-        tag = f"layer case {case}: T={T} M={M} H={H} E={E} k={k} cf={cf} {dtype} fp32_gate={fp32_gate} norm={norm} post={post}"
+        tag = f"layer case {case}: T={T} M={M} H={H} E={E} k={k} cf={cf} {dtype} fp32_gate={fp32_gate} norm={norm} post={post} megablocks={mega}"
         try:
             x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed * 31 + case)
             layer = make_layer(M, H, E, k, cf, dtype, weights, gate={"fp32_gate": fp32_gate}, normalize_gate=norm, is_postscore=post).eval()
@@ -181,10 +182,11 @@ def run_layer_fuzz(oracle, n_cases, seed, verbose=False):
                     layer(xd)
                 continue
             with torch.no_grad():
-                y = layer(xd)
+                y = layer(xd, megablocks_size=mega)
                 logits = layer.last_logits if layer.last_logits is not None else layer.gates[0](xd)
                 scores = ops.gate_topk(logits.contiguous(), k, apply_softmax=True, want_scores=True)[3].cpu()
-            crit, l_o = oracle.extract_critical(scores, k, cf, normalize_gate=norm)
+            # (upstream rounds the capacity up to megablocks_size where that mode is live: more than one local expert, moe_layer.py:278-300)
+            crit, l_o = oracle.extract_critical(scores, k, cf, normalize_gate=norm, alignment=mega if (mega > 0 and E > 1) else 1)
             idx, loc = layer.last_routing
             assert torch.equal(idx.cpu(), torch.stack([t.to(torch.int32) for t in crit[1]])), "idx"
             assert torch.equal(loc.cpu(), torch.stack([t.to(torch.int32) for t in crit[2]])), "loc"
