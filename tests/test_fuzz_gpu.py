@@ -201,6 +201,16 @@ def run_layer_fuzz(oracle, n_cases, seed, verbose=False):
             ffn = oracle.expert_ffn(enc, w1, b1, w2, b2, accum_fp32=mfma)
             yo = oracle.fast_decode(ffn.to(scores.dtype), crit, post).to(dtype)
             _close(y.view(T, -1), yo, dtype, vs_lowprec_reference=not mfma)
+            if cf > 0 and case % 4 == 0:
+                # every fourth capturable case: the forward as a HIP graph -- replays on the example and on another batch must carry the
+                # eager forward's bits (dropless routing reads its capacity back to the host and refuses capture, impls/graph.py)
+                from tutel_amd.impls.graph import GraphedForward
+                with torch.no_grad():
+                    gf = GraphedForward(layer, xd)
+                    assert torch.equal(gf(xd), y), "graph replay vs eager, the captured batch"
+                    x2 = torch.roll(xd, 1, 0)
+                    want2 = layer(x2)
+                    assert torch.equal(gf(x2), want2) and torch.equal(gf(x2), want2), "graph replay vs eager, another batch (twice)"
         except Exception as ex:  # noqa: BLE001
             bad.append(tag + " :: " + (str(ex) or type(ex).__name__)[:300].replace("\n", " "))
             if verbose:
@@ -339,7 +349,7 @@ def test_grouped_gemm_fuzz_vs_fp32_reference_and_across_kernels(n_cases):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_cases", [60, pytest.param(600, marks=pytest.mark.slow)])
+@pytest.mark.parametrize("n_cases", [40, pytest.param(600, marks=pytest.mark.slow)])
 def test_layer_forward_fuzz_vs_oracle(oracle, n_cases):
     bad = run_layer_fuzz(oracle, n_cases, seed=6062)
     assert not bad, "\n".join(bad[:20])
