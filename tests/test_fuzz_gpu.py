@@ -57,6 +57,18 @@ def run_routing_fuzz(oracle, n_cases, seed, verbose=False):
             assert torch.equal(torch.stack(crit[3]).cpu().double(), torch.stack(crit_o[3]).double()), "gates"
             tol = 1e-5 if dtype in (torch.float32, torch.float64) else 2e-2
             assert abs(float(l_aux) - float(l_o)) <= tol * max(1.0, abs(float(l_o))), f"l_aux {float(l_aux)} vs {float(l_o)}"
+            if case % 3 == 0 and dtype != torch.float64:
+                # the fused softmax + top-k form (what the layer launches): scores within a few ulps of softmax, routing exact on the
+                # scores the kernel itself produced
+                from tutel_amd import ops
+                lg = logits.to(dtype)
+                idx_k, gates_k, _, sc_k = ops.gate_topk(lg.cuda(), k, apply_softmax=True, normalize_gate=norm, want_scores=True)
+                ref = torch.softmax(lg.float(), dim=1)
+                stol = {torch.float32: 4e-6, torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11}[dtype]   # (fp32: the order of a 4096-term sum)
+                assert float((sc_k.cpu().float() - ref).abs().max()) <= stol * max(1.0, float(ref.max())) + 1e-7, "fused softmax scores"
+                crit_s, _ = oracle.extract_critical(sc_k.cpu(), k, cf, normalize_gate=norm, alignment=align)
+                assert torch.equal(idx_k.cpu(), torch.stack(crit_s[1]).to(torch.int32)), "fused softmax + top-k: idx"
+                assert torch.equal(gates_k.cpu().double(), torch.stack(crit_s[3]).double()), "fused softmax + top-k: gates"
             if crit[4] > 0 and dtype != torch.float64 and M * E * crit[4] < (1 << 26):
                 x = torch.randn([T, M], generator=g).to(dtype)
                 enc = moe.fast_encode(x.cuda(), crit, is_postscore=post)
