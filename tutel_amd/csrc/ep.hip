@@ -402,11 +402,13 @@ extern "C" int tutel_amd_ep_segment_alloc(size_t bytes, int flag_memory, tutel_a
   TUTEL_REQUIRE(sg != nullptr, "tutel_amd_ep_segment_alloc: out of memory");
   sg->bytes = bytes;
   sg->world = 1;
+  const char *what = "hipGetDevice";   // the call that failed, for the message (ranks sharing one device have shown transient failures here)
   hipError_t e = hipGetDevice(&sg->device);
   if (e == hipSuccess) {
     e = hipErrorInvalidValue;
     // flag words are polled while other agents write them: uncached device memory where the runtime has it (what RCCL uses for
     // its own peer flags), fine-grained next, plain device memory last (the polls are system-scope loads either way)
+    what = "hipExtMallocWithFlags / hipMalloc";
     if (flag_memory) e = hipExtMallocWithFlags(&sg->local, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess && flag_memory) e = hipExtMallocWithFlags(&sg->local, bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess && flag_memory) e = hipMalloc(&sg->local, bytes);
@@ -414,23 +416,26 @@ extern "C" int tutel_amd_ep_segment_alloc(size_t bytes, int flag_memory, tutel_a
       // data segment: the epoch canaries live behind the user bytes, in the SAME allocation (same memory type, same mapping in
       // every peer) -- they are only meaningful if they travel the way the rows do
       sg->canary_off = (bytes + 255) / 256 * 256;
+      what = "hipMalloc";
       e = hipMalloc(&sg->local, sg->canary_off + (size_t)EP_CANARY_WORDS * sizeof(uint32_t));
-      if (e == hipSuccess) e = hipMemset((char *)sg->local + sg->canary_off, 0, (size_t)EP_CANARY_WORDS * sizeof(uint32_t));
-      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e == hipSuccess) { what = "hipMemset"; e = hipMemset((char *)sg->local + sg->canary_off, 0, (size_t)EP_CANARY_WORDS * sizeof(uint32_t)); }
+      if (e == hipSuccess) { what = "hipDeviceSynchronize"; e = hipDeviceSynchronize(); }
     }
   }
   if (e == hipSuccess && flag_memory) {
+    what = "hipMemset";
     e = hipMemset(sg->local, 0, bytes);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) { what = "hipDeviceSynchronize"; e = hipDeviceSynchronize(); }
   }
   if (e == hipSuccess && handle_out != nullptr) {
     hipIpcMemHandle_t h;
+    what = "hipIpcGetMemHandle";
     e = hipIpcGetMemHandle(&h, sg->local);
     if (e == hipSuccess) memcpy(handle_out, &h, sizeof(h));
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    tutel_set_error("tutel_amd_ep_segment_alloc: %s", hipGetErrorString(e));
+    tutel_set_error("tutel_amd_ep_segment_alloc: %s: %s", what, hipGetErrorString(e));
     if (sg->local != nullptr) (void)hipFree(sg->local);
     free(sg);
     return (int)e;
