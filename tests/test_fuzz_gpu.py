@@ -1,8 +1,14 @@
-"""A wide seeded fuzz of the routing -> dispatch -> combine chain against the oracle: the form of
-test_ops_gpu.py::test_routing_randomized_shapes_vs_oracle with expert counts up to the kernels' 4096, k up to 16, capacity alignment, fp64
-scores, tie-heavy rows in every dtype -- every integer, every gate, every encoded / decoded element bit for bit.  150 cases in the default run,
-1500 with --runslow; `python tests/test_fuzz_gpu.py [cases] [seed] [routing|gemm|layer|train|ext]` runs any length and writes gpurun_out/r6_<what>_fuzz_<seed>.json
-(round 6: two seeds x 1500 cases are on record in profiles/)."""
+"""Seeded fuzzers of the single-GPU path, each a `run_*` function returning its failing cases (tests/test_ep_fuzz_one_gpu.py holds the
+expert-parallel one):
+  routing   routing -> dispatch -> combine against the oracle: the form of test_ops_gpu.py::test_routing_randomized_shapes_vs_oracle with
+            expert counts up to the kernels' 4096, k up to 16, capacity alignment, fp64 scores, tie-heavy rows in every dtype -- every
+            integer, every gate, every encoded / decoded element bit for bit; every third case also through the fused softmax + top-k
+  gemm      grouped GEMM vs an fp32 reference and, bit for bit, across a randomly forced kernel choice
+  layer     MOELayer forwards across the eligibility edges of the one-call path (dropless / megablocks, HIP-graph replays)
+  train     training steps: output and all gradients vs the fp32 layer, bar relative to upstream's ATen op sequence
+  ext       cosine top-k gate over SwiGLU experts
+The default run takes 150 / 120 / 40 / 40 / 40 cases, --runslow the full-length forms; `python tests/test_fuzz_gpu.py [cases] [seed] [what]`
+runs any length and writes gpurun_out/r6_<what>_fuzz_<seed>.json (round 6's records, incl. a soak with other seeds: profiles/README.md)."""
 import json
 import os
 import random
@@ -388,10 +394,11 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 6060
     what = sys.argv[3] if len(sys.argv) > 3 else "routing"
-    failed = (run_gemm_fuzz(n, sd, verbose=True) if what == "gemm" else run_layer_fuzz(moe_oracle, n, sd, verbose=True) if what == "layer"
-              else run_training_fuzz(moe_oracle, n, sd, verbose=True) if what == "train"
-              else run_ext_layer_fuzz(moe_oracle, n, sd, verbose=True) if what == "ext"
-              else run_routing_fuzz(moe_oracle, n, sd, verbose=True))
+    runners = {"routing": lambda: run_routing_fuzz(moe_oracle, n, sd, verbose=True), "gemm": lambda: run_gemm_fuzz(n, sd, verbose=True),
+               "layer": lambda: run_layer_fuzz(moe_oracle, n, sd, verbose=True), "train": lambda: run_training_fuzz(moe_oracle, n, sd, verbose=True),
+               "ext": lambda: run_ext_layer_fuzz(moe_oracle, n, sd, verbose=True)}
+    assert what in runners, f"what: one of {sorted(runners)}"
+    failed = runners[what]()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"r6_{what}_fuzz_{sd}.json"), "w") as f:
         json.dump(dict(source="tests/test_fuzz_gpu.py", cases=n, seed=sd, failed=failed), f, indent=1)
