@@ -1119,3 +1119,22 @@ def test_fused_location_keeps_every_bit(oracle, shape, dtype):
     assert torch.equal(got[-1]["idx"].cpu(), torch.stack([t.to(torch.int32) for t in crit[1]]))
     assert torch.equal(got[-1]["loc"].cpu(), torch.stack([t.to(torch.int32) for t in crit[2]]))
     assert torch.equal(got[-1]["cnt"].cpu(), crit[5])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_layer_input_that_starts_at_an_odd_element(oracle, dtype):
+    """a layer input that is a contiguous slice of a larger buffer starting at an odd element (data_ptr % 16 != 0): the forward copies it
+    to an aligned allocation (moe_layer.py) instead of failing in the C ABI -- the same bits as from an aligned input, on the one-call
+    path (bf16) and on the ATen-expert path (fp32)."""
+    T, M, H, E, k = 1000, 128, 256, 16, 2
+    x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=77)
+    layer = make_layer(M, H, E, k, 1.0, dtype, weights).eval()
+    big = torch.empty(T * M + 8, dtype=dtype, device="cuda")
+    with torch.no_grad():
+        want = layer(x.cuda())
+        for off in (1, 3, 5):
+            xv = big[off:off + T * M].view(T, M)
+            xv.copy_(x)
+            assert xv.data_ptr() % 16 != 0
+            y = layer(xv)
+            assert torch.equal(y, want) and float(y.l_aux) == float(want.l_aux), off

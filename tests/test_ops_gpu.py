@@ -817,3 +817,47 @@ def test_gate_projection_uncovered_shapes_say_so():
     wg = torch.zeros([64, 2048], dtype=torch.bfloat16, device="cuda")
     rc = _lib.lib().tutel_amd_gate_proj(x.data_ptr(), wg.data_ptr(), _lib.BF16, 128, 2048, 64, p.data_ptr(), 16, None)
     assert rc != 0 and b"too small" in _lib.lib().tutel_amd_last_error()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_offset_views_are_accepted_as_upstream_accepts_them(oracle, dtype):
+    """Contiguous tensors that START at an odd element of a larger buffer (data_ptr not a multiple of 16): upstream's
+    top_k_routing / fast_encode / fast_decode take them (fast_dispatch.py:208-221 only ask for contiguity), the kernels fetch 16-byte
+    vectors -- the host mirror copies such an activation into an aligned allocation instead of failing the call (ops._a16).  Same bits
+    as from aligned tensors, for every offset; a misaligned WEIGHT tensor is not copied per call and fails loudly."""
+    ops = _ops()
+    from tutel import moe
+    for off in (1, 2, 3, 5, 7):
+        for (T, E, k, M) in [(300, 64, 2, 40), (1000, 16, 2, 128), (129, 200, 3, 64)]:
+            g = torch.Generator().manual_seed(off * 100 + T)
+            scores = torch.softmax(torch.randn(T, E, generator=g), 1).to(dtype)
+            x = torch.randn(T, M, generator=g).to(dtype)
+
+            def view_at(t):
+                b = torch.empty(t.numel() + 8, dtype=t.dtype, device="cuda")
+                v = b[off:off + t.numel()].view(t.shape)
+                v.copy_(t)
+                assert v.is_contiguous() and (v.data_ptr() % 16 != 0 or (off * t.element_size()) % 16 == 0)
+                return v
+            crit_o, _ = oracle.extract_critical(scores, k, 1.0)
+            crit, _ = moe.top_k_routing(view_at(scores), k, capacity_factor=1.0)
+            assert torch.equal(torch.stack(crit[1]).cpu(), torch.stack(crit_o[1])) and torch.equal(torch.stack(crit[2]).cpu(), torch.stack(crit_o[2]))
+            assert torch.equal(torch.stack(crit[3]).cpu().double(), torch.stack(crit_o[3]).double())
+            enc_o = oracle.fast_encode(x, crit_o)
+            enc = moe.fast_encode(view_at(x), crit)
+            assert torch.equal(enc.cpu(), enc_o), (off, T, E, M)
+            dec = moe.fast_decode(view_at(enc.contiguous()), crit)
+            assert torch.equal(dec.cpu(), oracle.fast_decode(enc_o, crit_o)), (off, T, E, M)
+    if dtype in (torch.bfloat16, torch.float16):
+        a = torch.randn([2, 100, 128]).to(dtype)
+        w = (torch.randn([2, 64, 128]) / 11).to(dtype)
+        want = ops.expert_gemm(a.cuda(), w.cuda(), None, True)
+        ab = torch.empty(a.numel() + 8, dtype=dtype, device="cuda")
+        av = ab[3:3 + a.numel()].view(a.shape)
+        av.copy_(a)
+        assert torch.equal(ops.expert_gemm(av, w.cuda(), None, True), want)
+        wb = torch.empty(w.numel() + 8, dtype=dtype, device="cuda")
+        wv = wb[3:3 + w.numel()].view(w.shape)
+        wv.copy_(w)
+        with pytest.raises(Exception, match="16-byte aligned"):
+            ops.expert_gemm(a.cuda(), wv, None, True)

@@ -371,6 +371,8 @@ class MOELayer(torch.nn.Module):
             for p in self.experts.parameters():
                 x = x.to(p.dtype)
                 break
+        if x.is_cuda and x.data_ptr() % 16:
+            x = x.clone()   # an offset view of a larger buffer: the kernels fetch 16-byte vectors, upstream takes any tensor (ops._a16)
         gate = self.gates[gate_index]
         if a2a_ffn_overlap_degree is not None:
             self.a2a_ffn_overlap_degree = a2a_ffn_overlap_degree

@@ -31,6 +31,15 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _a16(t):
+    """an ACTIVATION operand at a 16-byte aligned address: the kernels fetch rows as 16-byte vectors, upstream's take any contiguous
+    tensor -- an offset view (a slice of a larger buffer) is copied into a fresh allocation instead of failing the call.  (Weights are
+    not copied per call: a misaligned parameter tensor fails loudly in the C ABI.)"""
+    if t is None or t.data_ptr() % 16 == 0:
+        return t
+    return t.clone(memory_format=torch.contiguous_format)
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -207,6 +216,7 @@ def fast_encode(x, smap, gates, n_slots, capacity=0, num_experts=0, chunk_rows=0
     chunk_rows / expert_slice select the order of the OUTPUT rows (see fast_decode)."""
     _dev(x, smap, gates)
     assert x.dim() == 2 and x.is_contiguous() and smap.dtype == torch.int32 and smap.numel() == n_slots
+    x = _a16(x)
     T, M = x.shape
     out = torch.empty([n_slots, M], dtype=x.dtype, device=x.device)
     if gates is not None:
@@ -225,6 +235,7 @@ def fast_decode(buf, idx, loc, gates, capacity, num_experts=0, chunk_rows=0, exp
     expert-sliced [E_loc/s, W, s, C, M] (the two layouts of the overlapped all-to-all)."""
     _dev(buf, idx, loc, gates)
     assert buf.dim() == 2 and buf.is_contiguous()
+    buf = _a16(buf)
     assert idx.dtype == torch.int32 and loc.dtype == torch.int32 and idx.is_contiguous() and loc.is_contiguous()
     k, T = idx.shape
     M = buf.shape[1]
@@ -243,6 +254,7 @@ def gate_grad(x, buf, idx, loc, capacity):
     """ggate [k,T] fp32 = <buf[slot(j,t)], x[t]>."""
     _dev(x, buf, idx, loc)
     assert x.is_contiguous() and buf.is_contiguous() and x.dtype == buf.dtype
+    x, buf = _a16(x), _a16(buf)
     k, T = idx.shape
     M = x.shape[1]
     out = torch.empty([k, T], dtype=torch.float32, device=x.device)
@@ -275,6 +287,7 @@ def expert_gemm(a, w, bias, w_kmajor, act="none", E_loc=None, R=None, a_layout=N
     E_loc = El if E_loc is None else E_loc
     if a_layout is None:
         assert a.dim() == 3 and a.is_contiguous() and a.shape[0] == E_loc and a.shape[2] == K
+        a = _a16(a)
         R = a.shape[1]
         a_layout = (R * K, 0, R, K)
     assert R is not None
@@ -314,6 +327,7 @@ def expert_gemm_gather(x, smap, w, bias, w_kmajor, act, R, row_counts=None, row_
     assert x.dim() == 2 and x.is_contiguous() and w.dim() == 3 and w.is_contiguous() and w.dtype == x.dtype
     E_loc, N, K = (w.shape if w_kmajor else (w.shape[0], w.shape[2], w.shape[1]))
     assert x.shape[1] == K and smap.dtype == torch.int32 and smap.numel() == E_loc * R
+    x = _a16(x)
     key = (x.device, x.dtype)
     z = _zero_rows.get(key)
     if z is None or z.numel() < K:
@@ -337,6 +351,7 @@ def expert_ffn(x, w1, b1, w2_kmajor, b2, act, R=None, smap=None, hid=None):
     E_loc, H, M = w1.shape
     M_out = w2_kmajor.shape[1]
     assert w2_kmajor.shape == (E_loc, M_out, H) and x.is_contiguous()
+    x = _a16(x)
     if smap is None:
         assert x.dim() == 3 and x.shape[0] == E_loc and x.shape[2] == M
         R = x.shape[1]
