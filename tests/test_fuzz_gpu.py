@@ -75,8 +75,11 @@ def run_routing_fuzz(oracle, n_cases, seed, verbose=False):
                 crit_s, _ = oracle.extract_critical(sc_k.cpu(), k, cf, normalize_gate=norm, alignment=align)
                 assert torch.equal(idx_k.cpu(), torch.stack(crit_s[1]).to(torch.int32)), "fused softmax + top-k: idx"
                 assert torch.equal(gates_k.cpu().double(), torch.stack(crit_s[3]).double()), "fused softmax + top-k: gates"
-            if crit[4] > 0 and dtype != torch.float64 and M * E * crit[4] < (1 << 26):
-                x = torch.randn([T, M], generator=g).to(dtype)
+            # the data's dtype: the scores' own in every other case, else one of the three the dispatch kernels take (upstream casts the
+            # gates to its fp32 dispatch dtype, fast_dispatch.py:94-128 -- any pairing is legal there)
+            xdt = dtype if (case % 2 == 0 and dtype != torch.float64) else (torch.float32, torch.bfloat16, torch.float16)[(case // 2) % 3]
+            if crit[4] > 0 and M * E * crit[4] < (1 << 26):
+                x = torch.randn([T, M], generator=g).to(xdt)
                 enc = moe.fast_encode(x.cuda(), crit, is_postscore=post)
                 enc_o = oracle.fast_encode(x, crit_o, is_postscore=post)
                 assert torch.equal(enc.cpu(), enc_o), "encode"

@@ -861,3 +861,26 @@ def test_offset_views_are_accepted_as_upstream_accepts_them(oracle, dtype):
         wv.copy_(w)
         with pytest.raises(Exception, match="16-byte aligned"):
             ops.expert_gemm(a.cuda(), wv, None, True)
+
+
+@pytest.mark.parametrize("M", [100, 36, 104])
+def test_fp16_rows_under_fp32_gates_round_twice_as_the_reference_does(oracle, M):
+    """fp16 data scaled by fp32 gates (any pairing is legal upstream: it dispatches in fp32, fast_dispatch.py:94-128): the product is
+    rounded to fp32 and THAT is narrowed to fp16.  On the per-element path (model_dim % 8 != 0) hipcc had folded the multiply and the
+    narrowing into v_fma_mixlo_f16 -- one rounding of the exact product -- which differs in ~1e-4 of the elements when the gate has more
+    than 11 significant bits (found by the mixed-dtype cases of tests/test_fuzz_gpu.py).  Encode (pre-scored) and decode (post-scored),
+    per-element (100, 36) and vector (104) paths, against the oracle bit for bit."""
+    from tutel import moe
+    T, E, k = 20000, 16, 2
+    g = torch.Generator().manual_seed(M)
+    scores = torch.softmax(torch.randn(T, E, generator=g), 1)            # fp32: 24 significant bits
+    x = torch.randn(T, M, generator=g).half()
+    crit_o, _ = oracle.extract_critical(scores, k, 2.0)
+    crit, _ = moe.top_k_routing(scores.cuda(), k, capacity_factor=2.0)
+    enc_o = oracle.fast_encode(x, crit_o, is_postscore=False)
+    enc = moe.fast_encode(x.cuda(), crit, is_postscore=False)
+    assert enc.dtype == torch.float16 and torch.equal(enc.cpu(), enc_o), int((enc.cpu() != enc_o).sum())
+    y = torch.randn(enc_o.shape, generator=g).half()
+    dec_o = oracle.fast_decode(y, crit_o, is_postscore=True)
+    dec = moe.fast_decode(y.cuda(), crit, is_postscore=True)
+    assert torch.equal(dec.cpu(), dec_o), int((dec.cpu() != dec_o).sum())

@@ -29,6 +29,15 @@ __device__ __forceinline__ float load_gate(const void *g, int gate_dtype, size_t
 // -------------------------------------------------------------------------------------------
 // encode
 // -------------------------------------------------------------------------------------------
+// an fp32 intermediate that must EXIST as an fp32 value before it is narrowed: without it hipcc folds (_Float16)(g * (float)h) of the
+// per-element (model_dim % 8 != 0) paths into v_fma_mixlo_f16 -- the exact product rounded ONCE, to fp16 -- where the reference rounds
+// the product to fp32 first and narrows that (it dispatches in fp32, fast_dispatch.py:94-96).  The two differ when the gate carries more
+// than 11 significant bits: fp32 gates over fp16 rows, found by the mixed-dtype cases of tests/test_fuzz_gpu.py.  No instruction.
+__device__ __forceinline__ float f32_value(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 template <typename T>
 __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict__ x,
                                                            const int32_t *__restrict__ slot_map,
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(DP_THREADS) void encode_kernel(const T *__restrict_
           ENC_ST16(d, i, v);
         }
       } else {
-        for (int i = lane; i < M; i += 64) dst[i] = Elem<T>::from_f32(mul_rn(g, Elem<T>::to_f32(src[i])));
+        for (int i = lane; i < M; i += 64) dst[i] = Elem<T>::from_f32(f32_value(mul_rn(g, Elem<T>::to_f32(src[i]))));
       }
     }
 #undef ENC_ST16
@@ -240,10 +249,10 @@ __device__ __forceinline__ void decode_body(const T *__restrict__ buf, const int
       for (int i = lane; i < M; i += 64) {
         float acc = 0.f;
         for (int j = 0; j < k && j < KMAX; ++j) {
-          float f = rows[j] ? mul_rn(g[j], Elem<T>::to_f32(rows[j][i])) : 0.f;
+          float f = rows[j] ? f32_value(mul_rn(g[j], Elem<T>::to_f32(rows[j][i]))) : 0.f;
           acc = (j == 0) ? f : add_rn(acc, f);
         }
-        dst[i] = Elem<T>::from_f32(acc);
+        dst[i] = Elem<T>::from_f32(f32_value(acc));
       }
     }
   }
@@ -302,11 +311,11 @@ __global__ __launch_bounds__(DP_THREADS) void decode_anyk_kernel(const T *__rest
           const size_t r = (chunk_rows > 0) ? ((size_t)(l / chunk_rows) * num_experts + e) * chunk_rows + (l % chunk_rows)
                                             : (size_t)e * capacity + l;
           const float g = gates ? load_gate(gates, gate_dtype, (size_t)j * Tn + t) : 1.0f;
-          f = mul_rn(g, Elem<T>::to_f32(buf[r * M + i]));
+          f = f32_value(mul_rn(g, Elem<T>::to_f32(buf[r * M + i])));
         }
         acc = (j == 0) ? f : add_rn(acc, f);
       }
-      dst[i] = Elem<T>::from_f32(acc);
+      dst[i] = Elem<T>::from_f32(f32_value(acc));
     }
   }
 }
