@@ -132,6 +132,7 @@ def run_gemm_fuzz(n_cases, seed, verbose=False):
         impl, tile = rnd.choice([-1, 0, 1, 4]), rnd.choice([-1, 0, 1, 2, 3, 4])
         tag = f"gemm case {case}: E={E} R={R} N={N} K={K} kmajor={kmajor} act={act} {dtype} bias={with_bias} gather={gather} impl={impl} tile={tile}"
         g = torch.Generator().manual_seed(seed * 7919 + case)
+        counts, row_align = None, 1
         w = ((torch.rand([E, N, K] if kmajor else [E, K, N], generator=g) * 2 - 1) / math.sqrt(K)).to(dtype)
         bias = torch.randn([E, N], generator=g).to(dtype) if with_bias else None
         try:
@@ -143,7 +144,20 @@ def run_gemm_fuzz(n_cases, seed, verbose=False):
                 run = lambda: ops.expert_gemm_gather(x.cuda(), smap.cuda(), w.cuda(), bias.cuda() if with_bias else None, kmajor, act, R).cpu()
             else:
                 a = torch.randn([E, R, K], generator=g).to(dtype)
-                run = lambda: ops.expert_gemm(a.cuda(), w.cuda(), bias.cuda() if with_bias else None, kmajor, act=act).cpu()
+                if case % 4 == 1:
+                    # dropless row counts (sparse_bmm_infer, custom_kernel.cpp:874-889): rows past an expert's count, rounded up to
+                    # row_align, are neither computed nor written -- a sentinel must survive there, the rows before it must be right
+                    row_align = (1, 4, 32)[(case // 4) % 3]
+                    counts = torch.randint(0, R + 1, (E,), generator=g, dtype=torch.int32)
+                    counts[case % E] = (0, R)[(case // 8) % 2]
+
+                    def run():
+                        o = torch.full([E, R, N], 3.0, dtype=dtype, device="cuda")
+                        ops.expert_gemm(a.cuda(), w.cuda(), bias.cuda() if with_bias else None, kmajor, act=act, out=o, d_layout=(R * N, 0, R, N),
+                                        row_counts=counts.cuda(), row_align=row_align)
+                        return o.cpu()
+                else:
+                    run = lambda: ops.expert_gemm(a.cuda(), w.cuda(), bias.cuda() if with_bias else None, kmajor, act=act).cpu()
             auto = run()
             ops.set_option(_lib.OPT_GEMM_IMPL, impl)
             ops.set_option(_lib.OPT_GEMM_TILE, tile)
@@ -157,6 +171,11 @@ def run_gemm_fuzz(n_cases, seed, verbose=False):
                 ref = ref + bias.float().unsqueeze(1)
             ref = acts[act](ref).to(dtype).float()
             tol = dict(rtol=2 ** -7, atol=2e-3) if dtype == torch.bfloat16 else dict(rtol=2 ** -10, atol=3e-4)
+            if counts is not None:
+                for e in range(E):
+                    n = min(R, (int(counts[e]) + row_align - 1) // row_align * row_align)
+                    assert bool((auto[e, n:] == 3.0).all()), f"expert {e}: rows past the aligned count {n} were written"
+                    ref[e, n:] = 3.0
             torch.testing.assert_close(auto.float(), ref, **tol)
             assert torch.equal(auto.view(torch.int16), forced.view(torch.int16)), f"forced kernel differs from the automatic one in {int((auto.view(torch.int16) != forced.view(torch.int16)).sum())} elements"
         except Exception as ex:  # noqa: BLE001
@@ -195,7 +214,15 @@ def run_layer_fuzz(oracle, n_cases, seed, verbose=False):
             x, *weights = oracle.make_problem(T, M, H, E, dtype=dtype, seed=seed * 31 + case)
             layer = make_layer(M, H, E, k, cf, dtype, weights, gate={"fp32_gate": fp32_gate}, normalize_gate=norm, is_postscore=post).eval()
             layer._keep_routing, layer.last_logits = True, None
-            xd = x.cuda()
+            if case % 3 == 1:
+                # an input of another dtype than the experts': cast to the parameters' dtype on the way in, the result back on the way out
+                # (moe_layer.py:264-270, 359-361) -- widened for 16-bit experts, narrowed to bf16 for fp32 experts
+                in_dtype = torch.float32 if dtype != torch.float32 else torch.bfloat16
+                x_in = x.to(in_dtype)
+                x = x_in.to(dtype)
+            else:
+                in_dtype, x_in = dtype, x
+            xd = x_in.cuda()
             if (k * int(cf * ((T + E - 1) // E)) if cf > 0 else 1) == 0:
                 # capacity 0: upstream's forward fails on an ambiguous reshape of the empty buckets (moe_layer.py:218 / fast_dispatch.py:214),
                 # and so does this one -- the same RuntimeError, not a silent result
@@ -204,7 +231,7 @@ def run_layer_fuzz(oracle, n_cases, seed, verbose=False):
                 continue
             with torch.no_grad():
                 y = layer(xd, megablocks_size=mega)
-                logits = layer.last_logits if layer.last_logits is not None else layer.gates[0](xd)
+                logits = layer.last_logits if layer.last_logits is not None else layer.gates[0](xd.to(dtype))
                 scores = ops.gate_topk(logits.contiguous(), k, apply_softmax=True, want_scores=True)[3].cpu()
             # (upstream rounds the capacity up to megablocks_size where that mode is live: more than one local expert, moe_layer.py:278-300)
             crit, l_o = oracle.extract_critical(scores, k, cf, normalize_gate=norm, alignment=mega if (mega > 0 and E > 1) else 1)
@@ -221,7 +248,11 @@ def run_layer_fuzz(oracle, n_cases, seed, verbose=False):
             mfma = dtype != torch.float32 and M % 64 == 0 and H % 64 == 0
             ffn = oracle.expert_ffn(enc, w1, b1, w2, b2, accum_fp32=mfma)
             yo = oracle.fast_decode(ffn.to(scores.dtype), crit, post).to(dtype)
-            _close(y.view(T, -1), yo, dtype, vs_lowprec_reference=not mfma)
+            assert y.dtype == in_dtype, f"output dtype {y.dtype}, input {in_dtype}"
+            if in_dtype == dtype or in_dtype == torch.float32:
+                _close(y.view(T, -1).to(dtype), yo, dtype, vs_lowprec_reference=not mfma)     # (widening the result back is exact)
+            else:
+                _close(y.view(T, -1), yo.to(in_dtype), in_dtype, vs_lowprec_reference=True)   # fp32 experts, output narrowed to bf16
             if cf > 0 and case % 4 == 0:
                 # every fourth capturable case: the forward as a HIP graph -- replays on the example and on another batch must carry the
                 # eager forward's bits (dropless routing reads its capacity back to the host and refuses capture, impls/graph.py)
