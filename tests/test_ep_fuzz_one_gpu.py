@@ -41,8 +41,9 @@ def _fuzz_worker(rank, world, port, native, n_cases, seed, q):
             norm, post = rnd.random() < 0.7, rnd.random() < 0.7
             uneq = rnd.random() < 0.2
             Ts = [max(1, T - rnd.randrange(0, T // 2)) if (uneq and r > 0) else T for r in range(world)]
+            use_2dh = case % 5 == 4      # the two-phase (intra-node, inter-node) all-to-all of BASELINE configs[4]: same values, another route
             tag = (f"case {case}: W={world} T={Ts} M={M} H={H} E_loc={E_loc} k={k} cf={cf} degree={degree} {dtype} norm={norm} post={post} "
-                   f"transport={native}")
+                   f"use_2dh={use_2dh} transport={native}")
             xs = [O.make_problem(Ts[r], M, H, E, dtype=dtype, seed=seed * 1009 + case * 16 + r)[0] for r in range(world)]
             _, wg, w1, b1, w2, b2 = O.make_problem(8, M, H, E, dtype=dtype, seed=seed * 1009 + case * 16 + 15)
             sl = slice(rank * E_loc, (rank + 1) * E_loc)
@@ -51,7 +52,7 @@ def _fuzz_worker(rank, world, port, native, n_cases, seed, q):
             layer = moe.moe_layer(gate_type={"type": "top", "k": k, "fp32_gate": True, "capacity_factor": cf}, model_dim=M,
                                   experts={"type": "ffn", "num_experts_per_device": E_loc, "hidden_size_per_expert": H,
                                            "activation_fn": lambda t: torch.nn.functional.relu(t)},
-                                  a2a_ffn_overlap_degree=degree, normalize_gate=norm, is_postscore=post)
+                                  a2a_ffn_overlap_degree=degree, normalize_gate=norm, is_postscore=post, use_2dh=use_2dh)
             torch.set_default_dtype(old)
             with torch.no_grad():
                 layer.gates[0].wg.weight.copy_(wg.float())
