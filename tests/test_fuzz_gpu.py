@@ -293,7 +293,9 @@ def run_training_fuzz(oracle, n_cases, seed, verbose=False):
         cf = rnd.choice([1.0, 1.0, 2.0, 0.5, 1.25])
         dtype = rnd.choice([torch.bfloat16, torch.float16])
         norm, post = rnd.random() < 0.7, rnd.random() < 0.7
-        if k * int(cf * ((T + E - 1) // E)) == 0:
+        if case % 7 == 3:
+            cf = (0.0, -1.5)[(case // 7) % 2]     # dropless / clamped dropless: the capacity follows the largest expert load
+        if cf > 0 and k * int(cf * ((T + E - 1) // E)) == 0:
             continue
         tag = f"train case {case}: T={T} M={M} H={H} E={E} k={k} cf={cf} {dtype} norm={norm} post={post}"
         fused_was = ffn._TRAIN_FUSED
